@@ -1,0 +1,159 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from
+/root/reference, never copied) on seeded inputs.  Development container only:
+the reference does not travel to the GPU box; the fixtures do.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Rules: torch.no_grad(); clone block lists before decoding
+(the reference decoder overwrites its input, quirk A1); clone X before the
+phasemix path (quirk A2); fixed thread count.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from xumx_slicq_amd.synth import synth_audio
+from xumx_slicq_amd.weights import seeded_state_dict
+
+OUT = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 1234
+
+
+def checksums(t: torch.Tensor):
+    a = t.detach().double().flatten()
+    return np.array([float(a.sum()), float((a * a).sum()), float(a.abs().max())])
+
+
+def main():
+    torch.set_num_threads(8)
+    from xumx_slicq_v2.transforms import NSGTBase, make_filterbanks, ComplexNorm
+    from xumx_slicq_v2.model import Unmix
+    from xumx_slicq_v2.phase import blockwise_wiener
+    from xumx_slicq_v2.separator import Separator
+
+    os.makedirs(OUT, exist_ok=True)
+    base = NSGTBase("bark", 262, 32.9, fs=44100.0, device="cpu")
+    enc, dec = make_filterbanks(base, 44100.0)
+    ns = base.nsgt
+    nb = ns.fbins_actual
+
+    # ---- (1) plan ---------------------------------------------------------
+    Lg = np.array([len(g) for g in ns.g[:nb]], dtype=np.int32)
+    assert np.array_equal(Lg, np.array([int(m) for m in ns.M[:nb]]))
+    c = np.array([int(w[len(w) // 2]) for w in ns.wins[:nb]], dtype=np.int32)  # centre bin mod L
+    from xumx_slicq_v2.nsgt.slicing import makewnd
+    tw = makewnd(base.sllen, base.trlen).numpy()
+    with torch.no_grad():
+        jag, _ = base.predict_input_size(1, 2, 2.0)
+    blocks = np.array([[b.shape[2], b.shape[4]] for b in jag], dtype=np.int32)
+    np.savez_compressed(
+        os.path.join(OUT, "plan.npz"),
+        L=base.sllen, tr=base.trlen, nbands=nb, Lg=Lg, c=c, blocks=blocks, tw=tw,
+        g=np.concatenate([g.numpy() for g in ns.g[:nb]]).astype(np.float32),
+        gd=np.concatenate([g.numpy() for g in ns.gd[:nb]]).astype(np.float64),
+        seq_dur_slices=jag[0].shape[3],
+    )
+
+    # ---- (2)+(3) forward / inverse ---------------------------------------
+    keep_blocks = [0, 1, 2, 4, 33, 69]
+    for n in (9031, 70000):
+        x = synth_audio(n, seed=20260101 + n)
+        with torch.no_grad():
+            C = enc(x)
+            rng = np.random.default_rng(n)
+            P = [cb + torch.from_numpy(
+                (0.1 * rng.standard_normal(cb.shape)).astype(np.float32)) for cb in C]
+            y = dec([p.clone() for p in P], n)
+        d = dict(n=n, S=C[0].shape[3],
+                 fwd_sums=np.stack([checksums(cb) for cb in C]),
+                 pert_sums=np.stack([checksums(p) for p in P]),
+                 inv=y.numpy())
+        if n == 9031:
+            for i, cb in enumerate(C):
+                d[f"fwd_{i}"] = cb.numpy()
+        else:
+            for i in keep_blocks:
+                d[f"fwd_{i}"] = C[i].numpy()
+        np.savez_compressed(os.path.join(OUT, f"slicqt_{n}.npz"), **d)
+
+    # ---- model with seeded weights -----------------------------------------
+    sd = seeded_state_dict([tuple(b) for b in blocks.tolist()], seed=WEIGHT_SEED)
+    cnorm = ComplexNorm()
+
+    def build(realtime_conv: bool, phasemix: bool):
+        m = Unmix(cnorm(jag), realtime=realtime_conv)
+        missing, unexpected = m.load_state_dict(sd, strict=True), None
+        m.freeze()
+        for blk in m.sliced_umx:         # flag read at model.py:264
+            blk.realtime = phasemix
+        return m
+
+    models = {
+        "realtime": build(True, True),       # config 1: causal conv + phasemix
+        "offline_phasemix": build(False, True),   # config 2: offline conv + phasemix
+        "offline_wiener": build(False, False),    # config 3: offline conv + Wiener-EM
+    }
+
+    # ---- (4) per-block CDAE masks ------------------------------------------
+    n = 70000
+    x = synth_audio(n, seed=20260101 + n)
+    d = dict(n=n, blocks=np.array(keep_blocks))
+    with torch.no_grad():
+        C = enc(x)
+        for name in ("realtime", "offline_wiener"):
+            _, masks = models[name]([cb.clone() for cb in C], return_masks=True)
+            for i in keep_blocks:
+                d[f"mask_{'causal' if name == 'realtime' else 'offline'}_{i}"] = masks[i].numpy()
+            d[f"mask_sums_{'causal' if name == 'realtime' else 'offline'}"] = np.stack(
+                [checksums(m) for m in masks])
+    np.savez_compressed(os.path.join(OUT, "cdae_masks_70000.npz"), **d)
+
+    # ---- (5) blockwise_wiener ----------------------------------------------
+    rng = np.random.default_rng(5)
+    mix = torch.from_numpy(rng.standard_normal((1, 2, 2, 26, 200, 2)).astype(np.float32))
+    mag = torch.from_numpy(np.abs(rng.standard_normal((4, 1, 2, 2, 26, 200))).astype(np.float32))
+    with torch.no_grad():
+        yw = blockwise_wiener(mix.clone(), mag.clone(), 5000)
+    rng = np.random.default_rng(6)   # the reference's own test shape, tests/test_phase.py:6-12
+    mix2 = torch.from_numpy(rng.standard_normal((1, 2, 14, 257, 37, 2)).astype(np.float32))
+    mag2 = torch.from_numpy(rng.standard_normal((4, 1, 2, 14, 257, 37)).astype(np.float32))
+    with torch.no_grad():
+        yw2 = blockwise_wiener(mix2.clone(), mag2.clone(), 5000)
+    assert yw2.shape == (4, 1, 2, 14, 257, 37, 2) and torch.all(torch.isfinite(yw2))
+    np.savez_compressed(os.path.join(OUT, "wiener.npz"),
+                        out_5200=yw.numpy(),
+                        out_testphase_sums=checksums(yw2),
+                        out_testphase_sub=yw2.flatten()[::97].numpy())
+
+    # ---- (6) end-to-end stems ----------------------------------------------
+    for n in (9031, 100000):
+        x = synth_audio(n, seed=20260101 + n)
+        d = dict(n=n)
+        for name, m in models.items():
+            sep = Separator(xumx_model=m, encoder=(enc, dec, cnorm), runtime_backend="torch-cpu",
+                            chunk_size=2621440 if n < 50000 else 60000, quiet=True)
+            sep.freeze()
+            with torch.no_grad():
+                est = sep(x.clone())
+            assert est.shape == (4, 1, 2, n)
+            d[f"{name}_sums"] = np.stack([checksums(est[t]) for t in range(4)])
+            d[f"{name}"] = est.numpy() if n == 9031 else est[..., ::7].contiguous().numpy()
+        d["chunk_size"] = 2621440 if n < 50000 else 60000
+        np.savez_compressed(os.path.join(OUT, f"stems_{n}.npz"), **d)
+
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

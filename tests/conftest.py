@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def oracle_plan():
+    from oracle import slicqt
+    return slicqt.make_plan()
+
+
+@pytest.fixture(scope="session")
+def seeded_sd(oracle_plan):
+    from xumx_slicq_amd.weights import seeded_state_dict
+    return seeded_state_dict([(F, T) for (_, F, T) in oracle_plan.blocks], seed=1234)
