@@ -1,0 +1,96 @@
+/*
+ * xumx_slicq_hip.h -- C ABI of the MI355X (gfx950) demix hot path of xumx-sliCQ-V2.
+ *
+ * The reference (sevagh/xumx-sliCQ, branch v2) is pure Python/PyTorch and has no FFI
+ * layer; its boundary for this path is the nn.Module surface of
+ *   xumx_slicq_v2/transforms.py  (NSGT_SL.forward :106-131, INSGT_SL.forward :154-178)
+ *   xumx_slicq_v2/model.py       (Unmix.forward :69-82, _SlicedUnmixCDAE.forward :213-271)
+ *   xumx_slicq_v2/phase.py       (blockwise_wiener :18-69, blockwise_phasemix_sep :96-113)
+ *   xumx_slicq_v2/separator.py   (Separator.forward :133-232)
+ * This library sits directly under the Python mirrors of those modules
+ * (xumx_slicq_amd/ *.py bind it with ctypes; INTEGRATION.md shows the stub a maintainer
+ * of the reference would add).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only; no torch types.
+ *  - every data pointer is DEVICE memory owned by the caller (tensor.data_ptr() of a
+ *    contiguous fp32 tensor); the library never frees caller memory.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *    Calls are asynchronous on that stream; nothing synchronises the device.
+ *  - return value: 0 on success, negative XSQ_ERR_* otherwise; xsq_last_error() gives
+ *    the message of the calling thread's last failure.  Nothing throws across the ABI.
+ *  - a plan / model is immutable after creation; workspaces are per call, so one plan
+ *    can serve several streams as long as each call has its own workspace.
+ *
+ * Coefficient arena ("ragged blocks in one allocation")
+ *  The sliCQT of `BC` packed channels with `S` slices is ONE fp32 buffer holding the
+ *  reference's list of per-block tensors back to back: block b (F_b bins x T_b
+ *  coefficients per slice) starts at float offset 2*BC*S*cum_b, cum_b = sum_{b'<b} F_b'*T_b',
+ *  and is laid out (BC, F_b, S, T_b, 2) contiguous -- exactly the tensor
+ *  NSGT_SL.forward returns for that block, so Python exposes views, not copies.
+ *  xsq_plan_block_table() returns (first_band, F_b, T_b, cum_b) per block.
+ */
+#ifndef XUMX_SLICQ_HIP_H
+#define XUMX_SLICQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XSQ_ABI_VERSION 1
+
+typedef struct xsq_plan xsq_plan;
+typedef struct xsq_model xsq_model;
+
+/* ---- library ---------------------------------------------------------------- */
+int xsq_abi_version(void);
+const char* xsq_last_error(void);
+
+/* ---- sliCQT plan ---------------------------------------------------------------
+ * Replaces the plan objects built by NSGT_sliced.__init__ (nsgt/slicq.py:70-151):
+ * window lengths M / windows g (nsgt/nsgfwin_sl.py:8-111), centre bins and index
+ * ranges (nsgt/util.py:72-100), dual windows gd (nsgt/util.py:103-116), slice window
+ * (nsgt/slicing.py:7-18).  The host computes those tables (xumx_slicq_amd/plan.py);
+ * this call uploads them and builds the per-band DFT matrices.
+ *   Lg[nbands], c[nbands]   band lengths and centre bins (bands DC..Nyquist)
+ *   g   concatenated analysis windows (sum Lg floats), peak at index 0 of each band
+ *   gd  concatenated dual windows (sum Lg doubles), same order
+ *   tw  slice (Tukey) window, L floats                                               */
+int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg,
+                    const int32_t* c, const float* g, const double* gd, const float* tw);
+int xsq_plan_destroy(xsq_plan* plan);
+int xsq_plan_num_blocks(const xsq_plan* plan);
+/* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
+int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);
+/* complex coefficients per channel-slice (sum_b F_b*T_b) */
+int64_t xsq_plan_coefs_per_slice(const xsq_plan* plan);
+/* slices of an n-sample signal (nsgt/slicing.py:47-72): floor((ceil(n/h)+1)/2)+1 */
+int xsq_plan_num_slices(const xsq_plan* plan, int64_t n);
+
+/* ---- forward sliCQT -----------------------------------------------------------
+ * Replaces NSGT_SL.forward (transforms.py:106-131) -> NSGT_sliced.forward
+ * (nsgt/slicq.py:182-196): slicing+Tukey (nsgt/slicing.py:21-72), L-point FFT and
+ * per-band window * gather * IFFT (nsgt/nsgtf.py:7-84), arrange (nsgt/slicq.py:13-33).
+ *   x     (BC, n) fp32 packed channels        coef  arena for BC channels, S slices  */
+size_t xsq_slicqt_forward_workspace(xsq_plan* plan, int BC, int64_t n);   /* 0 on error */
+int xsq_slicqt_forward(xsq_plan* plan, const float* x, int BC, int64_t n, float* coef,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- inverse sliCQT -----------------------------------------------------------
+ * Replaces INSGT_SL.forward (transforms.py:154-178) -> NSGT_sliced.backward
+ * (nsgt/slicq.py:198-230): per-band FFT, dual-window multiply and overlap-add into the
+ * slice spectrum (nsgt/nsigtf.py:5-106), irfft, un-rotate + overlap-add of slices
+ * (nsgt/unslicing.py:6-69), crop to `length`.  Does NOT modify `coef` (the reference
+ * decoder overwrites its input).
+ *   coef  arena for BC channels, S slices     y  (BC, length) fp32                    */
+size_t xsq_slicqt_inverse_workspace(xsq_plan* plan, int BC, int S);       /* 0 on error */
+int xsq_slicqt_inverse(xsq_plan* plan, const float* coef, int BC, int S, int64_t length,
+                       float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XUMX_SLICQ_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI in include/xumx_slicq_hip.h.
+
+The HIP library is the product: there is NO CPU fallback.  Importing this
+module without the built library raises immediately with build instructions,
+and every call checks its status code and raises ``XsqError`` with the
+library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must come first: it loads the ROCm runtime this library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxumx_slicq_hip.so")
+
+
+class XsqError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise XsqError(
+            f"{LIB_PATH} is missing: the HIP extension is the product path and has no CPU "
+            "fallback. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C xumx_slicq_amd/csrc`.")
+    # torch has already mapped its own libamdhip64.so / librocfft.so (same SONAMEs as the
+    # system ROCm ones this library was linked against), so the loader resolves our
+    # NEEDED entries to the copies torch uses and both sides share one HIP runtime.
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_vp = C.c_void_p
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+_SIGS = {
+    "xsq_abi_version": (C.c_int, []),
+    "xsq_last_error": (C.c_char_p, []),
+    "xsq_plan_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "xsq_plan_destroy": (C.c_int, [_vp]),
+    "xsq_plan_num_blocks": (C.c_int, [_vp]),
+    "xsq_plan_block_table": (C.c_int, [_vp, _vp]),
+    "xsq_plan_coefs_per_slice": (C.c_int64, [_vp]),
+    "xsq_plan_num_slices": (C.c_int, [_vp, C.c_int64]),
+    "xsq_slicqt_forward_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int64]),
+    "xsq_slicqt_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
+}
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_SIGS)
+
+
+def last_error() -> str:
+    return (lib.xsq_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise XsqError(f"{what} failed ({rc}): {last_error()}")
+
+
+def stream_ptr() -> int:
+    """The HIP stream torch is currently issuing work on."""
+    return torch.cuda.current_stream().cuda_stream

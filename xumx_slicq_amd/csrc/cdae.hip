@@ -1,0 +1,540 @@
+// Per-block convolutional denoising auto-encoders (CDAE) of xumx-sliCQ-V2 for gfx950.
+//
+// Reference: xumx_slicq_v2/model.py:213-271 (_SlicedUnmixCDAE.forward), layer stack :130-181,
+// causal first layer :274-290, phasemix phase.py:96-113 (== mask * X).
+// Per block b (F bins, W = T_b coefficients per slice, hop = W/2, kf = freq kernel) and target:
+//   xin  = (|X| + input_mean[f]) * input_scale[f]                       k_magnitude_whiten
+//   L1   Conv2d(2->50,(kf,W),stride(1,hop)) + BN + ReLU      GEMM  M=(b,f1,t1)  K=(ci,df,dt)    N=50
+//   L2   Conv2d(50->51,(kf,4)) + BN + ReLU                   GEMM  M=(b,f2,t2)  K=(df,dt,c1)    N=51
+//   L3   ConvTranspose2d(51->50,(kf,4)) + BN + ReLU          GEMM  M=(b,f3,t3)  K=(df,dt',c2)   N=50
+//   L4   ConvTranspose2d(50->2,(kf,W),stride(1,hop)) + bias  GEMM  M=(b,f4,u)   K=(df,tap,c3)   N=(c,dt<hop)
+//        + sigmoid -> mask;  Y[target] = mask * X  (complex)   fused epilogue
+// BatchNorm (eval, eps 1e-5) is folded into the weights (scale) and a per-channel shift.
+// Activations are channels-last with a channel stride of 52 floats (16-byte rows), so every
+// K-run of an implicit-GEMM row is one contiguous, aligned span; all 70 blocks x 4 targets
+// of a layer run in ONE grouped launch driven by a tile table.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xumx_slicq_hip.h"
+#include "gemm_tile.h"
+#include "plan.h"
+
+namespace xsq {
+
+static const int H1 = 50, H2 = 51, CS = 52;  // hidden sizes (model.py:92-93), padded channel stride
+static const int NT = 4;                      // targets
+
+struct CdaeBlockDev {
+    int F, T, hop, kf, F1, F2;
+    int cumF1, cumF2;     // sums over earlier blocks of F1, F2 (activation arena offsets)
+    int ld4;              // leading dimension of the layer-4 matrix: round_up(T, 64)
+    int pad;
+    int64_t cum;          // sum over earlier blocks of F*T
+    int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
+    int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
+    int64_t s1[NT], s2[NT], s3[NT], b4[NT];   // float offsets of shift vectors (64) / output bias (2)
+};
+
+}  // namespace xsq
+
+struct xsq_model {
+    xsq_plan* plan = nullptr;
+    int causal = 0;
+    int nblocks = 0;
+    std::vector<xsq::CdaeBlockDev> blocks;
+    int64_t sumF = 0, sumF1 = 0, sumF2 = 0;
+    xsq::CdaeBlockDev* d_blocks = nullptr;
+    float* d_pool = nullptr;       // all folded weights / shifts
+    float* d_mean = nullptr;       // (sumF) input_mean  (stored as -mean by the reference)
+    float* d_scale = nullptr;      // (sumF) input_scale (stored as 1/std)
+    int64_t* d_cum = nullptr;      // (nblocks+1) cumulative F*T, for the elementwise kernels
+    int* d_blockF = nullptr;       // (nblocks)
+    std::mutex mu;
+    std::map<std::tuple<int, int, int>, xsq::TileTable> tiles;   // (layer, B, S)
+};
+
+namespace xsq {
+
+// ------------------------------------------------------------------------------------------
+// |X| + whitening.  One thread per complex coefficient of the 2B-channel arena.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_magnitude_whiten(const float2* __restrict__ X, float* __restrict__ xin,
+                                                           const int64_t* __restrict__ cum,
+                                                           const int* __restrict__ blockF,
+                                                           const CdaeBlockDev* __restrict__ blocks,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ scale, int nblocks,
+                                                           int BC, int S, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    // block lookup: arena offset of block b is BC*S*cum[b]
+    const int64_t per = (int64_t)BC * S;
+    int lo = 0, hi = nblocks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (per * cum[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const CdaeBlockDev b = blocks[lo];
+    const int64_t r = i - per * cum[lo];
+    const int f = (int)((r / ((int64_t)S * b.T)) % b.F);
+    const float2 z = X[i];
+    const float mag = sqrtf(z.x * z.x + z.y * z.y);
+    xin[i] = (mag + mean[b.cumF + f]) * scale[b.cumF + f];
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit-GEMM operators.  group id = block*4 + target.
+// ------------------------------------------------------------------------------------------
+struct CdaeGroup {
+    int M, N, K, ldb;
+    const float* B;
+    const float* shift;
+    const float* in;     // input activation base for this (block[,target])
+    float* out;          // output activation base
+    int Fo, To;          // output rows / time positions per batch item
+    int Fi, Ti;          // input extents (bounds of the transposed convolutions)
+    int F, T, hop, kf, tgt;
+    int64_t cum;
+};
+
+struct CdaeArgs {
+    const CdaeBlockDev* blocks;
+    const float* pool;
+    const float* xin;     // whitened magnitude, arena layout (2B channels, real)
+    float* act1;          // (block, target, B, F1, T1, 52)
+    float* act2;          // (block, target, B, F2, T2, 52)
+    float* act3;          // (block, target, B, F1, T1, 52)
+    const float* X;       // mix coefficients (complex arena, 2B channels)
+    float* Y;             // estimates (complex arena, 8B channels, targets first)
+    float* masks;         // optional real arena (8B channels), nullptr to skip
+    int Bn, S, T1, T2, causal;
+};
+
+struct RowFT {
+    const float* p;   // row base pointer (may be out of range for transposed convs; checked per load)
+    int f, t;         // row's frequency / time coordinate
+};
+
+__device__ inline void split_row(int m, int Fo, int To, int& b, int& f, int& t) {
+    const int per = Fo * To;
+    b = m / per;
+    const int r = m - b * per;
+    f = r / To;
+    t = r - f * To;
+}
+
+// ---- layer 1 -----------------------------------------------------------------------------
+struct CdaeL1Op {
+    typedef CdaeGroup Group;
+    typedef RowFT RowA;
+    CdaeArgs a;
+    __device__ Group group(int gid) const {
+        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const int tgt = gid & 3;
+        Group g;
+        g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
+        g.Fo = b.F1; g.To = a.T1; g.Fi = b.F; g.Ti = a.S * b.T;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = 2 * b.kf * b.T; g.ldb = 64;
+        g.B = a.pool + b.w1[tgt]; g.shift = a.pool + b.s1[tgt];
+        g.in = a.xin + (int64_t)a.Bn * 2 * a.S * b.cum;
+        g.out = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
+        return g;
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        if (m >= g.M) return r;
+        int b, f, t;
+        split_row(m, g.Fo, g.To, b, f, t);
+        r.f = f;
+        r.t = t * g.hop - (a.causal ? g.T - 1 : 0);          // first input sample of the window
+        r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
+        return r;
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r.p == nullptr || k >= g.K) return v;
+        const int seg = k / g.T, dt = k - seg * g.T;          // seg = ci*kf + df
+        const int ci = seg / g.kf, df = seg - ci * g.kf;
+        const float* p = r.p + ((int64_t)ci * g.F + df) * g.Ti + dt;
+        if (!a.causal) {                                       // 8-byte aligned: hop even, dt % 4 == 0
+            const float2 lo = *reinterpret_cast<const float2*>(p);
+            const float2 hi = *reinterpret_cast<const float2*>(p + 2);
+            return make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        const int t0 = r.t + dt;                               // causal: zero left padding of W-1 samples
+        if (t0 >= 0) v.x = p[0];
+        if (t0 + 1 >= 0) v.y = p[1];
+        if (t0 + 2 >= 0) v.z = p[2];
+        if (t0 + 3 >= 0) v.w = p[3];
+        return v;
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        float* d = g.out + (int64_t)m * CS;
+        d[n] = fmaxf(v0 + g.shift[n], 0.f);
+        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    }
+};
+
+// ---- layer 2 -----------------------------------------------------------------------------
+struct CdaeL2Op {
+    typedef CdaeGroup Group;
+    typedef RowFT RowA;
+    CdaeArgs a;
+    __device__ Group group(int gid) const {
+        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const int tgt = gid & 3;
+        Group g;
+        g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
+        g.Fo = b.F2; g.To = a.T2; g.Fi = b.F1; g.Ti = a.T1;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = 64;
+        g.B = a.pool + b.w2[tgt]; g.shift = a.pool + b.s2[tgt];
+        g.in = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
+        g.out = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
+        return g;
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        if (m >= g.M) return r;
+        int b, f, t;
+        split_row(m, g.Fo, g.To, b, f, t);
+        r.f = f; r.t = t;
+        r.p = g.in + (((int64_t)b * g.Fi + f) * g.Ti + t) * CS;
+        return r;
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int df = k / (4 * CS), rem = k - df * 4 * CS;   // rem = dt*52 + c1, contiguous in memory
+        return *reinterpret_cast<const float4*>(r.p + (int64_t)df * g.Ti * CS + rem);
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        float* d = g.out + (int64_t)m * CS;
+        d[n] = fmaxf(v0 + g.shift[n], 0.f);
+        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    }
+};
+
+// ---- layer 3 (transposed conv as a gather over a zero-extended input) ----------------------
+struct CdaeL3Op {
+    typedef CdaeGroup Group;
+    typedef RowFT RowA;
+    CdaeArgs a;
+    __device__ Group group(int gid) const {
+        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const int tgt = gid & 3;
+        Group g;
+        g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
+        g.Fo = b.F1; g.To = a.T1; g.Fi = b.F2; g.Ti = a.T2;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = 64;
+        g.B = a.pool + b.w3[tgt]; g.shift = a.pool + b.s3[tgt];
+        g.in = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
+        g.out = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
+        return g;
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        if (m >= g.M) return r;
+        int b, f, t;
+        split_row(m, g.Fo, g.To, b, f, t);
+        r.f = f; r.t = t;
+        r.p = g.in + (((int64_t)b * g.Fi + f) * g.Ti + (t - 3)) * CS;   // (f3, t3-3); checked per load
+        return r;
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int df = k / (4 * CS), rem = k - df * 4 * CS;
+        const int dtp = rem / CS;                              // dt' = 3 - dt
+        const int fi = r.f - df, ti = r.t - 3 + dtp;
+        if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(r.p - (int64_t)df * g.Ti * CS + rem);
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        float* d = g.out + (int64_t)m * CS;
+        d[n] = fmaxf(v0 + g.shift[n], 0.f);
+        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    }
+};
+
+// ---- layer 4 + sigmoid + mask * X ------------------------------------------------------------
+// Output-stationary form of the strided transposed conv: output sample tau = u*hop + dt (dt < hop)
+// receives taps t3 = u (kernel column dt) and t3 = u-1 (kernel column dt + hop).
+struct CdaeL4Op {
+    typedef CdaeGroup Group;
+    typedef RowFT RowA;
+    CdaeArgs a;
+    __device__ Group group(int gid) const {
+        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const int tgt = gid & 3;
+        Group g;
+        g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
+        g.Fo = b.F; g.To = 2 * a.S; g.Fi = b.F1; g.Ti = a.T1;
+        g.M = a.Bn * g.Fo * g.To; g.N = b.T; g.K = b.kf * 2 * CS; g.ldb = b.ld4;
+        g.B = a.pool + b.w4[tgt]; g.shift = a.pool + b.b4[tgt];
+        g.in = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
+        g.out = nullptr;
+        return g;
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        if (m >= g.M) return r;
+        int b, f, t;
+        split_row(m, g.Fo, g.To, b, f, t);
+        r.f = f; r.t = t;
+        r.p = g.in + (((int64_t)b * g.Fi + f) * g.Ti + t) * CS;
+        return r;
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int df = k / (2 * CS), rem = k - df * 2 * CS;
+        const int tap = rem / CS, c3 = rem - tap * CS;
+        const int fi = r.f - df, ti = r.t - tap;
+        if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + tap) * CS + c3);
+    }
+    __device__ void put(const Group& g, int b, int f, int u, int n, float acc) const {
+        const int c = n / g.hop, dt = n - c * g.hop;
+        const float mask = 1.f / (1.f + __expf(-(acc + g.shift[c])));
+        const int64_t ST = (int64_t)a.S * g.T;
+        const int64_t tau = (int64_t)u * g.hop + dt;
+        const int64_t xi = (int64_t)a.Bn * 2 * a.S * g.cum + ((int64_t)(b * 2 + c) * g.F + f) * ST + tau;
+        const int64_t yi = (int64_t)a.Bn * 8 * a.S * g.cum +
+                           ((int64_t)((g.tgt * a.Bn + b) * 2 + c) * g.F + f) * ST + tau;
+        const float2 x = reinterpret_cast<const float2*>(a.X)[xi];
+        reinterpret_cast<float2*>(a.Y)[yi] = make_float2(mask * x.x, mask * x.y);
+        if (a.masks) a.masks[yi] = mask;
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        int b, f, u;
+        split_row(m, g.Fo, g.To, b, f, u);
+        if (n < g.N) put(g, b, f, u, n, v0);
+        if (n + 32 < g.N) put(g, b, f, u, n + 32, v1);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------
+static const int CDAE_BM = 128;
+
+static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
+
+static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(layer, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    std::vector<TileDev> t;
+    for (int b = 0; b < Mo->nblocks; ++b) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        int64_t M; int N;
+        switch (layer) {
+            case 1: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
+            case 2: M = (int64_t)Bn * d.F2 * T2; N = CS; break;
+            case 3: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
+            default: M = (int64_t)Bn * d.F * 2 * S; N = d.T; break;
+        }
+        for (int tgt = 0; tgt < NT; ++tgt)
+            for (int64_t m0 = 0; m0 < M; m0 += CDAE_BM)
+                for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, 0});
+    }
+    TileTable tt;
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
+static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace xsq
+
+using namespace xsq;
+
+extern "C" {
+
+int64_t xsq_model_num_params(const xsq_plan* P) {
+    if (!P) return XSQ_ERR_ARG;
+    int64_t n = 0;
+    for (const BlockHost& b : P->blocks) {
+        const int kf = kf_of(b.F);
+        n += 2 * b.F;
+        n += NT * ((int64_t)H1 * 2 * kf * b.T + 4 * H1 + (int64_t)H2 * H1 * kf * 4 + 4 * H2 +
+                   (int64_t)H2 * H1 * kf * 4 + 4 * H1 + (int64_t)H1 * 2 * kf * b.T + 2);
+    }
+    return n;
+}
+
+int xsq_model_create(xsq_model** out, xsq_plan* P, int causal, const float* params, int64_t nparams) {
+    XSQ_REQUIRE(out && P && params, "xsq_model_create: null argument");
+    XSQ_REQUIRE(nparams == xsq_model_num_params(P), "xsq_model_create: got %lld parameters, the plan needs %lld",
+                (long long)nparams, (long long)xsq_model_num_params(P));
+    for (const BlockHost& b : P->blocks)
+        XSQ_REQUIRE(b.F - 2 * (kf_of(b.F) - 1) >= 1, "xsq_model_create: block with F=%d too small", b.F);
+    xsq_model* Mo = new xsq_model();
+    Mo->plan = P; Mo->causal = causal ? 1 : 0; Mo->nblocks = P->nblocks;
+    const double eps = 1e-5;
+    std::vector<float> pool, mean, scale;
+    std::vector<int64_t> cum(P->nblocks + 1, 0);
+    std::vector<int> blockF(P->nblocks);
+    const float* p = params;
+    int cumF1 = 0, cumF2 = 0;
+    int64_t cumF = 0;
+    auto alloc = [&](size_t n) { size_t o = pool.size(); pool.resize(o + n, 0.f); return (int64_t)o; };
+    for (int bi = 0; bi < P->nblocks; ++bi) {
+        const BlockHost& hb = P->blocks[bi];
+        CdaeBlockDev d;
+        memset(&d, 0, sizeof(d));
+        d.F = hb.F; d.T = hb.T; d.hop = hb.T / 2; d.kf = kf_of(hb.F);
+        d.F1 = d.F - d.kf + 1; d.F2 = d.F1 - d.kf + 1;
+        d.cumF1 = cumF1; d.cumF2 = cumF2; d.cum = hb.cum; d.cumF = cumF; d.ld4 = (int)round_up(d.T, 64);
+        cumF1 += d.F1; cumF2 += d.F2; cumF += d.F;
+        cum[bi] = hb.cum; blockF[bi] = d.F;
+        const int kf = d.kf, W = d.T, hop = d.hop;
+        mean.insert(mean.end(), p, p + d.F); p += d.F;
+        scale.insert(scale.end(), p, p + d.F); p += d.F;
+        for (int t = 0; t < NT; ++t) {
+            // ---- L1: Conv2d weight (50,2,kf,W); BN(50)
+            const float* w = p; p += (size_t)H1 * 2 * kf * W;
+            const float *bw = p, *bb = p + H1, *rm = p + 2 * H1, *rv = p + 3 * H1; p += 4 * H1;
+            const int K1 = 2 * kf * W;
+            d.w1[t] = alloc((size_t)round_up(K1, 16) * 64);
+            d.s1[t] = alloc(64);
+            for (int co = 0; co < H1; ++co) {
+                const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
+                pool[d.s1[t] + co] = (float)((double)bb[co] - (double)rm[co] * s);
+                for (int k = 0; k < K1; ++k)       // k = (ci*kf + df)*W + dt, the weight's own order
+                    pool[d.w1[t] + (size_t)k * 64 + co] = (float)((double)w[(size_t)co * K1 + k] * s);
+            }
+            // ---- L2: Conv2d weight (51,50,kf,4); BN(51);  k = (df*4 + dt)*52 + c1
+            w = p; p += (size_t)H2 * H1 * kf * 4;
+            bw = p; bb = p + H2; rm = p + 2 * H2; rv = p + 3 * H2; p += 4 * H2;
+            const int K2 = kf * 4 * CS;
+            d.w2[t] = alloc((size_t)round_up(K2, 16) * 64);
+            d.s2[t] = alloc(64);
+            for (int co = 0; co < H2; ++co) {
+                const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
+                pool[d.s2[t] + co] = (float)((double)bb[co] - (double)rm[co] * s);
+                for (int ci = 0; ci < H1; ++ci)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            pool[d.w2[t] + (size_t)((df * 4 + dt) * CS + ci) * 64 + co] =
+                                (float)((double)w[(((size_t)co * H1 + ci) * kf + df) * 4 + dt] * s);
+            }
+            // ---- L3: ConvTranspose2d weight (51,50,kf,4) = (in,out,kH,kW); BN(50)
+            //      out3[c3,f3,t3] = sum w[c2,c3,df,dt] out2[c2,f3-df,t3-dt];  k = (df*4 + dt')*52 + c2, dt' = 3-dt
+            w = p; p += (size_t)H2 * H1 * kf * 4;
+            bw = p; bb = p + H1; rm = p + 2 * H1; rv = p + 3 * H1; p += 4 * H1;
+            d.w3[t] = alloc((size_t)round_up(K2, 16) * 64);
+            d.s3[t] = alloc(64);
+            for (int co = 0; co < H1; ++co) {
+                const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
+                pool[d.s3[t] + co] = (float)((double)bb[co] - (double)rm[co] * s);
+                for (int ci = 0; ci < H2; ++ci)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            pool[d.w3[t] + (size_t)((df * 4 + (3 - dt)) * CS + ci) * 64 + co] =
+                                (float)((double)w[(((size_t)ci * H1 + co) * kf + df) * 4 + dt] * s);
+            }
+            // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
+            //      k = (df*2 + tap)*52 + c3 ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
+            w = p; p += (size_t)H1 * 2 * kf * W;
+            const float* bias = p; p += 2;
+            const int K4 = kf * 2 * CS;
+            d.w4[t] = alloc((size_t)round_up(K4, 16) * d.ld4);
+            d.b4[t] = alloc(64);
+            pool[d.b4[t]] = bias[0]; pool[d.b4[t] + 1] = bias[1];
+            for (int ci = 0; ci < H1; ++ci)
+                for (int c = 0; c < 2; ++c)
+                    for (int df = 0; df < kf; ++df)
+                        for (int tap = 0; tap < 2; ++tap)
+                            for (int dt = 0; dt < hop; ++dt)
+                                pool[d.w4[t] + (size_t)((df * 2 + tap) * CS + ci) * d.ld4 + c * hop + dt] =
+                                    w[(((size_t)ci * 2 + c) * kf + df) * W + dt + tap * hop];
+        }
+        Mo->blocks.push_back(d);
+    }
+    cum[P->nblocks] = P->sumFT;
+    Mo->sumF = cumF; Mo->sumF1 = cumF1; Mo->sumF2 = cumF2;
+    if (p - params != nparams) {
+        set_error("xsq_model_create: internal parameter walk mismatch");
+        delete Mo;
+        return XSQ_ERR_ARG;
+    }
+#define UP(dst, vec, T)                                                                           \
+    do {                                                                                          \
+        XSQ_HIP(hipMalloc(&(dst), (vec).size() * sizeof(T)));                                     \
+        XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); \
+    } while (0)
+    UP(Mo->d_pool, pool, float);
+    UP(Mo->d_mean, mean, float);
+    UP(Mo->d_scale, scale, float);
+    UP(Mo->d_blocks, Mo->blocks, CdaeBlockDev);
+    UP(Mo->d_cum, cum, int64_t);
+    UP(Mo->d_blockF, blockF, int);
+#undef UP
+    *out = Mo;
+    return XSQ_OK;
+}
+
+int xsq_model_destroy(xsq_model* Mo) {
+    if (!Mo) return XSQ_OK;
+    for (auto& kv : Mo->tiles) (void)hipFree(kv.second.d_tiles);
+    (void)hipFree(Mo->d_pool); (void)hipFree(Mo->d_mean); (void)hipFree(Mo->d_scale);
+    (void)hipFree(Mo->d_blocks); (void)hipFree(Mo->d_cum); (void)hipFree(Mo->d_blockF);
+    delete Mo;
+    return XSQ_OK;
+}
+
+// workspace: xin | act1 | act2 | act3
+size_t xsq_cdae_workspace(const xsq_model* Mo, int Bn, int S) {
+    if (!Mo || Bn <= 0 || S < 3) return 0;
+    const int64_t T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    return al((size_t)Bn * 2 * S * Mo->plan->sumFT * 4) + 2 * al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4) +
+           al((size_t)CS * Bn * T2 * 4 * Mo->sumF2 * 4) + 256;
+}
+
+int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, float* masks, void* ws,
+                     size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(Mo && X && Y && ws, "xsq_cdae_forward: null argument");
+    XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_cdae_forward: Bn=%d S=%d (the conv stack needs >= 3 slices)", Bn, S);
+    XSQ_REQUIRE(ws_bytes >= xsq_cdae_workspace(Mo, Bn, S), "xsq_cdae_forward: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const xsq_plan* P = Mo->plan;
+    const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    char* w = (char*)ws;
+    float* xin = (float*)w;  w += al((size_t)Bn * 2 * S * P->sumFT * 4);
+    float* act1 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
+    float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
+    float* act2 = (float*)w;
+    const int64_t total = (int64_t)Bn * 2 * S * P->sumFT;
+    hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float2*)X, xin, Mo->d_cum, Mo->d_blockF, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
+                       Mo->nblocks, Bn * 2, S, total);
+    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal};
+    TileTable tt;
+    int rc;
+    if ((rc = get_cdae_tiles(Mo, 1, Bn, S, &tt))) return rc;
+    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+                       CdaeL1Op{a}, tt.d_tiles, tt.ntiles);
+    if ((rc = get_cdae_tiles(Mo, 2, Bn, S, &tt))) return rc;
+    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL2Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+                       CdaeL2Op{a}, tt.d_tiles, tt.ntiles);
+    if ((rc = get_cdae_tiles(Mo, 3, Bn, S, &tt))) return rc;
+    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL3Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+                       CdaeL3Op{a}, tt.d_tiles, tt.ntiles);
+    if ((rc = get_cdae_tiles(Mo, 4, Bn, S, &tt))) return rc;
+    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+                       CdaeL4Op{a}, tt.d_tiles, tt.ntiles);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+}  // extern "C"

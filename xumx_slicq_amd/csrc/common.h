@@ -1,0 +1,57 @@
+// Shared host/device definitions for the xumx-sliCQ MI355X hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define XSQ_OK 0
+#define XSQ_ERR_ARG (-1)
+#define XSQ_ERR_HIP (-2)
+#define XSQ_ERR_FFT (-3)
+#define XSQ_ERR_WORKSPACE (-4)
+
+namespace xsq {
+
+void set_error(const char* fmt, ...);
+
+#define XSQ_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            ::xsq::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,               \
+                             hipGetErrorString(e_));                                    \
+            return XSQ_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define XSQ_REQUIRE(cond, ...)                                                          \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            ::xsq::set_error(__VA_ARGS__);                                              \
+            return XSQ_ERR_ARG;                                                         \
+        }                                                                               \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// One band of the transform as the kernels see it.
+struct BandDev {
+    int Lg;        // band length (coefficients per slice), multiple of 4
+    int bin0;      // first spectrum bin of the band's window: c - Lg/2 (may be < 0 for DC)
+    int f;         // row of the band inside its block
+    int F;         // rows of the block
+    int64_t cum;   // sum over earlier blocks of F_b*T_b (complex coefficients per channel-slice)
+    int64_t w_off; // float offset of the band's DFT matrix inside Wf / Wi
+    int ldw;       // leading dimension (floats) of that matrix: round_up(2*Lg, 64)
+    int pad;
+};
+
+// One tile of work of a grouped GEMM launch.
+struct TileDev {
+    int group;  // band (sliCQT) or layer-group (CDAE)
+    int m0;     // first row of the tile
+    int n0;     // first column of the tile
+    int pad;
+};
+
+}  // namespace xsq

@@ -1,0 +1,48 @@
+// Host-side plan object behind the C ABI (include/xumx_slicq_hip.h).
+#pragma once
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include <rocfft/rocfft.h>
+
+#include "common.h"
+
+namespace xsq {
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct TileTable {
+    TileDev* d_tiles = nullptr;
+    int ntiles = 0;
+};
+
+struct BlockHost {
+    int first_band, F, T;
+    int64_t cum;  // sum of F*T over earlier blocks
+};
+
+}  // namespace xsq
+
+struct xsq_plan {
+    int L = 0, tr = 0, h = 0, nbins = 0, nbands = 0, nblocks = 0;
+    int64_t sumFT = 0;  // complex coefficients per channel-slice (18640 for Bark-262)
+    std::vector<xsq::BandDev> bands;
+    std::vector<xsq::BlockHost> blocks;
+    // device tables
+    float* d_tw = nullptr;          // (L) slice window
+    float* d_Wf = nullptr;          // per-band analysis matrices  (window, sign, 1/Lg folded in)
+    float* d_Wi = nullptr;          // per-band synthesis matrices (dual window, Lg, sign, 1/L folded in)
+    xsq::BandDev* d_bands = nullptr;
+    int* d_cov_ptr = nullptr;       // (nbins+1) CSR over spectrum bins -> covering bands
+    int* d_cov_band = nullptr;
+    // caches keyed by the call shape
+    std::mutex mu;
+    std::map<std::pair<int, int>, xsq::FftPlan> fft;              // (direction, batch)
+    std::map<std::tuple<int, int, int>, xsq::TileTable> tiles;   // (kind, rows, 0)
+};

@@ -1,0 +1,507 @@
+// Forward / inverse sliced Constant-Q transform for gfx950.
+//
+// Forward  (closed form, SURVEY.md 8(a) F*; reference nsgt/slicing.py, nsgt/nsgtf.py, nsgt/slicq.py:13-33)
+//   seg[bc,s,p]   = tw[p] * xpad[bc, (2s-2)h + p]                         k_slice_window   (HBM stream)
+//   U[bc,s,:]     = rfft_L(seg[bc,s,:])                                   rocFFT
+//   coef[bc,j,s,:] = U[bc,s, bin0_j : bin0_j+Lg_j] (Hermitian-reflected at DC/Nyquist) x Wf_j
+//                                                                         grouped fp32-MFMA GEMM
+//   Wf_j = diag(g_j * (-1)^(c_j/2) / Lg_j) * IDFT_Lg, real-ified on interleaved (re,im).
+// Inverse  (closed form I2; reference nsgt/nsigtf.py, nsgt/unslicing.py)
+//   Z[bc,j,s,:]   = coef[bc,j,s,:] x Wi_j,  Wi_j = DFT_Lg * diag(gd_j * Lg_j * (-1)^(c_j/2) / L)
+//   fr[bc,s,k]    = sum over bands covering bin k of Z[bc,j,s,k-bin0_j]   k_spectrum_gather (HBM stream)
+//   seg[bc,s,:]   = L * irfft_L(fr[bc,s,:])  (unnormalised c2r; the 1/L sits in Wi)   rocFFT
+//   y[bc,i]       = seg[bc,s0,i-(2s0-2)h] + seg[bc,s0+1,i-2h*s0],  s0 = i/(2h)        k_overlap_add
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/xumx_slicq_hip.h"
+#include "gemm_tile.h"
+#include "plan.h"
+
+namespace xsq {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming kernels
+// ------------------------------------------------------------------------------------------
+// grid (ceil(L/256), BC*S).  Reads x once (each sample lands in two slices), writes seg once.
+__global__ __launch_bounds__(256) void k_slice_window(const float* __restrict__ x,
+                                                       const float* __restrict__ tw,
+                                                       float* __restrict__ seg, int S, int64_t n, int L,
+                                                       int h) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= L) return;
+    const int row = blockIdx.y;  // bc*S + s
+    const int bc = row / S, s = row - bc * S;
+    const int64_t i = (int64_t)(2 * s - 2) * h + p;
+    float v = 0.f;
+    if (i >= 0 && i < n) v = tw[p] * x[(int64_t)bc * n + i];
+    seg[(int64_t)row * L + p] = v;
+}
+
+// grid (ceil(nbins/256), BC*S).  fr[row][k] = sum of the covering bands' synthesis outputs.
+__global__ __launch_bounds__(256) void k_spectrum_gather(const float* __restrict__ Z,
+                                                          const BandDev* __restrict__ bands,
+                                                          const int* __restrict__ cov_ptr,
+                                                          const int* __restrict__ cov_band,
+                                                          float2* __restrict__ fr, int BC, int S, int nbins) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nbins) return;
+    const int row = blockIdx.y;
+    const int bc = row / S, s = row - bc * S;
+    const int64_t BCS = (int64_t)BC * S;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int e = cov_ptr[k]; e < cov_ptr[k + 1]; ++e) {
+        const BandDev b = bands[cov_band[e]];
+        const int64_t off = 2 * (BCS * b.cum + (((int64_t)bc * b.F + b.f) * S + s) * b.Lg + (k - b.bin0));
+        const float2 z = *reinterpret_cast<const float2*>(Z + off);
+        acc.x += z.x;
+        acc.y += z.y;
+    }
+    // irfft ignores the imaginary part of the DC and Nyquist bins (torch.fft.irfft, nsigtf.py:103)
+    if (k == 0 || k == nbins - 1) acc.y = 0.f;
+    fr[(int64_t)row * nbins + k] = acc;
+}
+
+// grid (ceil(length/256), BC).  Each output sample is the sum of exactly two slices.
+__global__ __launch_bounds__(256) void k_overlap_add(const float* __restrict__ seg, float* __restrict__ y,
+                                                      int S, int64_t length, int L, int h) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= length) return;
+    const int bc = blockIdx.y;
+    const int s0 = (int)(i / (2 * h));
+    const int p1 = (int)(i - (int64_t)2 * h * s0);  // position inside slice s0+1
+    const float* base = seg + (int64_t)bc * S * L;
+    float v = base[(int64_t)s0 * L + p1 + 2 * h];
+    if (s0 + 1 < S) v += base[(int64_t)(s0 + 1) * L + p1];
+    y[(int64_t)bc * length + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// grouped GEMM operators
+// ------------------------------------------------------------------------------------------
+struct BandGroup {
+    int M, N, K, ldb;
+    const float* B;
+    int Lg, bin0, f, F;
+    int64_t base;  // float offset of (bc=0, f, s=0) of this band in the arena
+};
+
+// coef = U_window x Wf
+struct BandFwdOp {
+    typedef BandGroup Group;
+    struct RowA {
+        const float* p;  // U row (bc,s), nullptr when past M
+    };
+    const float* U;
+    float* coef;
+    const BandDev* bands;
+    const float* W;
+    int BC, S, nbins, L;
+
+    __device__ Group group(int j) const {
+        const BandDev b = bands[j];
+        Group g;
+        g.M = BC * S; g.N = 2 * b.Lg; g.K = 2 * b.Lg; g.ldb = b.ldw; g.B = W + b.w_off;
+        g.Lg = b.Lg; g.bin0 = b.bin0; g.f = b.f; g.F = b.F;
+        g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
+        return g;
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r;
+        r.p = m < g.M ? U + (int64_t)m * 2 * nbins : nullptr;
+        return r;
+    }
+    // two complex bins per call; bins outside [0, L/2] come from the Hermitian mirror (their
+    // conjugation is folded into the signs of Wf's imaginary rows)
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r.p == nullptr || k >= g.K) return v;
+        int i0 = g.bin0 + (k >> 1), i1 = i0 + 1;
+        i0 = i0 < 0 ? -i0 : (i0 > L / 2 ? L - i0 : i0);
+        i1 = i1 < 0 ? -i1 : (i1 > L / 2 ? L - i1 : i1);
+        const float2 a = *reinterpret_cast<const float2*>(r.p + 2 * i0);
+        const float2 b = *reinterpret_cast<const float2*>(r.p + 2 * i1);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        const int bc = m / S, s = m - bc * S;
+        float* d = coef + g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg);
+        if (n < g.N) d[n] = v0;
+        if (n + 32 < g.N) d[n + 32] = v1;
+    }
+};
+
+// Z = coef x Wi   (dense rows in, dense rows out, same arena layout)
+struct BandInvOp {
+    typedef BandGroup Group;
+    struct RowA {
+        const float* p;
+    };
+    const float* coef;
+    float* Z;
+    const BandDev* bands;
+    const float* W;
+    int BC, S;
+
+    __device__ Group group(int j) const {
+        const BandDev b = bands[j];
+        Group g;
+        g.M = BC * S; g.N = 2 * b.Lg; g.K = 2 * b.Lg; g.ldb = b.ldw; g.B = W + b.w_off;
+        g.Lg = b.Lg; g.bin0 = b.bin0; g.f = b.f; g.F = b.F;
+        g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
+        return g;
+    }
+    __device__ int64_t row_off(const Group& g, int m) const {
+        const int bc = m / S, s = m - bc * S;
+        return g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg);
+    }
+    __device__ RowA row_a(const Group& g, int m) const {
+        RowA r;
+        r.p = m < g.M ? coef + row_off(g, m) : nullptr;
+        return r;
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
+        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
+    }
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+        if (m >= g.M) return;
+        float* d = Z + row_off(g, m);
+        if (n < g.N) d[n] = v0;
+        if (n + 32 < g.N) d[n + 32] = v1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static const int BAND_BM = 128;
+
+static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
+    std::lock_guard<std::mutex> lk(P->mu);
+    auto key = std::make_tuple(0, rows, 0);
+    auto it = P->tiles.find(key);
+    if (it != P->tiles.end()) {
+        *out = it->second;
+        return XSQ_OK;
+    }
+    std::vector<TileDev> t;
+    for (int j = 0; j < P->nbands; ++j) {
+        const int N = 2 * P->bands[j].Lg;
+        // n fastest: the N-tiles of one M-tile run back to back and re-read the same A rows from L2
+        for (int m0 = 0; m0 < rows; m0 += BAND_BM)
+            for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{j, m0, n0, 0});
+    }
+    TileTable tt;
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    P->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
+static int get_fft(xsq_plan* P, int inverse, int batch, FftPlan* out) {
+    std::lock_guard<std::mutex> lk(P->mu);
+    auto key = std::make_pair(inverse, batch);
+    auto it = P->fft.find(key);
+    if (it != P->fft.end()) {
+        *out = it->second;
+        return XSQ_OK;
+    }
+    static std::once_flag once;
+    std::call_once(once, [] { rocfft_setup(); });
+    FftPlan f;
+    size_t len = (size_t)P->L;
+    rocfft_status st = rocfft_plan_create(&f.plan, rocfft_placement_notinplace,
+                                          inverse ? rocfft_transform_type_real_inverse
+                                                  : rocfft_transform_type_real_forward,
+                                          rocfft_precision_single, 1, &len, (size_t)batch, nullptr);
+    if (st != rocfft_status_success) {
+        set_error("rocfft_plan_create(L=%d, batch=%d, inverse=%d) failed: %d", P->L, batch, inverse, (int)st);
+        return XSQ_ERR_FFT;
+    }
+    rocfft_plan_get_work_buffer_size(f.plan, &f.work_bytes);
+    if (rocfft_execution_info_create(&f.info) != rocfft_status_success) {
+        set_error("rocfft_execution_info_create failed");
+        return XSQ_ERR_FFT;
+    }
+    P->fft[key] = f;
+    *out = f;
+    return XSQ_OK;
+}
+
+static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_t stream) {
+    if (rocfft_execution_info_set_stream(f.info, stream) != rocfft_status_success) {
+        set_error("rocfft_execution_info_set_stream failed");
+        return XSQ_ERR_FFT;
+    }
+    if (f.work_bytes) {
+        if (rocfft_execution_info_set_work_buffer(f.info, work, f.work_bytes) != rocfft_status_success) {
+            set_error("rocfft_execution_info_set_work_buffer failed");
+            return XSQ_ERR_FFT;
+        }
+    }
+    void* ib[1] = {in};
+    void* ob[1] = {out};
+    rocfft_status st = rocfft_execute(f.plan, ib, ob, f.info);
+    if (st != rocfft_status_success) {
+        set_error("rocfft_execute failed: %d", (int)st);
+        return XSQ_ERR_FFT;
+    }
+    return XSQ_OK;
+}
+
+static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace xsq
+
+using namespace xsq;
+
+extern "C" {
+
+int xsq_abi_version(void) { return XSQ_ABI_VERSION; }
+const char* xsq_last_error(void) { return g_err; }
+
+int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg, const int32_t* c,
+                    const float* g, const double* gd, const float* tw) {
+    XSQ_REQUIRE(out && Lg && c && g && gd && tw, "xsq_plan_create: null argument");
+    XSQ_REQUIRE(L > 0 && L % 4 == 0 && tr % 2 == 0 && nbands >= 2, "xsq_plan_create: bad L/tr/nbands");
+    xsq_plan* P = new xsq_plan();
+    P->L = L; P->tr = tr; P->h = L / 4; P->nbins = L / 2 + 1; P->nbands = nbands;
+    // blocks = runs of equal band length (nsgt/nsgtf.py:66-78)
+    int64_t cum = 0;
+    for (int j = 0; j < nbands;) {
+        int k = j;
+        while (k + 1 < nbands && Lg[k + 1] == Lg[j]) ++k;
+        P->blocks.push_back(BlockHost{j, k - j + 1, Lg[j], cum});
+        cum += (int64_t)(k - j + 1) * Lg[j];
+        j = k + 1;
+    }
+    P->nblocks = (int)P->blocks.size();
+    P->sumFT = cum;
+    int64_t woff = 0, goff = 0;
+    std::vector<int64_t> g_off(nbands);
+    for (const BlockHost& b : P->blocks) {
+        for (int f = 0; f < b.F; ++f) {
+            const int j = b.first_band + f;
+            if (Lg[j] % 4 != 0 || c[j] % 2 != 0 || Lg[j] > L / 2) {
+                set_error("xsq_plan_create: band %d has Lg=%d c=%d (need Lg%%4==0, c even, Lg<=L/2)", j, Lg[j], c[j]);
+                delete P;
+                return XSQ_ERR_ARG;
+            }
+            BandDev d;
+            d.Lg = Lg[j]; d.bin0 = c[j] - Lg[j] / 2; d.f = f; d.F = b.F; d.cum = b.cum;
+            d.ldw = (int)round_up(2 * Lg[j], 64); d.w_off = woff; d.pad = 0;
+            woff += round_up(2 * Lg[j], 16) * d.ldw;
+            P->bands.push_back(d);
+            g_off[j] = goff;
+            goff += Lg[j];
+        }
+    }
+    // ---- per-band real-ified DFT matrices --------------------------------------------
+    // row index k = 2p+ri over the band's window in spectrum order (bin = bin0 + p, window
+    // index q = (p + Lg/2) mod Lg since windows are stored peak-at-0); column n = 2t+ro.
+    std::vector<float> Wf((size_t)woff, 0.f), Wi((size_t)woff, 0.f);
+    const double PI2 = 6.283185307179586476925286766559;
+    for (int j = 0; j < nbands; ++j) {
+        const BandDev& d = P->bands[j];
+        const int n = d.Lg, ld = d.ldw;
+        const double sign = ((c[j] / 2) % 2 == 0) ? 1.0 : -1.0;
+        std::vector<double> cs(n), sn(n);
+        for (int r = 0; r < n; ++r) { cs[r] = std::cos(PI2 * r / n); sn[r] = std::sin(PI2 * r / n); }
+        float* wf = Wf.data() + d.w_off;
+        float* wi = Wi.data() + d.w_off;
+        for (int p = 0; p < n; ++p) {
+            const int q = (p + n / 2) % n;
+            const int bin = d.bin0 + p;
+            const double conj = (bin < 0 || bin > L / 2) ? -1.0 : 1.0;  // mirrored bin: input is conj(U)
+            const double ga = (double)g[g_off[j] + q] * sign / n;
+            const double gs = gd[g_off[j] + q] * n * sign / L;
+            for (int t = 0; t < n; ++t) {
+                const int r = (int)(((int64_t)q * t) % n);
+                // analysis: w = ga * e^{+i 2 pi q t / n};  (a_re + i conj a_im) * w
+                const double wr = ga * cs[r], wim = ga * sn[r];
+                wf[(size_t)(2 * p) * ld + 2 * t] = (float)wr;
+                wf[(size_t)(2 * p) * ld + 2 * t + 1] = (float)wim;
+                wf[(size_t)(2 * p + 1) * ld + 2 * t] = (float)(-conj * wim);
+                wf[(size_t)(2 * p + 1) * ld + 2 * t + 1] = (float)(conj * wr);
+                // synthesis: rows are coefficients t, columns spectrum positions p:
+                // w = gs * e^{-i 2 pi q t / n}
+                const double vr = gs * cs[r], vi = -gs * sn[r];
+                wi[(size_t)(2 * t) * ld + 2 * p] = (float)vr;
+                wi[(size_t)(2 * t) * ld + 2 * p + 1] = (float)vi;
+                wi[(size_t)(2 * t + 1) * ld + 2 * p] = (float)(-vi);
+                wi[(size_t)(2 * t + 1) * ld + 2 * p + 1] = (float)vr;
+            }
+        }
+    }
+    // ---- spectrum coverage (which bands add into bin k) ----------------------------------
+    std::vector<int> cov_ptr(P->nbins + 1, 0), cov_band;
+    {
+        std::vector<std::vector<int>> cov(P->nbins);
+        for (int j = 0; j < nbands; ++j)
+            for (int p = 0; p < P->bands[j].Lg; ++p) {
+                const int k = P->bands[j].bin0 + p;
+                if (k >= 0 && k <= L / 2) cov[k].push_back(j);
+            }
+        for (int k = 0; k < P->nbins; ++k) {
+            cov_ptr[k + 1] = cov_ptr[k] + (int)cov[k].size();
+            cov_band.insert(cov_band.end(), cov[k].begin(), cov[k].end());
+        }
+    }
+#define UP(dst, vec, T)                                                                           \
+    do {                                                                                          \
+        XSQ_HIP(hipMalloc(&(dst), (vec).size() * sizeof(T)));                                     \
+        XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); \
+    } while (0)
+    UP(P->d_Wf, Wf, float);
+    UP(P->d_Wi, Wi, float);
+    UP(P->d_bands, P->bands, BandDev);
+    UP(P->d_cov_ptr, cov_ptr, int);
+    UP(P->d_cov_band, cov_band, int);
+#undef UP
+    XSQ_HIP(hipMalloc(&P->d_tw, (size_t)L * sizeof(float)));
+    XSQ_HIP(hipMemcpy(P->d_tw, tw, (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+    *out = P;
+    return XSQ_OK;
+}
+
+int xsq_plan_destroy(xsq_plan* P) {
+    if (!P) return XSQ_OK;
+    for (auto& kv : P->fft) {
+        if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+        if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+    }
+    for (auto& kv : P->tiles) (void)hipFree(kv.second.d_tiles);
+    (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
+    (void)hipFree(P->d_cov_ptr); (void)hipFree(P->d_cov_band);
+    delete P;
+    return XSQ_OK;
+}
+
+int xsq_plan_num_blocks(const xsq_plan* P) { return P ? P->nblocks : XSQ_ERR_ARG; }
+
+int xsq_plan_block_table(const xsq_plan* P, int64_t* table) {
+    XSQ_REQUIRE(P && table, "xsq_plan_block_table: null argument");
+    for (int b = 0; b < P->nblocks; ++b) {
+        table[4 * b + 0] = P->blocks[b].first_band;
+        table[4 * b + 1] = P->blocks[b].F;
+        table[4 * b + 2] = P->blocks[b].T;
+        table[4 * b + 3] = P->blocks[b].cum;
+    }
+    return XSQ_OK;
+}
+
+int64_t xsq_plan_coefs_per_slice(const xsq_plan* P) { return P ? P->sumFT : XSQ_ERR_ARG; }
+
+int xsq_plan_num_slices(const xsq_plan* P, int64_t n) {
+    if (!P || n <= 0) return XSQ_ERR_ARG;
+    const int64_t nb = (n + P->h - 1) / P->h;
+    return (int)((nb + 1) / 2 + 1);
+}
+
+// workspace: seg | U | fft work
+size_t xsq_slicqt_forward_workspace(xsq_plan* P, int BC, int64_t n) {
+    if (!P || BC <= 0 || n <= 0) return 0;
+    const size_t rows = (size_t)BC * xsq_plan_num_slices(P, n);
+    FftPlan f;
+    if (get_fft(P, 0, (int)rows, &f)) return 0;
+    return al(rows * P->L * 4) + al(rows * P->nbins * 8) + al(f.work_bytes) + 256;
+}
+
+int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* coef, void* ws,
+                       size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(P && x && coef && ws, "xsq_slicqt_forward: null argument");
+    XSQ_REQUIRE(BC > 0 && n > 0, "xsq_slicqt_forward: BC=%d n=%lld", BC, (long long)n);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int S = xsq_plan_num_slices(P, n);
+    const int rows = BC * S;
+    XSQ_REQUIRE(S >= 2, "xsq_slicqt_forward: signal too short");
+    XSQ_REQUIRE((int64_t)BC * S <= 65535, "xsq_slicqt_forward: BC*S=%lld rows exceed one launch", (long long)BC * S);
+    FftPlan f;
+    int rc = get_fft(P, 0, rows, &f);
+    if (rc) return rc;
+    char* w = (char*)ws;
+    float* seg = (float*)w; w += al((size_t)rows * P->L * 4);
+    float* U = (float*)w;   w += al((size_t)rows * P->nbins * 8);
+    void* fwork = w;
+    if ((size_t)(w - (char*)ws) + f.work_bytes > ws_bytes) {
+        set_error("xsq_slicqt_forward: workspace too small (%zu needed, %zu given)",
+                  (size_t)(w - (char*)ws) + f.work_bytes, ws_bytes);
+        return XSQ_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
+                       S, n, P->L, P->h);
+    rc = run_fft(f, seg, U, fwork, stream);
+    if (rc) return rc;
+    TileTable tt;
+    rc = get_band_tiles(P, rows, &tt);
+    if (rc) return rc;
+    BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L};
+    hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
+                       tt.d_tiles, tt.ntiles);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+// workspace: Z | fr | seg | fft work
+size_t xsq_slicqt_inverse_workspace(xsq_plan* P, int BC, int S) {
+    if (!P || BC <= 0 || S <= 0) return 0;
+    const size_t rows = (size_t)BC * S;
+    FftPlan f;
+    if (get_fft(P, 1, (int)rows, &f)) return 0;
+    return al(rows * P->sumFT * 8) + al(rows * P->nbins * 8) + al(rows * P->L * 4) + al(f.work_bytes) + 256;
+}
+
+int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t length, float* y, void* ws,
+                       size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(P && coef && y && ws, "xsq_slicqt_inverse: null argument");
+    XSQ_REQUIRE(BC > 0 && S >= 2 && length > 0, "xsq_slicqt_inverse: BC=%d S=%d length=%lld", BC, S,
+                (long long)length);
+    XSQ_REQUIRE(length <= (int64_t)2 * S * P->h, "xsq_slicqt_inverse: length %lld exceeds the %d slices",
+                (long long)length, S);
+    XSQ_REQUIRE((int64_t)BC * S <= 65535, "xsq_slicqt_inverse: BC*S=%lld rows exceed one launch", (long long)BC * S);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int rows = BC * S;
+    FftPlan f;
+    int rc = get_fft(P, 1, rows, &f);
+    if (rc) return rc;
+    char* w = (char*)ws;
+    float* Z = (float*)w;    w += al((size_t)rows * P->sumFT * 8);
+    float2* fr = (float2*)w; w += al((size_t)rows * P->nbins * 8);
+    float* seg = (float*)w;  w += al((size_t)rows * P->L * 4);
+    void* fwork = w;
+    if ((size_t)(w - (char*)ws) + f.work_bytes > ws_bytes) {
+        set_error("xsq_slicqt_inverse: workspace too small (%zu needed, %zu given)",
+                  (size_t)(w - (char*)ws) + f.work_bytes, ws_bytes);
+        return XSQ_ERR_WORKSPACE;
+    }
+    TileTable tt;
+    rc = get_band_tiles(P, rows, &tt);
+    if (rc) return rc;
+    BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S};
+    hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
+                       tt.d_tiles, tt.ntiles);
+    hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,
+                       P->d_bands, P->d_cov_ptr, P->d_cov_band, fr, BC, S, P->nbins);
+    rc = run_fft(f, fr, seg, fwork, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_overlap_add, dim3((unsigned)((length + 255) / 256), BC), dim3(256), 0, stream, seg, y,
+                       S, length, P->L, P->h);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+}  // extern "C"

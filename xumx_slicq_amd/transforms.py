@@ -1,0 +1,223 @@
+"""Drop-in mirrors of /root/reference/xumx_slicq_v2/transforms.py on top of the
+HIP library: NSGTBase, NSGT_SL, INSGT_SL, ComplexNorm, make_filterbanks.
+
+Same names, argument meaning and error behaviour as the reference.  The
+arithmetic is in csrc/slicqt.hip; these classes only own device memory
+(PyTorch allocations) and hand pointers across the C ABI.  There is no CPU
+path: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .plan import SliCQPlan, build_plan
+
+
+def make_filterbanks(nsgt_base, sample_rate=44100.0):
+    """transforms.py:11-18."""
+    if sample_rate != 44100.0:
+        raise ValueError("i was lazy and harcoded a lot of 44100.0, forgive me")
+    return NSGT_SL(nsgt_base), INSGT_SL(nsgt_base)
+
+
+class SliCQEngine:
+    """Device-side plan handle (the role NSGT_sliced plays in the reference,
+    nsgt/slicq.py:70-230).  One handle per device, created on first use."""
+
+    def __init__(self, plan: SliCQPlan):
+        self.plan = plan
+        self.sl_len = plan.L
+        self.tr_area = plan.tr
+        self.fs = plan.fs
+        self.ncoefs = plan.ncoefs
+        self.fbins_actual = plan.nbands
+        self._handles = {}
+        self._ws = {}
+
+    # -- handle management ---------------------------------------------------
+    def handle(self, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.XsqError(
+                f"the sliCQT runs on a ROCm device only (got a tensor on '{device}'); there is no CPU fallback")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            p = self.plan
+            out = C.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(_lib.lib.xsq_plan_create(
+                    C.byref(out), p.L, p.tr, p.nbands,
+                    p.Lg.ctypes.data, p.c.ctypes.data, p.g.ctypes.data, p.gd.ctypes.data, p.tw.ctypes.data),
+                    "xsq_plan_create")
+            h = out
+            self._handles[idx] = h
+        return h
+
+    def workspace(self, device: torch.device, nbytes: int) -> Tensor:
+        """Grow-only scratch buffer per device (PyTorch owns the memory)."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = None
+            self._ws[key] = None
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                _lib.lib.xsq_plan_destroy(h)
+        except Exception:
+            pass
+
+    # -- arena helpers ---------------------------------------------------------
+    def arena_floats(self, BC: int, S: int) -> int:
+        return 2 * BC * S * self.plan.coefs_per_slice
+
+    def block_views(self, arena: Tensor, lead, S: int) -> List[Tensor]:
+        """The reference's list of per-block tensors (*lead, F_b, S, T_b, 2) as
+        zero-copy views of one arena allocation."""
+        BC = int(np.prod(lead)) if len(lead) else 1
+        out, off = [], 0
+        for (_, F, T) in self.plan.blocks:
+            n = 2 * BC * F * S * T
+            out.append(arena[off: off + n].view(*lead, F, S, T, 2))
+            off += n
+        return out
+
+    def as_arena(self, X_list: List[Tensor]):
+        """(arena, BC, S, lead) for a block list; zero-copy when the list already
+        is a set of views laid out back to back in one allocation."""
+        blocks = self.plan.blocks
+        if len(X_list) != len(blocks):
+            raise ValueError(f"expected {len(blocks)} blocks, got {len(X_list)}")
+        x0 = X_list[0]
+        lead = tuple(x0.shape[:-4])
+        S = x0.shape[-3]
+        BC = int(np.prod(lead)) if len(lead) else 1
+        total = self.arena_floats(BC, S)
+        contiguous_run = x0.dtype == torch.float32
+        ptr = x0.data_ptr()
+        for X, (_, F, T) in zip(X_list, blocks):
+            if tuple(X.shape) != (*lead, F, S, T, 2):
+                raise ValueError(f"block has shape {tuple(X.shape)}, expected {(*lead, F, S, T, 2)}")
+            if contiguous_run and (X.dtype != torch.float32 or not X.is_contiguous() or X.data_ptr() != ptr):
+                contiguous_run = False
+            ptr += X.numel() * 4
+        if contiguous_run and x0.untyped_storage().nbytes() - (x0.data_ptr() - x0.untyped_storage().data_ptr()) >= total * 4:
+            arena = torch.as_strided(x0, (total,), (1,))
+        else:
+            arena = torch.cat([X.to(torch.float32).reshape(-1) for X in X_list])
+        return arena, BC, S, lead
+
+    # -- transforms --------------------------------------------------------------
+    def forward(self, x: Tensor):
+        """x (*lead, n) fp32 on a ROCm device -> (arena, lead, S)."""
+        if x.dtype != torch.float32:
+            x = x.float()
+        lead = tuple(x.shape[:-1])
+        n = x.shape[-1]
+        xb = x.contiguous().view(-1, n)
+        BC = xb.shape[0]
+        h = self.handle(x.device)
+        with torch.cuda.device(x.device):
+            S = self.plan.num_slices(n)
+            arena = torch.empty(self.arena_floats(BC, S), dtype=torch.float32, device=x.device)
+            nbytes = _lib.lib.xsq_slicqt_forward_workspace(h, BC, n)
+            if nbytes == 0:
+                raise _lib.XsqError("xsq_slicqt_forward_workspace: " + _lib.last_error())
+            ws = self.workspace(x.device, nbytes)
+            _lib.check(_lib.lib.xsq_slicqt_forward(h, xb.data_ptr(), BC, n, arena.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _lib.stream_ptr()), "xsq_slicqt_forward")
+        return arena, lead, S
+
+    def backward(self, arena: Tensor, BC: int, S: int, length: int) -> Tensor:
+        """arena for BC channels, S slices -> (BC, length) fp32.  `arena` is left untouched."""
+        h = self.handle(arena.device)
+        with torch.cuda.device(arena.device):
+            y = torch.empty(BC, length, dtype=torch.float32, device=arena.device)
+            nbytes = _lib.lib.xsq_slicqt_inverse_workspace(h, BC, S)
+            if nbytes == 0:
+                raise _lib.XsqError("xsq_slicqt_inverse_workspace: " + _lib.last_error())
+            ws = self.workspace(arena.device, nbytes)
+            _lib.check(_lib.lib.xsq_slicqt_inverse(h, arena.data_ptr(), BC, S, length, y.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                       "xsq_slicqt_inverse")
+        return y
+
+
+class NSGTBase(nn.Module):
+    """transforms.py:21-94.  Holds the plan; `.nsgt` is the device engine."""
+
+    def __init__(self, scale, fbins, fmin, fmax=22050.0, fgamma=15.0, fs=44100.0, device="cuda"):
+        super().__init__()
+        self.fbins = fbins
+        self.fmin = fmin
+        self.fmax = fmax
+        self.plan = build_plan(scale, fbins, fmin, fmax, fs)
+        self.sllen, self.trlen = self.plan.L, self.plan.tr
+        print(f"scale={scale}, fbins={fbins}, fmin={fmin:.2f}, fmax={fmax:.2f}, "
+              f"sllen={self.sllen}, trlen={self.trlen}")
+        self.nsgt = SliCQEngine(self.plan)
+        self.M = self.nsgt.ncoefs
+        self.fs = fs
+        self.fbins_actual = self.nsgt.fbins_actual
+
+    def predict_input_size(self, batch_size, nb_channels, seq_dur_s):
+        """transforms.py:80-90.  The block shapes follow from the plan, so no
+        transform is run (and the global RNG is left alone);
+        the returned list holds zero tensors of the right shapes."""
+        n = int(seq_dur_s * self.fs)
+        S = self.plan.num_slices(n)
+        x = torch.zeros((batch_size, nb_channels, n), dtype=torch.float32)
+        jag = [torch.zeros((batch_size, nb_channels, F, S, T, 2), dtype=torch.float32)
+               for (_, F, T) in self.plan.blocks]
+        return jag, x
+
+
+class NSGT_SL(nn.Module):
+    """transforms.py:97-131."""
+
+    def __init__(self, nsgt):
+        super().__init__()
+        self.nsgt = nsgt
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        """(nb_samples, nb_channels, nb_timesteps) -> list over blocks of
+        (nb_samples, nb_channels, F_b, nb_slices, T_b, 2), views of one arena."""
+        eng = self.nsgt.nsgt
+        arena, lead, S = eng.forward(x)
+        return eng.block_views(arena, lead, S)
+
+
+class INSGT_SL(nn.Module):
+    """transforms.py:134-178.  Accepts 6-D (B,C,F,S,T,2) or 7-D (4,B,C,F,S,T,2) blocks."""
+
+    def __init__(self, nsgt):
+        super().__init__()
+        self.nsgt = nsgt
+
+    def forward(self, X_list, length: int) -> Tensor:
+        eng = self.nsgt.nsgt
+        arena, BC, S, lead = eng.as_arena(list(X_list))
+        y = eng.backward(arena, BC, S, int(length))
+        return y.view(*lead, -1)
+
+
+class ComplexNorm(nn.Module):
+    """transforms.py:181-208: magnitude of a block list or of one tensor."""
+
+    def forward(self, spec):
+        if isinstance(spec, list):
+            return [torch.abs(torch.view_as_complex(b)) for b in spec]
+        if isinstance(spec, Tensor):
+            return self.forward([spec])[0]
+        raise ValueError(f"unsupported type for 'spec': {type(spec)}")
