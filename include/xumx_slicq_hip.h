@@ -90,6 +90,55 @@ size_t xsq_slicqt_inverse_workspace(xsq_plan* plan, int BC, int S);       /* 0 o
 int xsq_slicqt_inverse(xsq_plan* plan, const float* coef, int BC, int S, int64_t length,
                        float* y, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- CDAE model ----------------------------------------------------------------
+ * Replaces Unmix.forward (model.py:69-82) -> _SlicedUnmixCDAE.forward (model.py:213-271)
+ * for all blocks and the four targets, with the mix-phase estimate
+ * blockwise_phasemix_sep (phase.py:96-113; == mask * X) fused into
+ * the last layer.  The Wiener-EM refinement is xsq_wiener_em below.
+ *
+ * `params` is a HOST buffer: the fp32 tensors of the reference state_dict in its own
+ * key order (per block: input_mean, input_scale; per target: 0.weight, 1.{weight,bias,
+ * running_mean,running_var}, 3.weight, 4.{...}, 6.weight, 7.{...}, 9.weight, 9.bias),
+ * num_batches_tracked left out.  BatchNorm (eval) is folded at creation.
+ * `causal` != 0 selects _CausalConv2d for layer 1 (model.py:274-290).  The block table
+ * (F_b bins, T_b coefficients per slice) is the one Unmix receives through its
+ * jagged_slicq_sample_input (model.py:29-57); kf follows model.py:112-117.               */
+int64_t xsq_model_num_params(int nblocks, const int32_t* F, const int32_t* T);
+int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32_t* T,
+                     int causal, const float* params, int64_t nparams);
+int xsq_model_destroy(xsq_model* model);
+size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
+/*   X      mix coefficients, arena for 2*B channels (B, 2, ...)
+ *   Y      out: mask * X, arena for 8*B channels laid out (4 targets, B, 2, ...)
+ *   masks  out, optional (NULL to skip): sigmoid masks, REAL arena with the geometry of Y
+ *          (one float per coefficient) -- Unmix.forward(return_masks=True)             */
+int xsq_cdae_forward(xsq_model* model, const float* X, int B, int S, float* Y, float* masks,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- post-filters on the arena ---------------------------------------------------
+ * Both take an explicit block table (nblocks, F[], T[]) so that they also serve the
+ * reference's single-block helpers (phase.py) on shapes outside the sliCQT plan.
+ *
+ * xsq_phasemix replaces blockwise_phasemix_sep (phase.py:96-113, with _atan2 :72-93):
+ *   Y[j,b,c] = mag[j,b,c] * X[b,c] / |X[b,c]|   (angle(0) := 0); does not modify X
+ *   (the reference's _atan2 adds 1 to re(X) where X == 0).
+ *   X  complex arena, 2*B channels;  mag  REAL arena, 8*B channels (4, B, 2, ...);
+ *   Y  complex arena, 8*B channels.
+ *
+ * xsq_wiener_em replaces blockwise_wiener (phase.py:18-69) after the initial estimate:
+ * norbert.wiener(v, x, iterations=1, use_softmask=False) (norbert/__init__.py:153-260)
+ * per window of <= win_len frames of the flattened (slice, time) axis.
+ *   X  complex arena, 2*B channels
+ *   Y  in: initial estimates y0 = v * exp(i angle x) (what xsq_cdae_forward / xsq_phasemix
+ *      write); out: refined estimates, in place.                                        */
+int xsq_phasemix(int nblocks, const int32_t* F, const int32_t* T, const float* X,
+                 const float* mag, float* Y, int B, int S, void* stream);
+size_t xsq_wiener_workspace(int nblocks, const int32_t* F, const int32_t* T, int B, int S,
+                            int win_len);                                   /* 0 on error */
+int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* X, float* Y,
+                  int B, int S, int win_len, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

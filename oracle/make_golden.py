@@ -98,6 +98,14 @@ def main():
             blk.realtime = phasemix
         return m
 
+    import hashlib
+    ref_sd = build(False, False).state_dict()
+    desc = "\n".join(f"{k} {tuple(v.shape)}" for k, v in ref_sd.items())
+    np.savez_compressed(os.path.join(OUT, "state_dict_layout.npz"),
+                        nkeys=len(ref_sd), nparams=sum(v.numel() for v in ref_sd.values() if v.dtype.is_floating_point),
+                        sha256=hashlib.sha256(desc.encode()).hexdigest(),
+                        first_keys=np.array(list(ref_sd.keys())[:30]))
+
     models = {
         "realtime": build(True, True),       # config 1: causal conv + phasemix
         "offline_phasemix": build(False, True),   # config 2: offline conv + phasemix

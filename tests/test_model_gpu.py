@@ -1,0 +1,144 @@
+"""GPU parity of the CDAE, the post-filters and the whole Separator (through the C
+ABI) against reference-generated fixtures and the CPU oracle.
+Bar (BASELINE.json): stems within 1e-4 RMS / 1e-3 max-abs of the torch-cpu reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from xumx_slicq_amd.synth import synth_audio
+
+pytestmark = pytest.mark.gpu
+KEEP = [0, 1, 2, 4, 33, 69]
+RMS_TOL, MAX_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def seps():
+    from xumx_slicq_amd.separator import seeded_separator
+    return {
+        "realtime": seeded_separator(realtime=True),
+        "offline_phasemix": seeded_separator(realtime=False, wiener=False),
+        "offline_wiener": seeded_separator(realtime=False),
+    }
+
+
+def test_cdae_masks_match_golden(seps):
+    g = load_golden("cdae_masks_70000.npz")
+    n = int(g["n"])
+    x = synth_audio(n, seed=20260101 + n).cuda()
+    for name, tag in (("offline_wiener", "offline"), ("realtime", "causal")):
+        sep = seps[name]
+        X = sep.nsgt(x)
+        keep = [b.clone() for b in X]
+        Y, masks = sep.xumx_model(X, return_masks=True)
+        assert all(torch.equal(a, b) for a, b in zip(X, keep)), "Unmix must not modify its input"
+        assert len(Y) == len(masks) == 70
+        for i in KEEP:
+            ref = torch.from_numpy(g[f"mask_{tag}_{i}"])
+            m = masks[i].cpu()
+            assert m.shape == ref.shape and Y[i].shape == (*ref.shape, 2)
+            assert float((m - ref).abs().max()) < 5e-5, (tag, i, float((m - ref).abs().max()))
+        sums = g[f"mask_sums_{tag}"]
+        for i in range(70):
+            a = masks[i].double()
+            assert abs(float(a.sum()) - sums[i][0]) < 1e-5 * masks[i].numel() + 1e-3, (tag, i)
+
+
+def test_phasemix_is_mask_times_mix(seps):
+    n = 50000
+    x = synth_audio(n, seed=11).cuda()
+    sep = seps["offline_phasemix"]
+    X = sep.nsgt(x)
+    Y, masks = sep.xumx_model(X, return_masks=True)
+    for i in range(70):
+        want = masks[i].unsqueeze(-1) * X[i].unsqueeze(0)
+        assert torch.equal(Y[i], want), i
+
+
+def test_blockwise_wiener_matches_golden():
+    from oracle import model as omodel
+    from xumx_slicq_amd.phase import blockwise_phasemix_sep, blockwise_wiener
+    g = load_golden("wiener.npz")
+    rng = np.random.default_rng(5)
+    mix = torch.from_numpy(rng.standard_normal((1, 2, 2, 26, 200, 2)).astype(np.float32))
+    mag = torch.from_numpy(np.abs(rng.standard_normal((4, 1, 2, 2, 26, 200))).astype(np.float32))
+    mixd, magd = mix.cuda(), mag.cuda()
+    y = blockwise_wiener(mixd, magd, 5000)
+    assert torch.equal(mixd.cpu(), mix) and torch.equal(magd.cpu(), mag)
+    ref = torch.from_numpy(g["out_5200"])
+    assert y.shape == ref.shape
+    assert float((y.cpu() - ref).abs().max()) < 5e-5
+    # the initial estimate alone
+    y0 = blockwise_phasemix_sep(mixd, magd).cpu()
+    assert float((y0 - omodel.phasemix_sep(mix, mag)).abs().max()) < 1e-5
+    # the reference's own test shape (tests/test_phase.py:6-12), negative "magnitudes" included
+    rng = np.random.default_rng(6)
+    mix2 = torch.from_numpy(rng.standard_normal((1, 2, 14, 257, 37, 2)).astype(np.float32))
+    mag2 = torch.from_numpy(rng.standard_normal((4, 1, 2, 14, 257, 37)).astype(np.float32))
+    y2 = blockwise_wiener(mix2.cuda(), mag2.cuda(), 5000).cpu()
+    assert y2.shape == (4, 1, 2, 14, 257, 37, 2) and bool(torch.all(torch.isfinite(y2)))
+    sub = torch.from_numpy(g["out_testphase_sub"])
+    assert float((y2.flatten()[::97] - sub).abs().max()) < 1e-3 * max(1.0, float(sub.abs().max()))
+    # batch of 2: the window maximum is shared across the batch dimension (quirk A13)
+    rng = np.random.default_rng(8)
+    mix3 = torch.from_numpy(rng.standard_normal((2, 2, 3, 13, 100, 2)).astype(np.float32))
+    mix3[1] *= 40.0
+    mag3 = torch.from_numpy(np.abs(rng.standard_normal((4, 2, 2, 3, 13, 100))).astype(np.float32))
+    y3 = blockwise_wiener(mix3.cuda(), mag3.cuda(), 500).cpu()
+    ref3 = omodel.blockwise_wiener(mix3, mag3, 500)
+    assert float((y3 - ref3).abs().max()) < 2e-4 * float(ref3.abs().max())
+
+
+@pytest.mark.parametrize("n", [9031, 100000])
+@pytest.mark.parametrize("name", ["realtime", "offline_phasemix", "offline_wiener"])
+def test_stems_match_reference_golden(seps, n, name):
+    g = load_golden(f"stems_{n}.npz")
+    sep = seps[name]
+    sep.chunk_size = int(g["chunk_size"])
+    x = synth_audio(n, seed=20260101 + n).cuda()
+    est = sep(x)
+    assert est.shape == (4, 1, 2, n) and est.dtype == torch.float32
+    ref = torch.from_numpy(g[name])
+    got = est.cpu() if n == 9031 else est.cpu()[..., ::7]
+    d = got - ref
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert rms < RMS_TOL and mx < MAX_TOL, (name, n, rms, mx)
+    sums = g[f"{name}_sums"]
+    for t in range(4):
+        assert abs(float(est[t].double().pow(2).sum()) - sums[t][1]) < 1e-3 * sums[t][1] + 1e-6
+
+
+@pytest.mark.parametrize("name,causal,wiener,n,B", [
+    ("realtime", True, False, 441000, 1),            # BASELINE config 1 shape (10 s)
+    ("offline_wiener", False, True, 150000, 2),      # batch of 2, several Wiener windows
+    ("offline_phasemix", False, False, 200000, 1),
+])
+def test_stems_match_oracle_at_larger_sizes(seps, oracle_plan, seeded_sd, name, causal, wiener, n, B):
+    from oracle import separator as osep
+    sep = seps[name]
+    sep.chunk_size = 2621440
+    x = synth_audio(n, seed=3 + n, nb_samples=B)
+    est = sep(x.cuda()).cpu()
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=causal, wiener=wiener)
+    d = est - ref
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert est.shape == (4, B, 2, n)
+    assert rms < RMS_TOL and mx < MAX_TOL, (name, rms, mx)
+
+
+def test_full_chunk_properties(seps):
+    """At BASELINE size (one full 59.4 s chunk + a short tail) the oracle is too slow for a
+    unit test; check size-independent properties instead: finite, deterministic, mix-phase
+    stems sum consistency, chunk independence (hard concat)."""
+    sep = seps["offline_phasemix"]
+    sep.chunk_size = 2621440
+    n = 2621440 + 98240
+    x = synth_audio(n, seed=99).cuda()
+    a = sep(x)
+    b = sep(x)
+    assert a.shape == (4, 1, 2, n) and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b), "the path must be bitwise deterministic"
+    tail = sep(x[..., 2621440:])
+    assert torch.equal(a[..., 2621440:], tail), "chunks are independent work items"
+    assert float(a.abs().max()) < 10.0 and float(a.pow(2).mean()) > 1e-4

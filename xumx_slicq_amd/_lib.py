@@ -51,6 +51,14 @@ _SIGS = {
     "xsq_slicqt_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_model_num_params": (C.c_int64, [C.c_int, _vp, _vp]),
+    "xsq_model_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64]),
+    "xsq_model_destroy": (C.c_int, [_vp]),
+    "xsq_cdae_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "xsq_cdae_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_phasemix": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "xsq_wiener_workspace": (C.c_size_t, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "xsq_wiener_em": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

@@ -40,9 +40,10 @@ struct CdaeBlockDev {
 }  // namespace xsq
 
 struct xsq_model {
-    xsq_plan* plan = nullptr;
     int causal = 0;
     int nblocks = 0;
+    int64_t sumFT = 0;             // complex coefficients per channel-slice
+    std::vector<xsq::BlockHost> table;
     std::vector<xsq::CdaeBlockDev> blocks;
     int64_t sumF = 0, sumF1 = 0, sumF2 = 0;
     xsq::CdaeBlockDev* d_blocks = nullptr;
@@ -297,7 +298,7 @@ struct CdaeL4Op {
     }
     __device__ void put(const Group& g, int b, int f, int u, int n, float acc) const {
         const int c = n / g.hop, dt = n - c * g.hop;
-        const float mask = 1.f / (1.f + __expf(-(acc + g.shift[c])));
+        const float mask = 1.f / (1.f + expf(-(acc + g.shift[c])));
         const int64_t ST = (int64_t)a.S * g.T;
         const int64_t tau = (int64_t)u * g.hop + dt;
         const int64_t xi = (int64_t)a.Bn * 2 * a.S * g.cum + ((int64_t)(b * 2 + c) * g.F + f) * ST + tau;
@@ -360,26 +361,35 @@ using namespace xsq;
 
 extern "C" {
 
-int64_t xsq_model_num_params(const xsq_plan* P) {
-    if (!P) return XSQ_ERR_ARG;
+int64_t xsq_model_num_params(int nblocks, const int32_t* F, const int32_t* T) {
+    if (!F || !T || nblocks <= 0) return XSQ_ERR_ARG;
     int64_t n = 0;
-    for (const BlockHost& b : P->blocks) {
-        const int kf = kf_of(b.F);
-        n += 2 * b.F;
-        n += NT * ((int64_t)H1 * 2 * kf * b.T + 4 * H1 + (int64_t)H2 * H1 * kf * 4 + 4 * H2 +
-                   (int64_t)H2 * H1 * kf * 4 + 4 * H1 + (int64_t)H1 * 2 * kf * b.T + 2);
+    for (int b = 0; b < nblocks; ++b) {
+        const int kf = kf_of(F[b]);
+        n += 2 * F[b];
+        n += NT * ((int64_t)H1 * 2 * kf * T[b] + 4 * H1 + (int64_t)H2 * H1 * kf * 4 + 4 * H2 +
+                   (int64_t)H2 * H1 * kf * 4 + 4 * H1 + (int64_t)H1 * 2 * kf * T[b] + 2);
     }
     return n;
 }
 
-int xsq_model_create(xsq_model** out, xsq_plan* P, int causal, const float* params, int64_t nparams) {
-    XSQ_REQUIRE(out && P && params, "xsq_model_create: null argument");
-    XSQ_REQUIRE(nparams == xsq_model_num_params(P), "xsq_model_create: got %lld parameters, the plan needs %lld",
-                (long long)nparams, (long long)xsq_model_num_params(P));
-    for (const BlockHost& b : P->blocks)
-        XSQ_REQUIRE(b.F - 2 * (kf_of(b.F) - 1) >= 1, "xsq_model_create: block with F=%d too small", b.F);
+int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
+                     const float* params, int64_t nparams) {
+    XSQ_REQUIRE(out && F && T && params && nblocks > 0, "xsq_model_create: null argument");
+    XSQ_REQUIRE(nparams == xsq_model_num_params(nblocks, F, T),
+                "xsq_model_create: got %lld parameters, the block table needs %lld", (long long)nparams,
+                (long long)xsq_model_num_params(nblocks, F, T));
+    struct PlanLike { std::vector<BlockHost> blocks; int nblocks; int64_t sumFT; } PL;
+    PL.nblocks = nblocks; PL.sumFT = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        XSQ_REQUIRE(F[b] >= 1 && T[b] >= 4 && T[b] % 4 == 0, "xsq_model_create: block %d has F=%d T=%d", b, F[b], T[b]);
+        XSQ_REQUIRE(F[b] - 2 * (kf_of(F[b]) - 1) >= 1, "xsq_model_create: block with F=%d too small", F[b]);
+        PL.blocks.push_back(BlockHost{0, F[b], T[b], PL.sumFT});
+        PL.sumFT += (int64_t)F[b] * T[b];
+    }
+    PlanLike* P = &PL;
     xsq_model* Mo = new xsq_model();
-    Mo->plan = P; Mo->causal = causal ? 1 : 0; Mo->nblocks = P->nblocks;
+    Mo->causal = causal ? 1 : 0; Mo->nblocks = nblocks; Mo->sumFT = PL.sumFT; Mo->table = PL.blocks;
     const double eps = 1e-5;
     std::vector<float> pool, mean, scale;
     std::vector<int64_t> cum(P->nblocks + 1, 0);
@@ -497,7 +507,7 @@ int xsq_model_destroy(xsq_model* Mo) {
 size_t xsq_cdae_workspace(const xsq_model* Mo, int Bn, int S) {
     if (!Mo || Bn <= 0 || S < 3) return 0;
     const int64_t T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
-    return al((size_t)Bn * 2 * S * Mo->plan->sumFT * 4) + 2 * al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4) +
+    return al((size_t)Bn * 2 * S * Mo->sumFT * 4) + 2 * al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4) +
            al((size_t)CS * Bn * T2 * 4 * Mo->sumF2 * 4) + 256;
 }
 
@@ -507,14 +517,13 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_cdae_forward: Bn=%d S=%d (the conv stack needs >= 3 slices)", Bn, S);
     XSQ_REQUIRE(ws_bytes >= xsq_cdae_workspace(Mo, Bn, S), "xsq_cdae_forward: workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
-    const xsq_plan* P = Mo->plan;
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
     char* w = (char*)ws;
-    float* xin = (float*)w;  w += al((size_t)Bn * 2 * S * P->sumFT * 4);
+    float* xin = (float*)w;  w += al((size_t)Bn * 2 * S * Mo->sumFT * 4);
     float* act1 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
-    const int64_t total = (int64_t)Bn * 2 * S * P->sumFT;
+    const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
     hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        (const float2*)X, xin, Mo->d_cum, Mo->d_blockF, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
                        Mo->nblocks, Bn * 2, S, total);

@@ -1,0 +1,316 @@
+// Mix-phase estimate and norbert Wiener-EM (one iteration) on the coefficient arena, gfx950.
+//
+// Reference: xumx_slicq_v2/phase.py:18-69 (blockwise_wiener: windows of <= 5000 frames over the
+// flattened (slice, time) axis), :96-113 (blockwise_phasemix_sep); norbert/__init__.py:153-260
+// (wiener, iterations=1, use_softmask=False) -> expectation_maximization :10-150 ->
+// get_local_gaussian_model :458-494, get_mix_model :416-437, _invert :312-350,
+// wiener_gain :353-388, apply_filter :391-413.
+//
+// Per (block, window w, batch item b, bin f) with frames n in the window, channels c,d in {0,1},
+// sources j in {0..3}, y0 = initial estimate (mask * X), ma = max(1, 0.1 * max |x|) over the whole
+// window INCLUDING the batch dimension (norbert :257), y' = y0/ma, x' = x/ma:
+//   v'[n,j]  = mean_c |y'[n,c,j]|^2
+//   R[j]     = sum_n y'[n,:,j] y'[n,:,j]^H / (sum_n v'[n,j] + eps)          eps = FLT_EPSILON
+//   Cxx[n]   = sum_j v'[n,j] R[j] + sqrt(eps) I ;  y[n,:,j] = ma * v'[n,j] R[j] Cxx[n]^-1 x'[n]
+// Three launches: k_wiener_stats (raw sums + max per row/window, fixed-order LDS tree, no atomics
+// -> bitwise reproducible), k_wiener_finalize (window max, R), k_wiener_apply (elementwise 2x2
+// solve, in place on Y).  All reads/writes are contiguous along the frame axis.
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xumx_slicq_hip.h"
+#include "plan.h"
+
+namespace xsq {
+
+static const int STAT = 20;   // floats per (row, window): 4 sources x (C00, C11, Re C01, Im C01), max|x|^2, pad
+
+struct WRow {          // one (block, batch item, bin) row of the arena
+    int F, T;          // block geometry
+    int b, f;          // batch item, bin
+    int nwin;          // windows of this block
+    int first_row;     // first row index of this row's block (rows of a block are consecutive)
+    int nrows;         // rows in the block (B*F)
+    int pad;
+    int64_t cum;       // sum over earlier blocks of F*T
+    int64_t stat;      // float offset of this row's window 0 in the stats buffer
+};
+
+struct WTable {
+    WRow* d_rows = nullptr;
+    int* d_work = nullptr;     // (row, window) pairs for the stats / finalize launches
+    int nrows = 0, nwork = 0, nblockwin = 0;
+    int* d_blockwin = nullptr; // (first_row, window) per (block, window)
+    int64_t stat_floats = 0;
+    int64_t max_frames = 0;
+};
+
+static std::mutex g_wmu;
+static std::map<std::vector<int>, WTable> g_wtables;
+
+__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+
+// complex arena index of (chan, f, frame n) for a block; nchan = packed channels of the arena
+__device__ inline int64_t cidx(const WRow& r, int nchan, int S, int chan, int64_t n) {
+    return (int64_t)nchan * S * r.cum + ((int64_t)chan * r.F + r.f) * ((int64_t)S * r.T) + n;
+}
+
+// ---- Y = mag * x/|x|  (phase.py:96-113; angle(0) = 0) --------------------------------------------
+__global__ __launch_bounds__(256) void k_phasemix(const float2* __restrict__ X, const float* __restrict__ mag,
+                                                   float2* __restrict__ Y, const WRow* __restrict__ rows, int Bn,
+                                                   int S) {
+    const WRow r = rows[blockIdx.y];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float2 x = X[cidx(r, 2 * Bn, S, r.b * 2 + c, n)];
+        const float ax = sqrtf(x.x * x.x + x.y * x.y);
+        const float2 u = ax > 0.f ? make_float2(x.x / ax, x.y / ax) : make_float2(1.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t yi = cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2 + c, n);
+            const float m = mag[yi];
+            Y[yi] = make_float2(m * u.x, m * u.y);
+        }
+    }
+}
+
+// ---- pass 1: raw sums and max per (row, window).  One workgroup per (row, window). -----------------
+__global__ __launch_bounds__(256) void k_wiener_stats(const float2* __restrict__ X, const float2* __restrict__ Y,
+                                                       const WRow* __restrict__ rows, const int* __restrict__ work,
+                                                       float* __restrict__ stats, int Bn, int S, int win_len) {
+    const int row = work[2 * blockIdx.x], w = work[2 * blockIdx.x + 1];
+    const WRow r = rows[row];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n0 = (int64_t)w * win_len;
+    const int64_t n1 = n0 + win_len < N ? n0 + win_len : N;
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+    const float2* x0 = X + cidx(r, 2 * Bn, S, r.b * 2, 0);
+    const float2* x1 = X + cidx(r, 2 * Bn, S, r.b * 2 + 1, 0);
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+        const float2 a = x0[n], b = x1[n];
+        acc[16] = fmaxf(acc[16], fmaxf(a.x * a.x + a.y * a.y, b.x * b.x + b.y * b.y));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 y0 = Y[cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2, n)];
+            const float2 y1 = Y[cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2 + 1, n)];
+            const float2 c01 = cmulc(y0, y1);
+            acc[4 * j + 0] += y0.x * y0.x + y0.y * y0.y;
+            acc[4 * j + 1] += y1.x * y1.x + y1.y * y1.y;
+            acc[4 * j + 2] += c01.x;
+            acc[4 * j + 3] += c01.y;
+        }
+    }
+    // wavefront butterfly, then a fixed-order sum of the 4 wave partials
+    __shared__ float red[4][17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v, off, 64);
+            v = (i == 16) ? fmaxf(v, o) : v + o;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        const int i = threadIdx.x;
+        float v;
+        if (i == 16) v = fmaxf(fmaxf(red[0][i], red[1][i]), fmaxf(red[2][i], red[3][i]));
+        else v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        stats[r.stat + (int64_t)w * STAT + i] = v;
+    }
+}
+
+// ---- pass 2: window max over all rows of the block, then R per row.  One workgroup per (block, window).
+__global__ __launch_bounds__(256) void k_wiener_finalize(const WRow* __restrict__ rows,
+                                                          const int* __restrict__ blockwin,
+                                                          float* __restrict__ stats) {
+    const int first = blockwin[2 * blockIdx.x], w = blockwin[2 * blockIdx.x + 1];
+    const int nrows = rows[first].nrows;
+    __shared__ float smax[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nrows; i += 256) m = fmaxf(m, stats[rows[first + i].stat + (int64_t)w * STAT + 16]);
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+        __syncthreads();
+    }
+    const float ma = fmaxf(1.f, 0.1f * sqrtf(smax[0]));     // norbert :257
+    const float inv_ma2 = 1.f / (ma * ma);
+    const float eps = FLT_EPSILON;
+    for (int i = threadIdx.x; i < nrows; i += 256) {
+        float* st = stats + rows[first + i].stat + (int64_t)w * STAT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c00 = st[4 * j] * inv_ma2, c11 = st[4 * j + 1] * inv_ma2;
+            const float den = 1.f / (0.5f * (c00 + c11) + eps);   // sum_n mean_c |y'|^2 + eps   (:491-493)
+            st[4 * j] = c00 * den;
+            st[4 * j + 1] = c11 * den;
+            st[4 * j + 2] = st[4 * j + 2] * inv_ma2 * den;
+            st[4 * j + 3] = st[4 * j + 3] * inv_ma2 * den;
+        }
+        st[16] = inv_ma2;
+    }
+}
+
+// ---- pass 3: per time-frequency point 2x2 solve and filter, in place on Y ---------------------------
+__global__ __launch_bounds__(256) void k_wiener_apply(const float2* __restrict__ X, float2* __restrict__ Y,
+                                                       const WRow* __restrict__ rows, const float* __restrict__ stats,
+                                                       int Bn, int S, int win_len) {
+    const WRow r = rows[blockIdx.y];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* st = stats + r.stat + (n / win_len) * STAT;
+    const float inv_ma2 = st[16];
+    const float2 x0 = X[cidx(r, 2 * Bn, S, r.b * 2, n)];
+    const float2 x1 = X[cidx(r, 2 * Bn, S, r.b * 2 + 1, n)];
+    float v[4];
+    float2 R01[4];
+    float R00[4], R11[4];
+    int64_t yi[4];
+    const float reg = sqrtf(FLT_EPSILON);
+    float c00 = reg, c11 = reg;
+    float2 c01 = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        yi[j] = cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2, n);
+        const float2 y0 = Y[yi[j]];
+        const float2 y1 = Y[yi[j] + (int64_t)r.F * N];
+        v[j] = 0.5f * ((y0.x * y0.x + y0.y * y0.y) * inv_ma2 + (y1.x * y1.x + y1.y * y1.y) * inv_ma2);
+        R00[j] = st[4 * j]; R11[j] = st[4 * j + 1]; R01[j] = make_float2(st[4 * j + 2], st[4 * j + 3]);
+        c00 += v[j] * R00[j];
+        c11 += v[j] * R11[j];
+        c01.x += v[j] * R01[j].x;
+        c01.y += v[j] * R01[j].y;
+    }
+    // Cxx = [[c00, c01], [conj(c01), c11]];  analytic inverse (norbert _invert :337-346)
+    const float det = c00 * c11 - (c01.x * c01.x + c01.y * c01.y);
+    const float idet = 1.f / det;
+    const float i00 = c11 * idet, i11 = c00 * idet;
+    const float2 i01 = make_float2(-c01.x * idet, -c01.y * idet);    // -c01/det
+    const float2 i10 = make_float2(-c01.x * idet, c01.y * idet);     // -conj(c01)/det
+    // z = Cxx^-1 x
+    const float2 z0 = make_float2(i00 * x0.x + (i01.x * x1.x - i01.y * x1.y), i00 * x0.y + (i01.x * x1.y + i01.y * x1.x));
+    const float2 z1 = make_float2((i10.x * x0.x - i10.y * x0.y) + i11 * x1.x, (i10.x * x0.y + i10.y * x0.x) + i11 * x1.y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // y_j = v_j R_j z ;  R_j = [[R00, R01], [conj(R01), R11]]
+        const float2 a = cmul(R01[j], z1);
+        const float2 b = cmulc(z0, R01[j]);      // conj(R01) * z0
+        Y[yi[j]] = make_float2(v[j] * (R00[j] * z0.x + a.x), v[j] * (R00[j] * z0.y + a.y));
+        Y[yi[j] + (int64_t)r.F * N] = make_float2(v[j] * (b.x + R11[j] * z1.x), v[j] * (b.y + R11[j] * z1.y));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, WTable* out) {
+    std::vector<int> key;
+    key.push_back(nblocks); key.push_back(Bn); key.push_back(S); key.push_back(win_len);
+    for (int b = 0; b < nblocks; ++b) { key.push_back(F[b]); key.push_back(T[b]); }
+    std::lock_guard<std::mutex> lk(g_wmu);
+    auto it = g_wtables.find(key);
+    if (it != g_wtables.end()) { *out = it->second; return XSQ_OK; }
+    std::vector<WRow> rows;
+    std::vector<int> work, blockwin;
+    int64_t cum = 0, stat = 0, maxN = 0;
+    for (int k = 0; k < nblocks; ++k) {
+        const int64_t N = (int64_t)S * T[k];
+        const int nwin = (int)((N + win_len - 1) / win_len);
+        const int first = (int)rows.size();
+        maxN = N > maxN ? N : maxN;
+        for (int b = 0; b < Bn; ++b)
+            for (int f = 0; f < F[k]; ++f) {
+                WRow r;
+                r.F = F[k]; r.T = T[k]; r.b = b; r.f = f; r.nwin = nwin; r.first_row = first;
+                r.nrows = Bn * F[k]; r.pad = 0; r.cum = cum; r.stat = stat;
+                for (int w = 0; w < nwin; ++w) { work.push_back((int)rows.size()); work.push_back(w); }
+                rows.push_back(r);
+                stat += (int64_t)nwin * STAT;
+            }
+        for (int w = 0; w < nwin; ++w) { blockwin.push_back(first); blockwin.push_back(w); }
+        cum += (int64_t)F[k] * T[k];
+    }
+    WTable t;
+    t.nrows = (int)rows.size(); t.nwork = (int)work.size() / 2; t.nblockwin = (int)blockwin.size() / 2;
+    t.stat_floats = stat; t.max_frames = maxN;
+    XSQ_HIP(hipMalloc(&t.d_rows, rows.size() * sizeof(WRow)));
+    XSQ_HIP(hipMemcpy(t.d_rows, rows.data(), rows.size() * sizeof(WRow), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&t.d_work, work.size() * sizeof(int)));
+    XSQ_HIP(hipMemcpy(t.d_work, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&t.d_blockwin, blockwin.size() * sizeof(int)));
+    XSQ_HIP(hipMemcpy(t.d_blockwin, blockwin.data(), blockwin.size() * sizeof(int), hipMemcpyHostToDevice));
+    g_wtables[key] = t;
+    *out = t;
+    return XSQ_OK;
+}
+
+static int check_table(const char* who, int nblocks, const int32_t* F, const int32_t* T, int Bn, int S) {
+    XSQ_REQUIRE(nblocks > 0 && F && T, "%s: null block table", who);
+    XSQ_REQUIRE(Bn > 0 && S > 0, "%s: B=%d S=%d", who, Bn, S);
+    int64_t rows = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        XSQ_REQUIRE(F[b] > 0 && T[b] > 0, "%s: block %d has F=%d T=%d", who, b, F[b], T[b]);
+        rows += (int64_t)Bn * F[b];
+    }
+    XSQ_REQUIRE(rows <= 65535, "%s: %lld rows exceed one launch", who, (long long)rows);
+    return XSQ_OK;
+}
+
+}  // namespace xsq
+
+using namespace xsq;
+
+extern "C" {
+
+int xsq_phasemix(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* mag, float* Y,
+                 int Bn, int S, void* stream_) {
+    int rc = check_table("xsq_phasemix", nblocks, F, T, Bn, S);
+    if (rc) return rc;
+    XSQ_REQUIRE(X && mag && Y, "xsq_phasemix: null argument");
+    WTable t;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, 5000, &t))) return rc;
+    hipLaunchKernelGGL(k_phasemix, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0,
+                       (hipStream_t)stream_, (const float2*)X, mag, (float2*)Y, t.d_rows, Bn, S);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+size_t xsq_wiener_workspace(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len) {
+    if (nblocks <= 0 || !F || !T || Bn <= 0 || S <= 0 || win_len <= 0) return 0;
+    int64_t stat = 0;
+    for (int k = 0; k < nblocks; ++k)
+        stat += (int64_t)Bn * F[k] * (((int64_t)S * T[k] + win_len - 1) / win_len) * STAT;
+    return (size_t)stat * 4 + 256;
+}
+
+int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* X, float* Y, int Bn, int S,
+                  int win_len, void* ws, size_t ws_bytes, void* stream_) {
+    int rc = check_table("xsq_wiener_em", nblocks, F, T, Bn, S);
+    if (rc) return rc;
+    XSQ_REQUIRE(X && Y && ws, "xsq_wiener_em: null argument");
+    XSQ_REQUIRE(win_len > 0, "xsq_wiener_em: win_len=%d", win_len);
+    XSQ_REQUIRE(ws_bytes >= xsq_wiener_workspace(nblocks, F, T, Bn, S, win_len), "xsq_wiener_em: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    WTable t;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, &t))) return rc;
+    float* stats = (float*)ws;
+    hipLaunchKernelGGL(k_wiener_stats, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, (const float2*)Y,
+                       t.d_rows, t.d_work, stats, Bn, S, win_len);
+    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats);
+    hipLaunchKernelGGL(k_wiener_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
+                       (const float2*)X, (float2*)Y, t.d_rows, stats, Bn, S, win_len);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+}  // extern "C"

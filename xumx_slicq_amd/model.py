@@ -1,0 +1,214 @@
+"""Drop-in mirror of /root/reference/xumx_slicq_v2/model.py (Unmix,
+_SlicedUnmixCDAE, _CausalConv2d) on top of the HIP library.
+
+The modules hold the parameters under exactly the reference's ``state_dict``
+keys (the same ``nn.Sequential`` skeleton), so reference checkpoints load
+unchanged; they are parameter holders only.  ``Unmix.forward`` packs the
+parameters once (BatchNorm folded in csrc/cdae.hip) and runs all 70 blocks x 4
+targets in grouped HIP launches.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+from torch.nn import BatchNorm2d, Conv2d, ConvTranspose2d, Parameter, ReLU, Sequential, Sigmoid
+
+from . import _lib
+from .arena import BlockTable
+from .weights import freq_filter
+
+
+class _CausalConv2d(Conv2d):
+    """model.py:274-290: left-pads time by kernel_width-1 (parameter holder here)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True):
+        self._left_pad = kernel_size[1] - 1
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=0, bias=bias)
+
+
+class _SlicedUnmixCDAE(nn.Module):
+    """model.py:86-211: the four target CDAEs of one time-frequency block."""
+
+    def __init__(self, slicq_sample_input, hidden_size_1: int = 50, hidden_size_2: int = 51,
+                 freq_filter_small: int = 1, freq_filter_medium: int = 3, freq_filter_large: int = 5,
+                 freq_thresh_small: int = 10, freq_thresh_medium: int = 20, time_filter_2: int = 4,
+                 realtime: bool = False, input_mean=None, input_scale=None):
+        super().__init__()
+        if (hidden_size_1, hidden_size_2, time_filter_2) != (50, 51, 4) or \
+                (freq_filter_small, freq_filter_medium, freq_filter_large,
+                 freq_thresh_small, freq_thresh_medium) != (1, 3, 5, 10, 20):
+            raise ValueError("the HIP kernels are built for the reference's default CDAE geometry "
+                             "(hidden 50/51, time filter 4, frequency filters 1/3/5 at thresholds 10/20)")
+        nb_samples, nb_channels, nb_f_bins, nb_slices, nb_t_bins = slicq_sample_input.shape
+        if nb_channels != 2:
+            raise ValueError("the hot path is stereo (nb_channels == 2)")
+        kf = freq_filter(nb_f_bins)
+        window, hop = nb_t_bins, nb_t_bins // 2
+        first = _CausalConv2d if realtime else Conv2d
+        layers = [
+            first(nb_channels, hidden_size_1, (kf, window), stride=(1, hop), bias=False),
+            BatchNorm2d(hidden_size_1), ReLU(),
+            Conv2d(hidden_size_1, hidden_size_2, (kf, time_filter_2), bias=False),
+            BatchNorm2d(hidden_size_2), ReLU(),
+            ConvTranspose2d(hidden_size_2, hidden_size_1, (kf, time_filter_2), bias=False),
+            BatchNorm2d(hidden_size_1), ReLU(),
+            ConvTranspose2d(hidden_size_1, nb_channels, (kf, window), stride=(1, hop), bias=True),
+            Sigmoid(),
+        ]
+        cdae = Sequential(*layers)
+        self.cdaes = nn.ModuleList([cdae] + [copy.deepcopy(cdae) for _ in range(3)])
+        self.mask = True
+        self.realtime = realtime          # read per call: True -> mix-phase, False -> Wiener-EM (model.py:264)
+        self.causal = realtime            # fixed at construction (model.py:125-128)
+        self.nb_f_bins, self.nb_t_bins = nb_f_bins, nb_t_bins
+        mean = torch.from_numpy(-input_mean).float() if input_mean is not None else torch.zeros(nb_f_bins)
+        scale = torch.from_numpy(1.0 / input_scale).float() if input_scale is not None else torch.ones(nb_f_bins)
+        self.input_mean = Parameter(mean)
+        self.input_scale = Parameter(scale)
+
+    def freeze(self):
+        for p in self.parameters():
+            p.grad = None
+        self.eval()
+
+    def forward(self, xcomplex: Tensor, x: Tensor):
+        raise NotImplementedError(
+            "blocks are not run one by one on the HIP path: call Unmix.forward, which runs every block "
+            "and target in grouped launches")
+
+
+class Unmix(nn.Module):
+    """model.py:29-82."""
+
+    def __init__(self, jagged_slicq_sample_input, realtime: bool = False, lstm: bool = False,
+                 input_means=None, input_scales=None):
+        super().__init__()
+        if lstm:
+            raise ValueError("the LSTM variant is not on the accelerated path (SURVEY.md 2, row 4b)")
+        self.sliced_umx = nn.ModuleList()
+        shapes = []
+        for i, C_block in enumerate(jagged_slicq_sample_input):
+            self.sliced_umx.append(_SlicedUnmixCDAE(
+                C_block, realtime=realtime,
+                input_mean=input_means[i] if input_means else None,
+                input_scale=input_scales[i] if input_scales else None))
+            shapes.append((C_block.shape[2], C_block.shape[4]))
+        self.table = BlockTable(shapes)
+        self._F = np.asarray([s[0] for s in shapes], dtype=np.int32)
+        self._T = np.asarray([s[1] for s in shapes], dtype=np.int32)
+        self._handles = {}      # device index -> (version, handle)
+        self._ws = {}
+
+    def freeze(self):
+        for p in self.parameters():
+            p.grad = None
+        self.eval()
+
+    # -- parameter packing -------------------------------------------------------
+    # The folded device copy is rebuilt whenever the parameters can have changed through
+    # the module API (load_state_dict, .to()/.float()/..., .train()); after editing
+    # parameter tensors in place by hand, call refresh().
+    def refresh(self):
+        self._stamp = getattr(self, "_stamp", 0) + 1
+
+    def _version(self) -> int:
+        return getattr(self, "_stamp", 0)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.refresh()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.refresh()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self.refresh()
+        return super().train(mode)
+
+    def packed_parameters(self) -> np.ndarray:
+        """fp32 tensors of the state_dict in key order, num_batches_tracked left out
+        (the host buffer xsq_model_create expects)."""
+        parts = [v.detach().to("cpu", torch.float32).reshape(-1)
+                 for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")]
+        return torch.cat(parts).numpy()
+
+    def _model(self, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.XsqError(f"Unmix runs on a ROCm device only (got '{device}'); there is no CPU fallback")
+        if self.training:
+            raise _lib.XsqError("the HIP CDAE is the inference path (BatchNorm folded); call .eval()/.freeze()")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ver = self._version()
+        cached = self._handles.get(idx)
+        if cached is not None and cached[0] == ver:
+            return cached[1]
+        if cached is not None:
+            _lib.lib.xsq_model_destroy(cached[1])
+        params = self.packed_parameters()
+        causal = {blk.causal for blk in self.sliced_umx}
+        if len(causal) != 1:
+            raise _lib.XsqError("all blocks must share the same first-layer type")
+        out = C.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib.xsq_model_create(
+                C.byref(out), len(self.table), self._F.ctypes.data, self._T.ctypes.data,
+                1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
+        self._handles[idx] = (ver, out)
+        return out
+
+    def __del__(self):
+        try:
+            for _, h in self._handles.values():
+                _lib.lib.xsq_model_destroy(h)
+        except Exception:
+            pass
+
+    def _workspace(self, device, nbytes):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws[key] = None
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # -- forward -----------------------------------------------------------------------
+    def forward(self, Xcomplex: List[Tensor], return_masks=False):
+        """list over blocks of (B, 2, F_b, S, T_b, 2) -> list of (4, B, 2, F_b, S, T_b, 2)
+        [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82."""
+        from .phase import wiener_em_arena
+        X, lead, S = self.table.as_arena(list(Xcomplex))
+        if len(lead) != 2 or lead[1] != 2:
+            raise ValueError(f"expected blocks of shape (nb_samples, 2, F, S, T, 2); got lead dims {lead}")
+        B = lead[0]
+        dev = X.device
+        h = self._model(dev)
+        modes = {bool(blk.realtime) for blk in self.sliced_umx}
+        if len(modes) != 1:
+            raise _lib.XsqError("mixed per-block post-filters (some mix-phase, some Wiener) are not supported")
+        phasemix = modes.pop()
+        with torch.cuda.device(dev):
+            Y = torch.empty(self.table.numel(8 * B, S), dtype=torch.float32, device=dev)
+            masks = torch.empty(self.table.numel(8 * B, S, complex_=False), dtype=torch.float32,
+                                device=dev) if return_masks else None
+            nbytes = _lib.lib.xsq_cdae_workspace(h, B, S)
+            if nbytes == 0:
+                raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
+            ws = self._workspace(dev, nbytes)
+            _lib.check(_lib.lib.xsq_cdae_forward(
+                h, X.data_ptr(), B, S, Y.data_ptr(), masks.data_ptr() if return_masks else None,
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
+            if not phasemix:
+                wiener_em_arena(self.table, X, Y, B, S)
+        Ylist = self.table.views(Y, (4, B, 2), S)
+        if return_masks:
+            return Ylist, self.table.views(masks, (4, B, 2), S, complex_=False)
+        return Ylist

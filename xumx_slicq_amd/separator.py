@@ -1,0 +1,157 @@
+"""Drop-in mirror of /root/reference/xumx_slicq_v2/separator.py (Separator,
+load_target_models) for the ROCm backend.
+
+Same class/function names, arguments, attribute names, output layout
+(targets first: (4, nb_samples, 2, N)) and exceptions as
+the reference's torch path.  The ONNX runtimes and the GitHub download are
+outside the accelerated path.
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .model import Unmix
+from .transforms import ComplexNorm, NSGTBase, make_filterbanks
+from .weights import seeded_state_dict
+
+# the reference's list (separator.py:29) plus the backend this package provides
+_SUPPORTED_RUNTIMES = ["torch-cpu", "torch-cuda", "onnx-cpu", "onnx-cuda", "hip-rocm"]
+_ACCELERATED = "hip-rocm"
+
+
+class Separator(nn.Module):
+    sources = ["bass", "vocals", "other", "drums"]      # separator.py:48
+
+    @classmethod
+    def load(cls, chunk_size: int = 2621440, model_path: Optional[str] = None,
+             runtime_backend: Optional[str] = _ACCELERATED, warmup: int = 0, realtime: bool = False,
+             device: Union[str, torch.device] = "cuda"):
+        """separator.py:50-93."""
+        if runtime_backend not in _SUPPORTED_RUNTIMES:
+            raise ValueError(f"requested runtime backend {runtime_backend} not in {_SUPPORTED_RUNTIMES}")
+        xumx_model, encoder, sample_rate = load_target_models(
+            model_path, runtime_backend=runtime_backend, realtime=realtime, device=device)
+        separator = cls(xumx_model=xumx_model, encoder=encoder, sample_rate=sample_rate,
+                        runtime_backend=runtime_backend, chunk_size=chunk_size, device=device).to(device)
+        separator.freeze()
+        for _ in range(warmup):
+            waveform = torch.rand((1, 2, int(100 * sample_rate)), dtype=torch.float32, device=device)
+            separator.forward(waveform)
+        return separator
+
+    def __init__(self, xumx_model: Unmix = None, encoder: Tuple = None, runtime_backend: str = _ACCELERATED,
+                 sample_rate: float = 44100.0, chunk_size: Optional[int] = 2621440, device: str = "cuda",
+                 quiet: bool = False):
+        super().__init__()
+        if runtime_backend != _ACCELERATED:
+            raise ValueError(f"this package provides the '{_ACCELERATED}' backend only (got {runtime_backend}); "
+                             "use the reference for torch-*/onnx-*")
+        self.device = device
+        self.nb_channels = 2
+        self.register_buffer("sample_rate", torch.as_tensor(sample_rate))
+        self.chunk_size = chunk_size if chunk_size is not None else sys.maxsize
+        self.xumx_model = xumx_model
+        self.runtime_backend = runtime_backend
+        self.nsgt, self.insgt, self.cnorm = encoder
+        self.quiet = quiet
+        self.sources = Separator.sources
+
+    def freeze(self):
+        for p in self.parameters():
+            p.grad = None
+        self.xumx_model.freeze()
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, audio_big: Tensor) -> Tensor:
+        """(nb_samples, 2, N) fp32 on a ROCm device -> (4, nb_samples, 2, N).  separator.py:133-232:
+        sequential chunks of chunk_size samples, short chunks zero-padded to sllen/2+1, hard concat."""
+        N = audio_big.shape[-1]
+        final_estimates = []
+        min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
+        for start in range(0, N, self.chunk_size):
+            audio = audio_big[..., start:min(start + self.chunk_size, N)]
+            n_samples = audio.shape[-1]
+            if n_samples < min_samples:
+                audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
+                                                      device=audio.device, dtype=audio.dtype)], dim=-1)
+            X = self.nsgt(audio)
+            Ycomplex_all = self.xumx_model(X)
+            final_estimates.append(self.insgt(Ycomplex_all, n_samples))
+        return final_estimates[0] if len(final_estimates) == 1 else torch.cat(final_estimates, axis=-1)
+
+    @staticmethod
+    def to_dict(estimates: Tensor, aggregate_dict: Optional[dict] = None) -> dict:
+        """separator.py:234-259."""
+        estimates_dict = {target: estimates[k] for k, target in enumerate(Separator.sources)}
+        if aggregate_dict is not None:
+            new_estimates = {}
+            for key in aggregate_dict:
+                new_estimates[key] = torch.tensor(0.0)
+                for target in aggregate_dict[key]:
+                    new_estimates[key] = new_estimates[key] + estimates_dict[target]
+            estimates_dict = new_estimates
+        return estimates_dict
+
+
+def build_models(fscale: str = "bark", fbins: int = 262, fmin: float = 32.9, sample_rate: float = 44100.0,
+                 seq_dur: float = 2.0, realtime: bool = False, device="cuda", state=None,
+                 strict: bool = True):
+    """Plan + filterbanks + Unmix from explicit config (what load_target_models does after
+    reading the JSON, separator.py:321-356)."""
+    nsgt_base = NSGTBase(fscale, fbins, fmin, fs=sample_rate, device=device)
+    jagged_slicq, _ = nsgt_base.predict_input_size(1, 2, seq_dur)
+    cnorm = ComplexNorm()
+    nsgt, insgt = make_filterbanks(nsgt_base, sample_rate)
+    xumx_model = Unmix(cnorm(jagged_slicq), realtime=realtime)
+    if state is not None:
+        # the reference loads with strict=False and silently drops mismatches (quirk A7); be strict
+        xumx_model.load_state_dict(state, strict=strict)
+    xumx_model.freeze()
+    return xumx_model, (nsgt, insgt, cnorm), sample_rate
+
+
+def load_target_models(model_path: str, runtime_backend: str = _ACCELERATED, realtime: bool = False,
+                       device="cuda"):
+    """separator.py:262-387 for the accelerated backend: <model_path>/xumx_slicq_v2.json
+    (args.sample_rate, fscale, fbins, fmin, seq_dur, realtime) + xumx_slicq_v2.pth."""
+    if runtime_backend != _ACCELERATED:
+        raise ValueError(f"unsupported runtime backend: {runtime_backend}")
+    if model_path is None:
+        raise ValueError("model_path is required: there is no network to download the pretrained model from")
+    model_path = Path(model_path).expanduser()
+    json_path = Path(model_path, "xumx_slicq_v2.json")
+    assert model_path.exists() and json_path.exists()
+    with open(json_path, "r") as stream:
+        results = json.load(stream)
+    pth = Path(model_path, "xumx_slicq_v2.pth")
+    if pth.stat().st_size < 4096:
+        raise RuntimeError(f"{pth} is a Git-LFS pointer, not a checkpoint; fetch the real weights or use "
+                           "seeded_separator() for synthetic ones")
+    state = torch.load(pth, map_location="cpu")
+    args = results["args"]
+    return build_models(args["fscale"], args["fbins"], args["fmin"], args["sample_rate"], args["seq_dur"],
+                        realtime=args["realtime"], device=device, state=state)
+
+
+def seeded_separator(realtime: bool = False, wiener: Optional[bool] = None, seed: int = 1234,
+                     device="cuda", chunk_size: int = 2621440, **cfg) -> Separator:
+    """Separator with the seeded synthetic weights (no checkpoint exists offline).
+    ``wiener`` overrides the post-filter: None follows the reference (offline -> Wiener-EM,
+    realtime -> mix-phase); False on the offline stack is BASELINE config 2."""
+    xumx_model, encoder, sr = build_models(realtime=realtime, device=device, **cfg)
+    xumx_model.load_state_dict(seeded_state_dict(xumx_model.table.shapes, seed=seed), strict=True)
+    if wiener is not None:
+        for blk in xumx_model.sliced_umx:      # the flag the reference reads at model.py:264
+            blk.realtime = not wiener
+    sep = Separator(xumx_model=xumx_model, encoder=encoder, sample_rate=sr, chunk_size=chunk_size,
+                    device=device, quiet=True).to(device)
+    sep.freeze()
+    return sep

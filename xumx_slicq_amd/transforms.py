@@ -17,6 +17,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import _lib
+from .arena import BlockTable
 from .plan import SliCQPlan, build_plan
 
 
@@ -38,6 +39,7 @@ class SliCQEngine:
         self.fs = plan.fs
         self.ncoefs = plan.ncoefs
         self.fbins_actual = plan.nbands
+        self.table = BlockTable(plan.block_shapes())
         self._handles = {}
         self._ws = {}
 
@@ -78,46 +80,6 @@ class SliCQEngine:
         except Exception:
             pass
 
-    # -- arena helpers ---------------------------------------------------------
-    def arena_floats(self, BC: int, S: int) -> int:
-        return 2 * BC * S * self.plan.coefs_per_slice
-
-    def block_views(self, arena: Tensor, lead, S: int) -> List[Tensor]:
-        """The reference's list of per-block tensors (*lead, F_b, S, T_b, 2) as
-        zero-copy views of one arena allocation."""
-        BC = int(np.prod(lead)) if len(lead) else 1
-        out, off = [], 0
-        for (_, F, T) in self.plan.blocks:
-            n = 2 * BC * F * S * T
-            out.append(arena[off: off + n].view(*lead, F, S, T, 2))
-            off += n
-        return out
-
-    def as_arena(self, X_list: List[Tensor]):
-        """(arena, BC, S, lead) for a block list; zero-copy when the list already
-        is a set of views laid out back to back in one allocation."""
-        blocks = self.plan.blocks
-        if len(X_list) != len(blocks):
-            raise ValueError(f"expected {len(blocks)} blocks, got {len(X_list)}")
-        x0 = X_list[0]
-        lead = tuple(x0.shape[:-4])
-        S = x0.shape[-3]
-        BC = int(np.prod(lead)) if len(lead) else 1
-        total = self.arena_floats(BC, S)
-        contiguous_run = x0.dtype == torch.float32
-        ptr = x0.data_ptr()
-        for X, (_, F, T) in zip(X_list, blocks):
-            if tuple(X.shape) != (*lead, F, S, T, 2):
-                raise ValueError(f"block has shape {tuple(X.shape)}, expected {(*lead, F, S, T, 2)}")
-            if contiguous_run and (X.dtype != torch.float32 or not X.is_contiguous() or X.data_ptr() != ptr):
-                contiguous_run = False
-            ptr += X.numel() * 4
-        if contiguous_run and x0.untyped_storage().nbytes() - (x0.data_ptr() - x0.untyped_storage().data_ptr()) >= total * 4:
-            arena = torch.as_strided(x0, (total,), (1,))
-        else:
-            arena = torch.cat([X.to(torch.float32).reshape(-1) for X in X_list])
-        return arena, BC, S, lead
-
     # -- transforms --------------------------------------------------------------
     def forward(self, x: Tensor):
         """x (*lead, n) fp32 on a ROCm device -> (arena, lead, S)."""
@@ -130,7 +92,7 @@ class SliCQEngine:
         h = self.handle(x.device)
         with torch.cuda.device(x.device):
             S = self.plan.num_slices(n)
-            arena = torch.empty(self.arena_floats(BC, S), dtype=torch.float32, device=x.device)
+            arena = torch.empty(self.table.numel(BC, S), dtype=torch.float32, device=x.device)
             nbytes = _lib.lib.xsq_slicqt_forward_workspace(h, BC, n)
             if nbytes == 0:
                 raise _lib.XsqError("xsq_slicqt_forward_workspace: " + _lib.last_error())
@@ -195,7 +157,7 @@ class NSGT_SL(nn.Module):
         (nb_samples, nb_channels, F_b, nb_slices, T_b, 2), views of one arena."""
         eng = self.nsgt.nsgt
         arena, lead, S = eng.forward(x)
-        return eng.block_views(arena, lead, S)
+        return eng.table.views(arena, lead, S)
 
 
 class INSGT_SL(nn.Module):
@@ -207,7 +169,8 @@ class INSGT_SL(nn.Module):
 
     def forward(self, X_list, length: int) -> Tensor:
         eng = self.nsgt.nsgt
-        arena, BC, S, lead = eng.as_arena(list(X_list))
+        arena, lead, S = eng.table.as_arena(list(X_list))
+        BC = int(np.prod(lead)) if len(lead) else 1
         y = eng.backward(arena, BC, S, int(length))
         return y.view(*lead, -1)
 
