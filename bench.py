@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: real-time factor of the demix hot path on MI355X.
+
+Metric (BASELINE.json): audio-seconds demixed / wall-seconds, 44.1 kHz stereo, offline
+model, timed around the `separator(audio)` call with the model resident and warm, file
+I/O excluded (the reference's own convention, xumx_slicq_v2/inference.py:28-31).
+
+Workload = BASELINE.json configs[1]: offline conv stack (Bark-262 sliCQT), ONE 240 s track
+(10,584,000 samples = 4 full 59.4 s chunks + a 98,240-sample tail), Wiener off (mix-phase),
+seeded synthetic audio and seeded synthetic weights (no dataset / checkpoint offline).
+A "step" = one full pass sliCQT -> CDAE -> phasemix -> isliCQT over that track, input already
+resident in HBM.  With --gpus N (one process per GPU under torch.distributed.run, RCCL)
+every rank demixes its own track per step and the stems are all-gathered (the final
+waveform concat of the north star) -> weak scaling; value = total audio-seconds / max-rank time.
+
+One JSON line on stdout from rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRACK_SAMPLES = 10_584_000        # 240 s at 44.1 kHz
+CHUNK = 2_621_440
+FS = 44100.0
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def algorithmic_work(plan, B, chunk_lengths, wiener):
+    """Per-kernel ALGORITHMIC work of one pass over the given chunks: name -> (bound, amount)
+    in bytes (hbm) or flops (mfma).  Per-unit figures are SURVEY.md 8(d): per channel-slice
+    sliCQT = read 9030*4 + write 18640*8 B; CDAE flops formula; Wiener 160 B per TF point."""
+    L, nbins, sumFT = plan.L, plan.L // 2 + 1, plan.coefs_per_slice
+    Lg = plan.Lg.astype("int64")
+    w = {}
+
+    def add(k, bound, v):
+        w[k] = (bound, w.get(k, (bound, 0))[1] + v)
+
+    from xumx_slicq_amd.weights import freq_filter
+    for n in chunk_lengths:
+        n = max(n, L // 2 + 1)
+        S = plan.num_slices(n)
+        T1, T2 = 2 * S - 1, 2 * S - 4
+        r2, r8 = 2 * B * S, 8 * B * S
+        add("slice_window", "hbm", 2 * B * n * 4 + r2 * L * 4)
+        add("rfft_L", "hbm", r2 * L * 4 + r2 * nbins * 8)
+        add("band_analysis_gemm", "mfma", r2 * 8 * int((Lg * Lg).sum()))
+        add("magnitude_whiten", "hbm", r2 * sumFT * 12)
+        f1 = f2 = f3 = f4 = 0
+        for (_, F, T) in plan.blocks:
+            kf = freq_filter(F)
+            F1, F2 = F - kf + 1, F - 2 * kf + 2
+            f1 += 2 * B * F1 * T1 * (2 * kf * T) * 50 * 4
+            f2 += 2 * B * F2 * T2 * (50 * kf * 4) * 51 * 4
+            f3 += 2 * B * F1 * T1 * (51 * kf * 4) * 50 * 4
+            f4 += 2 * B * F1 * T1 * 50 * (2 * kf * T) * 4
+        add("cdae_l1_gemm", "mfma", f1)
+        add("cdae_l2_gemm", "mfma", f2)
+        add("cdae_l3_gemm", "mfma", f3)
+        add("cdae_l4_gemm", "mfma", f4)
+        add("band_synthesis_gemm", "mfma", r8 * 8 * int((Lg * Lg).sum()))
+        add("spectrum_gather", "hbm", r8 * sumFT * 8 + r8 * nbins * 8)
+        add("irfft_L", "hbm", r8 * nbins * 8 + r8 * L * 4)
+        add("overlap_add", "hbm", r8 * L * 4 + 8 * B * n * 4)
+        if wiener:
+            add("wiener_stats", "hbm", B * S * sumFT * 80)
+            add("wiener_apply", "hbm", B * S * sumFT * 144)
+    return w
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this
+    box's host cores on a bounded sample: one 30 s clip through the same configuration."""
+    from oracle import separator as osep
+    from oracle import slicqt as oslicqt
+    from xumx_slicq_amd.synth import synth_audio
+    from xumx_slicq_amd.weights import seeded_state_dict
+    torch.set_num_threads(threads)
+    plan = oslicqt.make_plan()
+    sd = seeded_state_dict([(F, T) for (_, F, T) in plan.blocks])
+    n = 30 * 44100
+    x = synth_audio(n)
+    osep.separate(plan, sd, x[..., :44100], causal=False, wiener=False)   # warm
+    t0 = time.perf_counter()
+    osep.separate(plan, sd, x, causal=False, wiener=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / FS / dt, 3), "unit": "x real-time", "cores": threads, "kind": "port",
+            "sample": "30 s stereo clip (1,323,000 samples), offline conv stack + mix-phase, oracle/ torch-CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nnodes=1 "
+                     "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP library is the product path and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.sharding import chunk_items, demix_sharded
+    from xumx_slicq_amd.synth import synth_audio
+
+    sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
+    # every rank keeps all tracks of the step resident (inputs are in HBM before timing starts)
+    tracks = [synth_audio(TRACK_SAMPLES, seed=20260101 + t).to(dev) for t in range(world)]
+
+    def step():
+        if world == 1:
+            return sep(tracks[0])
+        return demix_sharded(sep, tracks, CHUNK)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        audio_s = world * args.steps * TRACK_SAMPLES / FS
+        # roofline of the dominant kernel (largest share of the timed region on this rank)
+        plan = sep.nsgt.nsgt.plan
+        my_items = [it.length for it in chunk_items([TRACK_SAMPLES], CHUNK)]
+        work = algorithmic_work(plan, 1, my_items, args.wiener)
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        roofline = None
+        if dom is not None:
+            ms, launches = prof[dom]
+            bound, amount = work[dom]
+            per_launch = amount * args.steps / launches          # algorithmic work per launch
+            avg_s = ms / launches * 1e-3
+            if bound == "hbm":
+                ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+                        "share_of_step": round(ms / (dt * 1e3), 4)}
+        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        result = {
+            "metric": "real-time factor (audio-s demixed / wall-s), 44.1 kHz stereo, offline model",
+            "value": round(audio_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
+                                   "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
+                                   % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
+                       "parallelism": "chunk items sharded, %d rank(s)%s" % (world, ", RCCL all-gather of stems" if world > 1 else "")},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

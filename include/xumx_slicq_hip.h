@@ -139,6 +139,16 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
                   int B, int S, int win_len, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* ---- per-kernel timing (bench.py roofline) ------------------------------------------
+ * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on
+ * its own launch stream.  xsq_profile_read synchronises the outstanding events and
+ * returns accumulated milliseconds / launch counts per kernel name (newline-separated
+ * names, same order as ms[] / launches[]); returns the number of entries.              */
+int xsq_profile_enable(int on);
+int xsq_profile_reset(void);
+int xsq_profile_read(char* names, size_t names_bytes, double* ms, int64_t* launches,
+                     int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

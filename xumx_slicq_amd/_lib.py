@@ -58,6 +58,9 @@ _SIGS = {
     "xsq_cdae_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "xsq_phasemix": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "xsq_wiener_workspace": (C.c_size_t, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "xsq_profile_enable": (C.c_int, [C.c_int]),
+    "xsq_profile_reset": (C.c_int, []),
+    "xsq_profile_read": (C.c_int, [C.c_char_p, C.c_size_t, _vp, _vp, C.c_int]),
     "xsq_wiener_em": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
 }
 
@@ -81,3 +84,22 @@ def check(rc: int, what: str):
 def stream_ptr() -> int:
     """The HIP stream torch is currently issuing work on."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_enable(on: bool = True):
+    lib.xsq_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib.xsq_profile_reset()
+
+
+def profile_read() -> dict:
+    """{kernel name: (total ms, launches)} accumulated since the last reset."""
+    import numpy as np
+    buf = C.create_string_buffer(8192)
+    ms = np.zeros(128, dtype=np.float64)
+    cnt = np.zeros(128, dtype=np.int64)
+    n = lib.xsq_profile_read(buf, len(buf), ms.ctypes.data, cnt.ctypes.data, 128)
+    names = buf.value.decode().split("\n")[:n]
+    return {nm: (float(ms[i]), int(cnt[i])) for i, nm in enumerate(names)}

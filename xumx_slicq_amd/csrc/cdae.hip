@@ -20,6 +20,7 @@
 #include "../../include/xumx_slicq_hip.h"
 #include "gemm_tile.h"
 #include "plan.h"
+#include "prof.h"
 
 namespace xsq {
 
@@ -524,24 +525,29 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
     const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
+    { XSQ_PROF("magnitude_whiten", stream);
     hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        (const float2*)X, xin, Mo->d_cum, Mo->d_blockF, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
-                       Mo->nblocks, Bn * 2, S, total);
+                       Mo->nblocks, Bn * 2, S, total); }
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal};
     TileTable tt;
     int rc;
     if ((rc = get_cdae_tiles(Mo, 1, Bn, S, &tt))) return rc;
+    { XSQ_PROF("cdae_l1_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL1Op{a}, tt.d_tiles, tt.ntiles);
+                       CdaeL1Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 2, Bn, S, &tt))) return rc;
+    { XSQ_PROF("cdae_l2_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL2Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL2Op{a}, tt.d_tiles, tt.ntiles);
+                       CdaeL2Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 3, Bn, S, &tt))) return rc;
+    { XSQ_PROF("cdae_l3_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL3Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL3Op{a}, tt.d_tiles, tt.ntiles);
+                       CdaeL3Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 4, Bn, S, &tt))) return rc;
+    { XSQ_PROF("cdae_l4_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL4Op{a}, tt.d_tiles, tt.ntiles);
+                       CdaeL4Op{a}, tt.d_tiles, tt.ntiles); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

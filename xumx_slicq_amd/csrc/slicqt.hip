@@ -19,6 +19,7 @@
 #include "../../include/xumx_slicq_hip.h"
 #include "gemm_tile.h"
 #include "plan.h"
+#include "prof.h"
 
 namespace xsq {
 
@@ -442,16 +443,18 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
                   (size_t)(w - (char*)ws) + f.work_bytes, ws_bytes);
         return XSQ_ERR_WORKSPACE;
     }
+    { XSQ_PROF("slice_window", stream);
     hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
-                       S, n, P->L, P->h);
-    rc = run_fft(f, seg, U, fwork, stream);
+                       S, n, P->L, P->h); }
+    { XSQ_PROF("rfft_L", stream); rc = run_fft(f, seg, U, fwork, stream); }
     if (rc) return rc;
     TileTable tt;
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
     BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L};
+    { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
-                       tt.d_tiles, tt.ntiles);
+                       tt.d_tiles, tt.ntiles); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }
@@ -492,14 +495,17 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S};
+    { XSQ_PROF("band_synthesis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
-                       tt.d_tiles, tt.ntiles);
+                       tt.d_tiles, tt.ntiles); }
+    { XSQ_PROF("spectrum_gather", stream);
     hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,
-                       P->d_bands, P->d_cov_ptr, P->d_cov_band, fr, BC, S, P->nbins);
-    rc = run_fft(f, fr, seg, fwork, stream);
+                       P->d_bands, P->d_cov_ptr, P->d_cov_band, fr, BC, S, P->nbins); }
+    { XSQ_PROF("irfft_L", stream); rc = run_fft(f, fr, seg, fwork, stream); }
     if (rc) return rc;
+    { XSQ_PROF("overlap_add", stream);
     hipLaunchKernelGGL(k_overlap_add, dim3((unsigned)((length + 255) / 256), BC), dim3(256), 0, stream, seg, y,
-                       S, length, P->L, P->h);
+                       S, length, P->L, P->h); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

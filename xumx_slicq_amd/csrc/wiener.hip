@@ -21,6 +21,7 @@
 
 #include "../../include/xumx_slicq_hip.h"
 #include "plan.h"
+#include "prof.h"
 
 namespace xsq {
 
@@ -304,11 +305,14 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
     WTable t;
     if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, &t))) return rc;
     float* stats = (float*)ws;
+    { XSQ_PROF("wiener_stats", stream);
     hipLaunchKernelGGL(k_wiener_stats, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, (const float2*)Y,
-                       t.d_rows, t.d_work, stats, Bn, S, win_len);
-    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats);
+                       t.d_rows, t.d_work, stats, Bn, S, win_len); }
+    { XSQ_PROF("wiener_finalize", stream);
+    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats); }
+    { XSQ_PROF("wiener_apply", stream);
     hipLaunchKernelGGL(k_wiener_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
-                       (const float2*)X, (float2*)Y, t.d_rows, stats, Bn, S, win_len);
+                       (const float2*)X, (float2*)Y, t.d_rows, stats, Bn, S, win_len); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }
