@@ -130,7 +130,9 @@ def main():
     from xumx_slicq_amd.sharding import chunk_items, demix_sharded
     from xumx_slicq_amd.synth import synth_audio
 
-    sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # keep stdout to the one JSON line
+        sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
     # every rank keeps all tracks of the step resident (inputs are in HBM before timing starts)
     tracks = [synth_audio(TRACK_SAMPLES, seed=20260101 + t).to(dev) for t in range(world)]
 

@@ -1,0 +1,17 @@
+# Diagnostic: build ablated variants of the library and time the bench with each (results of the
+# ablated builds are wrong by construction; only their timings matter).  Run on the GPU box.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R/xumx_slicq_amd/csrc
+for v in ${VARIANTS:-0 1 2 4 6 8 14 15}; do
+  for f in slicqt cdae wiener prof; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DXSQ_ABLATE=$v -c $f.hip -o /tmp/ab_$f.o 2>/dev/null
+  done
+  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 /tmp/ab_slicqt.o /tmp/ab_cdae.o /tmp/ab_wiener.o /tmp/ab_prof.o -o /tmp/libab_$v.so -L/opt/rocm/lib -lrocfft
+  echo "== ablate=$v"
+  XSQ_LIB=/tmp/libab_$v.so python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/tmp/ab_err.txt > /tmp/ab_out.json || tail -5 /tmp/ab_err.txt
+  python3 -c "
+import json
+d=json.loads(open('/tmp/ab_out.json').read().strip().splitlines()[-1]); k=d['kernels']
+print(' ms/step', d['ms_per_step'], {n: round(v['ms_per_step'],2) for n,v in k.items() if 'gemm' in n})" || tail -5 /tmp/ab_err.txt
+done
+/opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 $R/tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && /tmp/mfma_peak

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must come first: it loads the ROCm runtime this library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxumx_slicq_hip.so")
+# XSQ_LIB selects a diagnostic build (tools/ablate.sh); the default is the product library.
+LIB_PATH = os.environ.get("XSQ_LIB") or os.path.join(_HERE, "libxumx_slicq_hip.so")
 
 
 class XsqError(RuntimeError):

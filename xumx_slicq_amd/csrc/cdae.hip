@@ -13,6 +13,7 @@
 // Activations are channels-last with a channel stride of 52 floats (16-byte rows), so every
 // K-run of an implicit-GEMM row is one contiguous, aligned span; all 70 blocks x 4 targets
 // of a layer run in ONE grouped launch driven by a tile table.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -30,8 +31,7 @@ static const int NT = 4;                      // targets
 struct CdaeBlockDev {
     int F, T, hop, kf, F1, F2;
     int cumF1, cumF2;     // sums over earlier blocks of F1, F2 (activation arena offsets)
-    int ld4;              // leading dimension of the layer-4 matrix: round_up(T, 64)
-    int pad;
+    int ld1, ld4;         // row lengths of the transposed layer-1 / layer-4 matrices (K padded to 16)
     int64_t cum;          // sum over earlier blocks of F*T
     int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
     int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
@@ -133,12 +133,12 @@ struct CdaeL1Op {
     typedef RowFT RowA;
     CdaeArgs a;
     __device__ Group group(int gid) const {
-        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const CdaeBlockDev& b = a.blocks[gid >> 2];
         const int tgt = gid & 3;
         Group g;
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F1; g.To = a.T1; g.Fi = b.F; g.Ti = a.S * b.T;
-        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = 2 * b.kf * b.T; g.ldb = 64;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = 2 * b.kf * b.T; g.ldb = b.ld1;
         g.B = a.pool + b.w1[tgt]; g.shift = a.pool + b.s1[tgt];
         g.in = a.xin + (int64_t)a.Bn * 2 * a.S * b.cum;
         g.out = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
@@ -172,7 +172,7 @@ struct CdaeL1Op {
         if (t0 + 3 >= 0) v.w = p[3];
         return v;
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
         if (m >= g.M) return;
         float* d = g.out + (int64_t)m * CS;
         d[n] = fmaxf(v0 + g.shift[n], 0.f);
@@ -186,12 +186,12 @@ struct CdaeL2Op {
     typedef RowFT RowA;
     CdaeArgs a;
     __device__ Group group(int gid) const {
-        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const CdaeBlockDev& b = a.blocks[gid >> 2];
         const int tgt = gid & 3;
         Group g;
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F2; g.To = a.T2; g.Fi = b.F1; g.Ti = a.T1;
-        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = 64;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = b.kf * 4 * CS;
         g.B = a.pool + b.w2[tgt]; g.shift = a.pool + b.s2[tgt];
         g.in = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
         g.out = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
@@ -211,7 +211,7 @@ struct CdaeL2Op {
         const int df = k / (4 * CS), rem = k - df * 4 * CS;   // rem = dt*52 + c1, contiguous in memory
         return *reinterpret_cast<const float4*>(r.p + (int64_t)df * g.Ti * CS + rem);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
         if (m >= g.M) return;
         float* d = g.out + (int64_t)m * CS;
         d[n] = fmaxf(v0 + g.shift[n], 0.f);
@@ -225,12 +225,12 @@ struct CdaeL3Op {
     typedef RowFT RowA;
     CdaeArgs a;
     __device__ Group group(int gid) const {
-        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const CdaeBlockDev& b = a.blocks[gid >> 2];
         const int tgt = gid & 3;
         Group g;
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F1; g.To = a.T1; g.Fi = b.F2; g.Ti = a.T2;
-        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = 64;
+        g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = b.kf * 4 * CS;
         g.B = a.pool + b.w3[tgt]; g.shift = a.pool + b.s3[tgt];
         g.in = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
         g.out = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
@@ -253,7 +253,7 @@ struct CdaeL3Op {
         if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(r.p - (int64_t)df * g.Ti * CS + rem);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
         if (m >= g.M) return;
         float* d = g.out + (int64_t)m * CS;
         d[n] = fmaxf(v0 + g.shift[n], 0.f);
@@ -269,7 +269,7 @@ struct CdaeL4Op {
     typedef RowFT RowA;
     CdaeArgs a;
     __device__ Group group(int gid) const {
-        const CdaeBlockDev b = a.blocks[gid >> 2];
+        const CdaeBlockDev& b = a.blocks[gid >> 2];
         const int tgt = gid & 3;
         Group g;
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
@@ -309,20 +309,18 @@ struct CdaeL4Op {
         reinterpret_cast<float2*>(a.Y)[yi] = make_float2(mask * x.x, mask * x.y);
         if (a.masks) a.masks[yi] = mask;
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
         if (m >= g.M) return;
         int b, f, u;
         split_row(m, g.Fo, g.To, b, f, u);
         if (n < g.N) put(g, b, f, u, n, v0);
-        if (n + 32 < g.N) put(g, b, f, u, n + 32, v1);
+        if (wide && n + 32 < g.N) put(g, b, f, u, n + 32, v1);
     }
 };
 
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
-static const int CDAE_BM = 128;
-
 static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
 
 static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
@@ -332,7 +330,15 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
     std::vector<TileDev> t;
-    for (int b = 0; b < Mo->nblocks; ++b) {
+    // longest tiles first: order the blocks by the K of this layer, descending
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    auto kof = [&](int b) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        return layer == 1 ? 2 * d.kf * d.T : (layer == 4 ? d.kf * 2 * CS : d.kf * 4 * CS);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return kof(x) > kof(y); });
+    for (int b : order) {
         const CdaeBlockDev& d = Mo->blocks[b];
         int64_t M; int N;
         switch (layer) {
@@ -341,9 +347,7 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             case 3: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
             default: M = (int64_t)Bn * d.F * 2 * S; N = d.T; break;
         }
-        for (int tgt = 0; tgt < NT; ++tgt)
-            for (int64_t m0 = 0; m0 < M; m0 += CDAE_BM)
-                for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, 0});
+        for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N);
     }
     TileTable tt;
     tt.ntiles = (int)t.size();
@@ -405,7 +409,8 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
         memset(&d, 0, sizeof(d));
         d.F = hb.F; d.T = hb.T; d.hop = hb.T / 2; d.kf = kf_of(hb.F);
         d.F1 = d.F - d.kf + 1; d.F2 = d.F1 - d.kf + 1;
-        d.cumF1 = cumF1; d.cumF2 = cumF2; d.cum = hb.cum; d.cumF = cumF; d.ld4 = (int)round_up(d.T, 64);
+        d.cumF1 = cumF1; d.cumF2 = cumF2; d.cum = hb.cum; d.cumF = cumF;
+        d.ld1 = (int)round_up(2 * d.kf * d.T, 16); d.ld4 = (int)round_up(d.kf * 2 * CS, 16);
         cumF1 += d.F1; cumF2 += d.F2; cumF += d.F;
         cum[bi] = hb.cum; blockF[bi] = d.F;
         const int kf = d.kf, W = d.T, hop = d.hop;
@@ -416,19 +421,19 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
             const float* w = p; p += (size_t)H1 * 2 * kf * W;
             const float *bw = p, *bb = p + H1, *rm = p + 2 * H1, *rv = p + 3 * H1; p += 4 * H1;
             const int K1 = 2 * kf * W;
-            d.w1[t] = alloc((size_t)round_up(K1, 16) * 64);
+            d.w1[t] = alloc((size_t)64 * d.ld1);                 // Wt[n = co][k]
             d.s1[t] = alloc(64);
             for (int co = 0; co < H1; ++co) {
                 const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
                 pool[d.s1[t] + co] = (float)((double)bb[co] - (double)rm[co] * s);
                 for (int k = 0; k < K1; ++k)       // k = (ci*kf + df)*W + dt, the weight's own order
-                    pool[d.w1[t] + (size_t)k * 64 + co] = (float)((double)w[(size_t)co * K1 + k] * s);
+                    pool[d.w1[t] + (size_t)co * d.ld1 + k] = (float)((double)w[(size_t)co * K1 + k] * s);
             }
             // ---- L2: Conv2d weight (51,50,kf,4); BN(51);  k = (df*4 + dt)*52 + c1
             w = p; p += (size_t)H2 * H1 * kf * 4;
             bw = p; bb = p + H2; rm = p + 2 * H2; rv = p + 3 * H2; p += 4 * H2;
             const int K2 = kf * 4 * CS;
-            d.w2[t] = alloc((size_t)round_up(K2, 16) * 64);
+            d.w2[t] = alloc((size_t)64 * K2);                    // K2 % 16 == 0
             d.s2[t] = alloc(64);
             for (int co = 0; co < H2; ++co) {
                 const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
@@ -436,14 +441,14 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
                 for (int ci = 0; ci < H1; ++ci)
                     for (int df = 0; df < kf; ++df)
                         for (int dt = 0; dt < 4; ++dt)
-                            pool[d.w2[t] + (size_t)((df * 4 + dt) * CS + ci) * 64 + co] =
+                            pool[d.w2[t] + (size_t)co * K2 + (df * 4 + dt) * CS + ci] =
                                 (float)((double)w[(((size_t)co * H1 + ci) * kf + df) * 4 + dt] * s);
             }
             // ---- L3: ConvTranspose2d weight (51,50,kf,4) = (in,out,kH,kW); BN(50)
             //      out3[c3,f3,t3] = sum w[c2,c3,df,dt] out2[c2,f3-df,t3-dt];  k = (df*4 + dt')*52 + c2, dt' = 3-dt
             w = p; p += (size_t)H2 * H1 * kf * 4;
             bw = p; bb = p + H1; rm = p + 2 * H1; rv = p + 3 * H1; p += 4 * H1;
-            d.w3[t] = alloc((size_t)round_up(K2, 16) * 64);
+            d.w3[t] = alloc((size_t)64 * K2);
             d.s3[t] = alloc(64);
             for (int co = 0; co < H1; ++co) {
                 const double s = (double)bw[co] / std::sqrt((double)rv[co] + eps);
@@ -451,15 +456,14 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
                 for (int ci = 0; ci < H2; ++ci)
                     for (int df = 0; df < kf; ++df)
                         for (int dt = 0; dt < 4; ++dt)
-                            pool[d.w3[t] + (size_t)((df * 4 + (3 - dt)) * CS + ci) * 64 + co] =
+                            pool[d.w3[t] + (size_t)co * K2 + (df * 4 + (3 - dt)) * CS + ci] =
                                 (float)((double)w[(((size_t)ci * H1 + co) * kf + df) * 4 + dt] * s);
             }
             // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
             //      k = (df*2 + tap)*52 + c3 ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
             w = p; p += (size_t)H1 * 2 * kf * W;
             const float* bias = p; p += 2;
-            const int K4 = kf * 2 * CS;
-            d.w4[t] = alloc((size_t)round_up(K4, 16) * d.ld4);
+            d.w4[t] = alloc((size_t)round_up(W, 64) * d.ld4);    // Wt[n = c*hop + dtlo][k]
             d.b4[t] = alloc(64);
             pool[d.b4[t]] = bias[0]; pool[d.b4[t] + 1] = bias[1];
             for (int ci = 0; ci < H1; ++ci)
@@ -467,7 +471,7 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
                     for (int df = 0; df < kf; ++df)
                         for (int tap = 0; tap < 2; ++tap)
                             for (int dt = 0; dt < hop; ++dt)
-                                pool[d.w4[t] + (size_t)((df * 2 + tap) * CS + ci) * d.ld4 + c * hop + dt] =
+                                pool[d.w4[t] + (size_t)(c * hop + dt) * d.ld4 + (df * 2 + tap) * CS + ci] =
                                     w[(((size_t)ci * 2 + c) * kf + df) * W + dt + tap * hop];
         }
         Mo->blocks.push_back(d);
@@ -534,19 +538,19 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     int rc;
     if ((rc = get_cdae_tiles(Mo, 1, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l1_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL1Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 2, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l2_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL2Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL2Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 3, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l3_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL3Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL3Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 4, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l4_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CDAE_BM, CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL4Op{a}, tt.d_tiles, tt.ntiles); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;

@@ -34,6 +34,15 @@ void set_error(const char* fmt, ...);
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+struct TileDev;
+// tiles of one group: 128-row x 64-column tiles, plus a 32-column tile when the N tail is <= 32
+template <class Vec>
+static inline void push_group_tiles(Vec& out, int group, int64_t M, int N) {
+    for (int64_t m0 = 0; m0 < M; m0 += 128)          // n fastest: the N-tiles of one M-tile run back
+        for (int n0 = 0; n0 < N; n0 += 64)           // to back and re-read the same A rows from L2
+            out.push_back({group, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
+}
+
 // One band of the transform as the kernels see it.
 struct BandDev {
     int Lg;        // band length (coefficients per slice), multiple of 4
@@ -42,7 +51,7 @@ struct BandDev {
     int F;         // rows of the block
     int64_t cum;   // sum over earlier blocks of F_b*T_b (complex coefficients per channel-slice)
     int64_t w_off; // float offset of the band's DFT matrix inside Wf / Wi
-    int ldw;       // leading dimension (floats) of that matrix: round_up(2*Lg, 64)
+    int ldw;       // row length (floats) of that matrix, stored transposed Wt[n][k]: round_up(2*Lg, 16)
     int pad;
 };
 
@@ -51,7 +60,7 @@ struct TileDev {
     int group;  // band (sliCQT) or layer-group (CDAE)
     int m0;     // first row of the tile
     int n0;     // first column of the tile
-    int pad;
+    int narrow; // 1: the tile is 32 columns wide (N tail), 0: 64
 };
 
 }  // namespace xsq

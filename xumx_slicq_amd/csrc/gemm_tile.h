@@ -1,115 +1,151 @@
 // fp32 MFMA tile engine for the grouped (ragged) GEMM-shaped kernels of the hot path:
 // per-band DFTs of the sliCQT / isliCQT and the four CDAE layers as implicit GEMMs.
 //
-// One workgroup = 256 threads = 4 wavefronts (64 lanes each) stacked along M.
-// Tile BM x 64, K-step 16.  BM = 128 -> 32x64 per wave, BM = 256 -> 64x64 per wave,
-// built from v_mfma_f32_32x32x2_f32 (exact fp32: the parity bar is 1e-4 RMS against a
-// torch-CPU fp32 reference, so operands stay fp32).  Operand maps (cdna guide section 3):
+// One workgroup = 256 threads = 4 wavefronts (64 lanes) stacked along M.  Tile 128 x 64
+// (or 128 x 32 for N tails, TileDev.narrow), K-step 16, v_mfma_f32_32x32x2_f32 (exact fp32:
+// the parity bar is 1e-4 RMS against a torch-CPU fp32 reference, so operands stay fp32).
+// Operand maps (cdna guide section 3):
 //   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
 //   C: reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
 //
-// A is produced by an operator-specific loader (gathers, reflections, zero padding);
-// B is always a dense row-major matrix padded to (K%16==0, N%64==0) with zeros, so its
-// loads are unconditional 16-byte loads.  Global->LDS staging goes through registers
-// with the next K-step's loads issued before the current step's MFMAs.
+// Both operands are K-contiguous: A comes from an operator-specific loader (gathers,
+// reflections, zero padding), B is a dense matrix stored TRANSPOSED, Bt[n][k], padded to
+// (K%16==0, N%64==0) with zeros, so its loads are unconditional 16-byte loads.  In LDS a
+// tile row is 16 k-values with a stride of 20 floats (80 B: 16-byte aligned and conflict-free
+// for ds_read_b128 over 16 consecutive rows).  The sum over k is order-free, so MFMA step i
+// of a K-step takes k = i from the lower half-wave and k = 8+i from the upper one: every lane
+// reads its 8 operand values as two ds_read_b128, all fragment reads of a K-step are issued
+// up front and the 16 MFMAs then run back to back.  LDS is double-buffered (one barrier per
+// K-step); the next K-step's global loads are in flight during the MFMAs.
 #pragma once
 #include "common.h"
+
+// Diagnostic builds only (tools/ablate.sh): bit 0 skip MFMAs, bit 1 skip A global loads,
+// bit 2 skip B global loads, bit 3 skip LDS fragment reads.  0 in the product build.
+#ifndef XSQ_ABLATE
+#define XSQ_ABLATE 0
+#endif
 
 namespace xsq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Blocks b and b+8 share an XCD (observed round-robin placement; speed only).  Give each
-// XCD a contiguous run of tiles so that neighbouring tiles, which share the B matrix of
-// their group and often A rows, hit the same 4 MiB L2.  Bijective for any grid size.
+// Blocks b and b+8 share an XCD (observed round-robin placement; speed only, never
+// correctness).  Tiles that are neighbours in the table share the B matrix of their group and
+// often their A rows, so they should meet in one XCD's 4 MiB L2 -- but the work per tile varies
+// by 20x across groups, so an XCD must not own one contiguous eighth of the table.  Deal the
+// table out in chunks of 16 tiles: chunk c goes to XCD c % 8.  Bijective for any grid size
+// (the ragged tail of fewer than 128 tiles keeps the identity order).
 __device__ inline int xcd_remap(int bid, int nblocks) {
-    const int q = nblocks >> 3, r = nblocks & 7;
-    const int x = bid & 7;
-    return x * q + (x < r ? x : r) + (bid >> 3);
+    constexpr int G = 16;
+    const int full = (nblocks / (8 * G)) * (8 * G);
+    if (bid >= full) return bid;
+    const int x = bid & 7, l = bid >> 3;
+    return ((l / G) * 8 + x) * G + (l % G);
 }
 
-template <int BM, class Op>
+constexpr int GEMM_BM = 128, GEMM_BN = 64, GEMM_BK = 16, GEMM_LD = 20;
+
+template <class Op>
 __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
                                                             int ntiles) {
-    constexpr int BN = 64, BK = 16, LDA = BK + 1;
-    constexpr int WM = BM / 4;      // rows per wave
-    constexpr int MT = WM / 32;     // 32-row MFMA tiles per wave along M
+    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
     constexpr int RA = BM / 64;     // A rows staged per thread
 
-    __shared__ float As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LD];
+    float* const As0 = lds;
+    float* const Bs0 = lds + 2 * BM * LD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const bool wide = t.narrow == 0;          // wave-uniform
     const typename Op::Group g = op.group(t.group);
     const int K = g.K;
 
-    // ---- staging assignment -------------------------------------------------
-    const int a_row = tid >> 2;          // 0..63 (+64*i)
-    const int a_kq = (tid & 3) * 4;      // 0,4,8,12
+    // ---- staging assignment: one float4 (4 consecutive k) of one row per thread and slot ----
+    const int s_row = tid >> 2;          // 0..63
+    const int s_kq = (tid & 3) * 4;      // 0,4,8,12
     typename Op::RowA ra[RA];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = op.row_a(g, t.m0 + a_row + 64 * i);
-    const int b_k = tid >> 4;            // 0..15
-    const int b_n = (tid & 15) * 4;      // 0..60
-    const float* bp = g.B + (int64_t)b_k * g.ldb + t.n0 + b_n;
+    for (int i = 0; i < RA; ++i) ra[i] = op.row_a(g, t.m0 + s_row + 64 * i);
+    const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
+    const bool b_on = wide || s_row < 32;
 
     float4 ga[RA];
-    float4 gb;
+    float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ga[i] = op.load_a4(g, ra[i], a_kq);
-    gb = *reinterpret_cast<const float4*>(bp);
+    for (int i = 0; i < RA; ++i) ga[i] = op.load_a4(g, ra[i], s_kq);
+    if (b_on) gb = *reinterpret_cast<const float4*>(bp);
+    float4 fa_lo = ga[0], fa_hi = ga[0], fb_lo = gb, fb_hi = gb;   // only used by ablation builds
 
-    f32x16 acc[MT][2];
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
     const int lrow = lane & 31, lk = lane >> 5;
+    const int a_frag = (wave * 32 + lrow) * LD + 8 * lk;
+    const int b_frag = lrow * LD + 8 * lk;
+
+    // prologue: stage K-step 0 into buffer 0
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        *reinterpret_cast<float4*>(&As0[(s_row + 64 * i) * LD + s_kq]) = ga[i];
+    *reinterpret_cast<float4*>(&Bs0[s_row * LD + s_kq]) = gb;
+    __syncthreads();
+
+    int cur = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        // registers -> LDS
+        const bool more = k0 + BK < K;
+        if (more) {   // next K-step's global loads; they land while the MFMAs run
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            float* d = &As[(a_row + 64 * i) * LDA + a_kq];
-            d[0] = ga[i].x; d[1] = ga[i].y; d[2] = ga[i].z; d[3] = ga[i].w;
+            for (int i = 0; i < RA; ++i)
+                if (!(XSQ_ABLATE & 2)) ga[i] = op.load_a4(g, ra[i], k0 + BK + s_kq);
+            if (b_on && !(XSQ_ABLATE & 4)) gb = *reinterpret_cast<const float4*>(bp + k0 + BK);
         }
-        *reinterpret_cast<float4*>(&Bs[b_k * BN + b_n]) = gb;
+        const float* As = As0 + cur * BM * LD;
+        const float* Bs = Bs0 + cur * BN * LD;
+        const float4 a_lo = (XSQ_ABLATE & 8) ? fa_lo : *reinterpret_cast<const float4*>(&As[a_frag]);
+        const float4 a_hi = (XSQ_ABLATE & 8) ? fa_hi : *reinterpret_cast<const float4*>(&As[a_frag + 4]);
+        const float4 b0_lo = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag]);
+        const float4 b0_hi = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 4]);
+        const float a[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+        const float b0[8] = {b0_lo.x, b0_lo.y, b0_lo.z, b0_lo.w, b0_hi.x, b0_hi.y, b0_hi.z, b0_hi.w};
+        if (wide) {
+            const float4 b1_lo = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD]);
+            const float4 b1_hi = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD + 4]);
+            const float b1[8] = {b1_lo.x, b1_lo.y, b1_lo.z, b1_lo.w, b1_hi.x, b1_hi.y, b1_hi.z, b1_hi.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (XSQ_ABLATE & 1) { acc0[i] += a[i] * b0[i]; acc1[i] += a[i] * b1[i]; continue; }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1[i], acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (XSQ_ABLATE & 1) { acc0[i] += a[i] * b0[i]; continue; }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
+            }
+        }
+        if (more) {   // fill the other buffer (last read one K-step ago, behind the previous barrier)
+            float* Aw = As0 + (cur ^ 1) * BM * LD;
+            float* Bw = Bs0 + (cur ^ 1) * BN * LD;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                *reinterpret_cast<float4*>(&Aw[(s_row + 64 * i) * LD + s_kq]) = ga[i];
+            *reinterpret_cast<float4*>(&Bw[s_row * LD + s_kq]) = gb;
+        }
         __syncthreads();
-        // issue next step's global loads; they land while the MFMAs run
-        if (k0 + BK < K) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ga[i] = op.load_a4(g, ra[i], k0 + BK + a_kq);
-            gb = *reinterpret_cast<const float4*>(bp + (int64_t)(k0 + BK) * g.ldb);
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[MT], b[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = As[(wave * WM + i * 32 + lrow) * LDA + kk + lk];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + lk) * BN + j * 32 + lrow];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue -------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = t.m0 + wave * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            op.store_row(g, m, t.n0 + lrow, acc[i][0][r], acc[i][1][r]);
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int m = t.m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        op.store_row(g, m, t.n0 + lrow, acc0[r], acc1[r], wide);
     }
 }
 

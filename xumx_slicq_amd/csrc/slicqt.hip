@@ -134,12 +134,12 @@ struct BandFwdOp {
         const float2 b = *reinterpret_cast<const float2*>(r.p + 2 * i1);
         return make_float4(a.x, a.y, b.x, b.y);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
         if (m >= g.M) return;
         const int bc = m / S, s = m - bc * S;
         float* d = coef + g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg);
         if (n < g.N) d[n] = v0;
-        if (n + 32 < g.N) d[n + 32] = v1;
+        if (wide && n + 32 < g.N) d[n + 32] = v1;
     }
 };
 
@@ -176,19 +176,17 @@ struct BandInvOp {
         if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1) const {
+    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
         if (m >= g.M) return;
         float* d = Z + row_off(g, m);
         if (n < g.N) d[n] = v0;
-        if (n + 32 < g.N) d[n + 32] = v1;
+        if (wide && n + 32 < g.N) d[n + 32] = v1;
     }
 };
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const int BAND_BM = 128;
-
 static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
     std::lock_guard<std::mutex> lk(P->mu);
     auto key = std::make_tuple(0, rows, 0);
@@ -198,12 +196,8 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
         return XSQ_OK;
     }
     std::vector<TileDev> t;
-    for (int j = 0; j < P->nbands; ++j) {
-        const int N = 2 * P->bands[j].Lg;
-        // n fastest: the N-tiles of one M-tile run back to back and re-read the same A rows from L2
-        for (int m0 = 0; m0 < rows; m0 += BAND_BM)
-            for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{j, m0, n0, 0});
-    }
+    // longest tiles first (K = 2*Lg grows along the band table): the launch ends on short tiles
+    for (int j = P->nbands - 1; j >= 0; --j) push_group_tiles(t, j, rows, 2 * P->bands[j].Lg);
     TileTable tt;
     tt.ntiles = (int)t.size();
     XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
@@ -304,16 +298,18 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
             }
             BandDev d;
             d.Lg = Lg[j]; d.bin0 = c[j] - Lg[j] / 2; d.f = f; d.F = b.F; d.cum = b.cum;
-            d.ldw = (int)round_up(2 * Lg[j], 64); d.w_off = woff; d.pad = 0;
-            woff += round_up(2 * Lg[j], 16) * d.ldw;
+            d.ldw = (int)round_up(2 * Lg[j], 16); d.w_off = woff; d.pad = 0;
+            woff += round_up(2 * Lg[j], 64) * d.ldw;
             P->bands.push_back(d);
             g_off[j] = goff;
             goff += Lg[j];
         }
     }
     // ---- per-band real-ified DFT matrices --------------------------------------------
-    // row index k = 2p+ri over the band's window in spectrum order (bin = bin0 + p, window
-    // index q = (p + Lg/2) mod Lg since windows are stored peak-at-0); column n = 2t+ro.
+    // stored transposed, Wt[n][k] (K contiguous, as the tile engine wants its B operand).
+    // analysis: k = 2p+ri over the band's window in spectrum order (bin = bin0 + p, window
+    // index q = (p + Lg/2) mod Lg since windows are stored peak-at-0), n = 2t+ro over coefficients;
+    // synthesis: k = 2t+ri over coefficients, n = 2p+ro over spectrum positions.
     std::vector<float> Wf((size_t)woff, 0.f), Wi((size_t)woff, 0.f);
     const double PI2 = 6.283185307179586476925286766559;
     for (int j = 0; j < nbands; ++j) {
@@ -334,17 +330,17 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
                 const int r = (int)(((int64_t)q * t) % n);
                 // analysis: w = ga * e^{+i 2 pi q t / n};  (a_re + i conj a_im) * w
                 const double wr = ga * cs[r], wim = ga * sn[r];
-                wf[(size_t)(2 * p) * ld + 2 * t] = (float)wr;
-                wf[(size_t)(2 * p) * ld + 2 * t + 1] = (float)wim;
-                wf[(size_t)(2 * p + 1) * ld + 2 * t] = (float)(-conj * wim);
-                wf[(size_t)(2 * p + 1) * ld + 2 * t + 1] = (float)(conj * wr);
+                wf[(size_t)(2 * t) * ld + 2 * p] = (float)wr;                    // re <- re
+                wf[(size_t)(2 * t + 1) * ld + 2 * p] = (float)wim;               // im <- re
+                wf[(size_t)(2 * t) * ld + 2 * p + 1] = (float)(-conj * wim);     // re <- im
+                wf[(size_t)(2 * t + 1) * ld + 2 * p + 1] = (float)(conj * wr);   // im <- im
                 // synthesis: rows are coefficients t, columns spectrum positions p:
                 // w = gs * e^{-i 2 pi q t / n}
                 const double vr = gs * cs[r], vi = -gs * sn[r];
-                wi[(size_t)(2 * t) * ld + 2 * p] = (float)vr;
-                wi[(size_t)(2 * t) * ld + 2 * p + 1] = (float)vi;
-                wi[(size_t)(2 * t + 1) * ld + 2 * p] = (float)(-vi);
-                wi[(size_t)(2 * t + 1) * ld + 2 * p + 1] = (float)vr;
+                wi[(size_t)(2 * p) * ld + 2 * t] = (float)vr;                    // re <- re
+                wi[(size_t)(2 * p + 1) * ld + 2 * t] = (float)vi;                // im <- re
+                wi[(size_t)(2 * p) * ld + 2 * t + 1] = (float)(-vi);             // re <- im
+                wi[(size_t)(2 * p + 1) * ld + 2 * t + 1] = (float)vr;            // im <- im
             }
         }
     }
@@ -453,7 +449,7 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
     if (rc) return rc;
     BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L};
     { XSQ_PROF("band_analysis_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
+    hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
@@ -496,7 +492,7 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     if (rc) return rc;
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S};
     { XSQ_PROF("band_synthesis_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<BAND_BM, BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
+    hipLaunchKernelGGL((grouped_gemm_kernel<BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     { XSQ_PROF("spectrum_gather", stream);
     hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,
