@@ -52,6 +52,10 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         S = plan.num_slices(n)
         T1, T2 = 2 * S - 1, 2 * S - 4
         r2, r8 = 2 * B * S, 8 * B * S
+        # hand-written LDS slice FFTs (window / band-spectrum gather fused in)
+        add("slice_rfft", "hbm", 2 * B * n * 4 + r2 * nbins * 8)
+        add("slice_irfft", "hbm", r8 * sumFT * 8 + r8 * L * 4)
+        # rocFFT fallback path (other plans)
         add("slice_window", "hbm", 2 * B * n * 4 + r2 * L * 4)
         add("rfft_L", "hbm", r2 * L * 4 + r2 * nbins * 8)
         add("band_analysis_gemm", "mfma", r2 * 8 * int((Lg * Lg).sum()))

@@ -63,6 +63,9 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
                     const int32_t* c, const float* g, const double* gd, const float* tw);
 int xsq_plan_destroy(xsq_plan* plan);
 int xsq_plan_num_blocks(const xsq_plan* plan);
+/* slice-FFT backend: 0 (default) = the hand-written LDS-resident transform when L == 18060
+ * (the Bark-262 plan of both pretrained models), rocFFT otherwise; 1 = always rocFFT.     */
+int xsq_plan_set_fft_backend(xsq_plan* plan, int backend);
 /* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
 int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);
 /* complex coefficients per channel-slice (sum_b F_b*T_b) */

@@ -90,3 +90,26 @@ def test_ragged_lengths(fb):
     for n in (9031, 9032, 13545, 13546, 18059, 18061, 27090, 27091):
         x = synth_audio(n, seed=n).cuda()
         assert float((dec(enc(x), n) - x).abs().max()) < 1e-5
+
+
+def test_rocfft_and_lds_fft_backends_agree(fb, oracle_plan):
+    """The Bark-262 plan runs on the hand-written LDS FFT; rocFFT stays as the generic backend."""
+    from oracle import slicqt as O
+    base, enc, dec = fb
+    eng = base.nsgt
+    n = 70000
+    x = synth_audio(n, seed=5).cuda()
+    try:
+        eng.set_fft_backend(1)
+        C_roc = [c.clone() for c in enc(x)]
+        y_roc = dec(C_roc, n)
+    finally:
+        eng.set_fft_backend(0)
+    C_lds = enc(x)
+    y_lds = dec(C_roc, n)
+    Co = O.forward(oracle_plan, x.cpu())
+    for i in range(70):
+        assert float((C_lds[i] - C_roc[i]).abs().max()) < 2e-4, i
+        assert float((C_lds[i].cpu() - Co[i]).abs().max()) < 2e-4, i
+    assert float((y_lds - y_roc).abs().max()) < 5e-6
+    assert float((y_lds - x).abs().max()) < 1e-5

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense a tools/collect_profiles.sh output directory (gpurun_out/prof_<round>) into the
+small summaries committed under profiles/: per-kernel rocprofv3 --stats table, SQ counters,
+and HBM traffic (FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for
+gfx950 wide coalesced reads; WRITE_SIZE as is; both in bytes per launch)."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+pick = max if (len(sys.argv) < 5 or sys.argv[4] == "newest") else min   # several runs may share the directory
+os.makedirs(dst, exist_ok=True)
+_glob = glob.glob
+
+
+def newest(pattern):
+    return [pick(_glob(pattern), key=os.path.getmtime)]
+
+
+glob.glob = newest
+
+
+def short(n):
+    n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("void xsq::grouped_gemm_kernel<128, xsq::", "gemm128<").replace("xsq::", "")
+    return n.split("(")[0][:48]
+
+
+ours = "gemm<|k_|fft|bluestein|c2r|r2c"
+st = pd.read_csv(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0])
+st["Kernel"] = st["Name"].map(short)
+st = st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"]]
+st.to_csv(f"{dst}/{tag}_kernel_stats.csv", index=False)
+
+out = {}
+sq = pd.read_csv(glob.glob(f"{src}/pmc_sq/*/*counter_collection.csv")[0])
+sq["Kernel"] = sq["Kernel_Name"].map(short)
+p = sq[sq.Kernel.str.contains(ours)].pivot_table(index="Kernel", columns="Counter_Name", values="Counter_Value", aggfunc="sum")
+meta = sq.groupby("Kernel")[["VGPR_Count", "Accum_VGPR_Count", "LDS_Block_Size", "Scratch_Size"]].max()
+p = p.join(meta)
+p["wait_any_frac"] = p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"]
+p["wait_inst_frac"] = p["SQ_WAIT_INST_ANY"] / p["SQ_WAVE_CYCLES"]
+p.round(4).to_csv(f"{dst}/{tag}_pmc_sq.csv")
+
+rows = []
+for name, corr in (("fetch", 2.0), ("write", 1.0)):
+    d = pd.read_csv(glob.glob(f"{src}/pmc_{name}/*/*counter_collection.csv")[0])
+    d["Kernel"] = d["Kernel_Name"].map(short)
+    d = d[d.Kernel.str.contains(ours)]
+    g = d.groupby("Kernel")["Counter_Value"].agg(["mean", "max", "count"])
+    g.columns = [f"{name}_KB_mean_raw", f"{name}_KB_max_raw", "launches"]
+    g[f"{name}_MB_per_full_chunk_launch"] = g[f"{name}_KB_max_raw"] * corr / 1024.0
+    rows.append(g)
+t = rows[0].join(rows[1], lsuffix="", rsuffix="_w")
+t.round(3).to_csv(f"{dst}/{tag}_hbm_traffic.csv")
+for f in ("trace_bench.json", "pmc_sq_bench.json"):
+    try:
+        line = open(f"{src}/{f}").read().strip().splitlines()[-1]
+        json.loads(line)
+        open(f"{dst}/{tag}_{f}", "w").write(line + "\n")
+    except Exception as e:  # noqa: BLE001
+        print("skip", f, e)
+print(st.head(14).to_string())
+print(t.round(1).to_string())

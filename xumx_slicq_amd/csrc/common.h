@@ -52,7 +52,7 @@ struct BandDev {
     int64_t cum;   // sum over earlier blocks of F_b*T_b (complex coefficients per channel-slice)
     int64_t w_off; // float offset of the band's DFT matrix inside Wf / Wi
     int ldw;       // row length (floats) of that matrix, stored transposed Wt[n][k]: round_up(2*Lg, 16)
-    int pad;
+    int ent;       // entry offset of the band inside a row of the phase-ordered synthesis output (slice_fft.h)
 };
 
 // One tile of work of a grouped GEMM launch.

@@ -35,6 +35,10 @@ struct xsq_plan {
     std::vector<xsq::BandDev> bands;
     std::vector<xsq::BlockHost> blocks;
     // device tables
+    int fft_backend = 0;            // 0: hand-written LDS FFT when L == 18060, else rocFFT; 1: always rocFFT
+    float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)
+    int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap
+    int phase_begin[5] = {0, 0, 0, 0, 0};
     float* d_tw = nullptr;          // (L) slice window
     float* d_Wf = nullptr;          // per-band analysis matrices  (window, sign, 1/Lg folded in)
     float* d_Wi = nullptr;          // per-band synthesis matrices (dual window, Lg, sign, 1/L folded in)

@@ -1,0 +1,246 @@
+// LDS-resident real FFT of one slice (length L = 18060 = 2 * 43 * 14 * 15) for gfx950.
+//
+// rocFFT needs Bluestein for the prime factor 43 (7 kernels and ~6 passes over HBM per
+// transform; 4.5 % of the HBM roofline measured in profiles/r01).  Here one workgroup owns one
+// (channel, slice) row: the half-length complex sequence z[n] = v[2n] + i v[2n+1] (9030 points,
+// 72,240 B) lives in LDS for the whole transform, so HBM sees each row exactly once in and once
+// out, and the neighbouring streaming kernels are fused in:
+//   forward  k_slice_rfft : slice + Tukey window (nsgt/slicing.py:21-72) on the load side,
+//                           radix 43 x 14 x 15 Cooley-Tukey in LDS, real post-processing on the store side
+//   inverse  k_slice_irfft: gather-sum of the per-band synthesis spectra (nsgt/nsigtf.py:85-95) and
+//                           real pre-processing on the load side, same FFT with conjugate twiddles
+// Index maps (N = 9030, M1 = 210):
+//   step 1: n = n1*210 + m,   DFT_43 over n1,  x W_N^(m*k1)        -> Z[k1*210 + m]
+//   step 2: m = n2*15 + n3,   DFT_14 over n2,  x W_N^(43*n3*k2)    -> Z[k1*210 + k2*15 + n3]
+//   step 3:                   DFT_15 over n3                        -> Z[k1*210 + k2*15 + k3] = X[k1 + 43*k2 + 602*k3]
+// Small DFTs pair x[n] +- x[R-n] (R^2/2 real FMAs instead of 2R^2) with compile-time twiddles.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+#include "dft_tables.h"
+
+namespace xsq {
+
+constexpr int FFT_L = 18060, FFT_N = 9030, FFT_R1 = 43, FFT_R2 = 14, FFT_R3 = 15, FFT_M1 = 210;
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+// X[k] = sum_n x[n] exp(SIGN * 2 pi i n k / R), results handed to emit(k, X[k]) as they are produced.
+template <int R, int SIGN, class Emit>
+__device__ __forceinline__ void dft_small(const float2 (&x)[R], Emit&& emit) {
+    constexpr int H = (R - 1) / 2;
+    constexpr bool EVEN = (R % 2) == 0;
+    float2 a[H], b[H];
+    float2 s0 = x[0];
+    static_for<1, H + 1>([&](auto nc) {
+        constexpr int n = nc;
+        a[n - 1] = c_add(x[n], x[R - n]);
+        b[n - 1] = c_sub(x[n], x[R - n]);
+        s0 = c_add(s0, a[n - 1]);
+    });
+    if constexpr (EVEN) s0 = c_add(s0, x[R / 2]);
+    emit(0, s0);
+    static_for<1, H + 1>([&](auto kc) {
+        constexpr int k = kc;
+        float2 P = x[0];
+        if constexpr (EVEN) P = (k & 1) ? c_sub(P, x[R / 2]) : c_add(P, x[R / 2]);
+        float2 Q = make_float2(0.f, 0.f);
+        static_for<1, H + 1>([&](auto nc) {
+            constexpr int n = nc;
+            constexpr float c = DftTw<R>::c[(n * k) % R];
+            constexpr float s = DftTw<R>::s[(n * k) % R];
+            P.x = fmaf(a[n - 1].x, c, P.x);
+            P.y = fmaf(a[n - 1].y, c, P.y);
+            Q.x = fmaf(b[n - 1].x, s, Q.x);
+            Q.y = fmaf(b[n - 1].y, s, Q.y);
+        });
+        // X[k] = P + SIGN*i*Q,  X[R-k] = P - SIGN*i*Q,  i*Q = (-Q.y, Q.x)
+        const float2 iq = make_float2(-SIGN * Q.y, SIGN * Q.x);
+        emit(k, c_add(P, iq));
+        emit(R - k, c_sub(P, iq));
+    });
+    if constexpr (EVEN) {
+        float2 P = ((R / 2) & 1) ? c_sub(x[0], x[R / 2]) : c_add(x[0], x[R / 2]);
+        static_for<1, H + 1>([&](auto nc) {
+            constexpr int n = nc;
+            P = (n & 1) ? c_sub(P, a[n - 1]) : c_add(P, a[n - 1]);
+        });
+        emit(R / 2, P);
+    }
+}
+
+// LDS position of output bin k (k = k1 + 43*k2 + 602*k3)
+__device__ __forceinline__ int fft_pos(int k) {
+    const int k3 = k / (FFT_R1 * FFT_R2);
+    const int r = k - k3 * (FFT_R1 * FFT_R2);
+    const int k2 = r / FFT_R1;
+    const int k1 = r - k2 * FFT_R1;
+    return k1 * FFT_M1 + k2 * FFT_R3 + k3;
+}
+
+// Twiddle tables of one plan, laid out so that consecutive lanes read consecutive entries:
+//   w1[k1*210 + m] = W_N^(m*k1)   w2[k2*15 + n3] = W_N^(43*n3*k2)   wl[k] = W_L^k (real pre/post-processing)
+struct FftTables {
+    const float2* w1;
+    const float2* w2;
+    const float2* wl;
+};
+
+// Inverse-side gather schedule.  The synthesis GEMM writes each row's 18640 band values
+// row-major, bands ordered by phase (band index mod 4) -- bands of one phase never overlap in
+// the spectrum, so a phase is accumulated into LDS with plain read-modify-writes (no atomics,
+// fixed order => bitwise reproducible) from contiguous, independent, coalesced global loads.
+struct GatherSched {
+    const int* tgt;        // (sumLg) target bin of each entry, -1 when outside [0, N]
+    int begin[5];          // entry range of phase p is [begin[p], begin[p+1])
+    int row_len;           // entries per row (sum of band lengths)
+};
+
+// Steps 2 and 3 of the complex FFT, in place on Z.  The step-1 twiddles W_N^(m*k1) are applied
+// here on the load side, where the 14 table reads of a butterfly are independent loads issued
+// together (inside step 1 each one sat behind a 43-point butterfly).  w2s = step-2 twiddles in LDS.
+// SIGN = +1 uses the conjugate twiddles.
+template <int SIGN>
+__device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restrict__ w1, const float2* w2s, int tid) {
+    for (int bf = tid; bf < FFT_R1 * FFT_R3; bf += 256) {
+        const int k1 = bf / FFT_R3, n3 = bf - k1 * FFT_R3;
+        float2* base = Z + k1 * FFT_M1 + n3;
+        const float2* wb = w1 + k1 * FFT_M1 + n3;
+        float2 v[FFT_R2], w[FFT_R2];
+#pragma unroll
+        for (int n2 = 0; n2 < FFT_R2; ++n2) w[n2] = wb[n2 * FFT_R3];
+#pragma unroll
+        for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = base[n2 * FFT_R3];
+#pragma unroll
+        for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = SIGN < 0 ? c_mul(v[n2], w[n2]) : c_mulc(v[n2], w[n2]);
+        dft_small<FFT_R2, SIGN>(v, [&](int k2, float2 X) {
+            const float2 t = w2s[k2 * FFT_R3 + n3];
+            base[k2 * FFT_R3] = SIGN < 0 ? c_mul(X, t) : c_mulc(X, t);
+        });
+    }
+    __syncthreads();
+    for (int bf = tid; bf < FFT_R1 * FFT_R2; bf += 256) {
+        float2* base = Z + bf * FFT_R3;
+        float2 v[FFT_R3];
+#pragma unroll
+        for (int n3 = 0; n3 < FFT_R3; ++n3) v[n3] = base[n3];
+        dft_small<FFT_R3, SIGN>(v, [&](int k3, float2 X) { base[k3] = X; });
+    }
+    __syncthreads();
+}
+
+// ---- forward: U[row, 0..N] = rfft_L( tw * xpad[(2s-2)h : (2s+2)h] ) --------------------------------
+__global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
+                                                     const FftTables T, float2* __restrict__ U,
+                                                     int S, int64_t n, int h) {
+    __shared__ float2 Z[FFT_N];
+    __shared__ float2 w2s[FFT_R2 * FFT_R3];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const int bc = row / S, s = row - bc * S;
+    const float* xr = x + (int64_t)bc * n;
+    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
+    const int64_t i0 = (int64_t)(2 * s - 2) * h;
+    if (tid < FFT_M1) {
+        const int m = tid;
+        float2 v[FFT_R1];
+#pragma unroll
+        for (int n1 = 0; n1 < FFT_R1; ++n1) {
+            const int p = 2 * (n1 * FFT_M1 + m);
+            const int64_t i = i0 + p;
+            v[n1].x = (i >= 0 && i < n) ? tw[p] * xr[i] : 0.f;
+            v[n1].y = (i + 1 >= 0 && i + 1 < n) ? tw[p + 1] * xr[i + 1] : 0.f;
+        }
+        dft_small<FFT_R1, -1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+    }
+    __syncthreads();
+    fft_steps_2_3<-1>(Z, T.w1, w2s, tid);
+    // real post-processing: U[k] = E + G, U[N-k] = conj(E - G), E = (Z[k] + conj Z[N-k])/2,
+    // G = -i/2 * W_L^k * (Z[k] - conj Z[N-k])
+    float2* Ur = U + (int64_t)row * (FFT_N + 1);
+    for (int k = tid; k <= FFT_N / 2; k += 256) {
+        const float2 zk = Z[fft_pos(k)];
+        const float2 zn = Z[fft_pos(k == 0 ? 0 : FFT_N - k)];
+        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 D = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+        const float2 td = c_mul(T.wl[k], D);
+        const float2 G = make_float2(td.y, -td.x);   // -i * td
+        Ur[k] = c_add(E, G);
+        Ur[FFT_N - k] = make_float2(E.x - G.x, -(E.y - G.y));
+    }
+}
+
+// ---- inverse: seg[row] = L * irfft_L( sum over covering bands of the synthesis spectra ) ------------
+__global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
+                                                      const FftTables T, float* __restrict__ seg) {
+    __shared__ float2 Z[FFT_N + 1];        // bins 0..N while gathering, then the complex sequence
+    __shared__ float2 w2s[FFT_R2 * FFT_R3];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
+    for (int k = tid; k <= FFT_N; k += 256) Z[k] = make_float2(0.f, 0.f);
+    __syncthreads();
+    // gather-sum of the band spectra, one phase of mutually disjoint bands at a time
+    const float2* zr = Zrow + (int64_t)row * G.row_len;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int e0 = G.begin[ph], e1 = G.begin[ph + 1];
+        constexpr int UN = 8;              // independent loads in flight per lane
+        for (int e = e0 + tid; e < e1; e += 256 * UN) {
+            float2 z[UN];
+            int k[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int ee = e + 256 * u;
+                k[u] = -1;
+                z[u] = make_float2(0.f, 0.f);
+                if (ee < e1) { k[u] = G.tgt[ee]; z[u] = zr[ee]; }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (k[u] >= 0) { float2 a = Z[k[u]]; a.x += z[u].x; a.y += z[u].y; Z[k[u]] = a; }
+        }
+        __syncthreads();
+    }
+    // real pre-processing in place: Zin[k] = E + i O, Zin[N-k] = conj(E) + i conj(O),
+    // E = U[k] + conj U[N-k], O = (U[k] - conj U[N-k]) * conj(W_L^k)   (no 1/2: output = L * irfft)
+    for (int k = tid; k <= FFT_N / 2; k += 256) {
+        float2 uk = Z[k], un = Z[FFT_N - k];
+        if (k == 0) { uk.y = 0.f; un.y = 0.f; }   // irfft ignores Im of DC / Nyquist (nsigtf.py:103)
+        const float2 E = make_float2(uk.x + un.x, uk.y - un.y);
+        const float2 D = make_float2(uk.x - un.x, uk.y + un.y);
+        const float2 O = c_mulc(D, T.wl[k]);
+        Z[k] = make_float2(E.x - O.y, E.y + O.x);
+        if (k != 0) Z[FFT_N - k] = make_float2(E.x + O.y, O.x - E.y);
+    }
+    __syncthreads();
+    if (tid < FFT_M1) {
+        const int m = tid;
+        float2 v[FFT_R1];
+#pragma unroll
+        for (int n1 = 0; n1 < FFT_R1; ++n1) v[n1] = Z[n1 * FFT_M1 + m];
+        dft_small<FFT_R1, +1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+    }
+    __syncthreads();
+    fft_steps_2_3<+1>(Z, T.w1, w2s, tid);
+    float2* out = reinterpret_cast<float2*>(seg + (int64_t)row * FFT_L);
+    for (int nn = tid; nn < FFT_N; nn += 256) out[nn] = Z[fft_pos(nn)];
+}
+
+}  // namespace xsq

@@ -20,6 +20,7 @@
 #include "gemm_tile.h"
 #include "plan.h"
 #include "prof.h"
+#include "slice_fft.h"
 
 namespace xsq {
 
@@ -154,12 +155,13 @@ struct BandInvOp {
     const BandDev* bands;
     const float* W;
     int BC, S;
+    int row_len;   // > 0: write row-major, phase-ordered (rows of row_len complex entries) for k_slice_irfft
 
     __device__ Group group(int j) const {
         const BandDev b = bands[j];
         Group g;
         g.M = BC * S; g.N = 2 * b.Lg; g.K = 2 * b.Lg; g.ldb = b.ldw; g.B = W + b.w_off;
-        g.Lg = b.Lg; g.bin0 = b.bin0; g.f = b.f; g.F = b.F;
+        g.Lg = b.Lg; g.bin0 = b.ent; g.f = b.f; g.F = b.F;   // bin0 slot carries the entry offset here
         g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
         return g;
     }
@@ -178,7 +180,7 @@ struct BandInvOp {
     }
     __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
         if (m >= g.M) return;
-        float* d = Z + row_off(g, m);
+        float* d = row_len ? Z + 2 * ((int64_t)m * row_len + g.bin0) : Z + row_off(g, m);
         if (n < g.N) d[n] = v0;
         if (wide && n + 32 < g.N) d[n + 32] = v1;
     }
@@ -260,6 +262,11 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
+static inline bool lds_fft(const xsq_plan* P) { return P->fft_backend == 0 && P->L == FFT_L && P->d_tgt != nullptr; }
+static inline FftTables fft_tables(const xsq_plan* P) {
+    return FftTables{P->d_T, P->d_T + FFT_R1 * FFT_M1, P->d_T + FFT_R1 * FFT_M1 + FFT_R2 * FFT_R3};
+}
+
 }  // namespace xsq
 
 using namespace xsq;
@@ -298,7 +305,7 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
             }
             BandDev d;
             d.Lg = Lg[j]; d.bin0 = c[j] - Lg[j] / 2; d.f = f; d.F = b.F; d.cum = b.cum;
-            d.ldw = (int)round_up(2 * Lg[j], 16); d.w_off = woff; d.pad = 0;
+            d.ldw = (int)round_up(2 * Lg[j], 16); d.w_off = woff; d.ent = 0;
             woff += round_up(2 * Lg[j], 64) * d.ldw;
             P->bands.push_back(d);
             g_off[j] = goff;
@@ -369,6 +376,46 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
     UP(P->d_cov_ptr, cov_ptr, int);
     UP(P->d_cov_band, cov_band, int);
 #undef UP
+    if (L == FFT_L) {   // tables of the hand-written slice FFT
+        auto W = [&](int64_t j) {   // exp(-2 pi i j / L), argument reduced exactly
+            j %= L;
+            return make_float2((float)std::cos(PI2 * j / L), (float)(-std::sin(PI2 * j / L)));
+        };
+        std::vector<float2> T;
+        for (int k1 = 0; k1 < FFT_R1; ++k1)
+            for (int m = 0; m < FFT_M1; ++m) T.push_back(W(2 * (int64_t)k1 * m));
+        for (int k2 = 0; k2 < FFT_R2; ++k2)
+            for (int n3 = 0; n3 < FFT_R3; ++n3) T.push_back(W(2 * (int64_t)FFT_R1 * n3 * k2));
+        for (int k = 0; k <= FFT_N; ++k) T.push_back(W(k));
+        XSQ_HIP(hipMalloc(&P->d_T, T.size() * sizeof(float2)));
+        XSQ_HIP(hipMemcpy(P->d_T, T.data(), T.size() * sizeof(float2), hipMemcpyHostToDevice));
+        // phase-ordered entry table of the inverse gather: bands j with j % 4 == ph are laid out back
+        // to back; valid only if the bands of one phase are pairwise disjoint inside [0, L/2]
+        std::vector<int> tgt;
+        bool ok = true;
+        for (int ph = 0; ph < 4; ++ph) {
+            P->phase_begin[ph] = (int)tgt.size();
+            int last_end = -1 << 30;
+            for (int j = ph; j < nbands; j += 4) {
+                BandDev& b = P->bands[j];
+                b.ent = (int)tgt.size();
+                const int lo = b.bin0 < 0 ? 0 : b.bin0;
+                if (lo < last_end) ok = false;
+                last_end = b.bin0 + b.Lg > L / 2 + 1 ? L / 2 + 1 : b.bin0 + b.Lg;
+                for (int q = 0; q < b.Lg; ++q) {
+                    const int k = b.bin0 + q;
+                    tgt.push_back(k >= 0 && k <= L / 2 ? k : -1);
+                }
+            }
+        }
+        P->phase_begin[4] = (int)tgt.size();
+        if (ok) {
+            XSQ_HIP(hipMalloc(&P->d_tgt, tgt.size() * sizeof(int)));
+            XSQ_HIP(hipMemcpy(P->d_tgt, tgt.data(), tgt.size() * sizeof(int), hipMemcpyHostToDevice));
+            // the device copy of the band table was uploaded before .ent was known
+            XSQ_HIP(hipMemcpy(P->d_bands, P->bands.data(), P->bands.size() * sizeof(BandDev), hipMemcpyHostToDevice));
+        }
+    }
     XSQ_HIP(hipMalloc(&P->d_tw, (size_t)L * sizeof(float)));
     XSQ_HIP(hipMemcpy(P->d_tw, tw, (size_t)L * sizeof(float), hipMemcpyHostToDevice));
     *out = P;
@@ -382,13 +429,19 @@ int xsq_plan_destroy(xsq_plan* P) {
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
     }
     for (auto& kv : P->tiles) (void)hipFree(kv.second.d_tiles);
-    (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
+    (void)hipFree(P->d_T); (void)hipFree(P->d_tgt); (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
     (void)hipFree(P->d_cov_ptr); (void)hipFree(P->d_cov_band);
     delete P;
     return XSQ_OK;
 }
 
 int xsq_plan_num_blocks(const xsq_plan* P) { return P ? P->nblocks : XSQ_ERR_ARG; }
+
+int xsq_plan_set_fft_backend(xsq_plan* P, int backend) {
+    XSQ_REQUIRE(P && (backend == 0 || backend == 1), "xsq_plan_set_fft_backend: backend must be 0 (auto) or 1 (rocFFT)");
+    P->fft_backend = backend;
+    return XSQ_OK;
+}
 
 int xsq_plan_block_table(const xsq_plan* P, int64_t* table) {
     XSQ_REQUIRE(P && table, "xsq_plan_block_table: null argument");
@@ -414,7 +467,7 @@ size_t xsq_slicqt_forward_workspace(xsq_plan* P, int BC, int64_t n) {
     if (!P || BC <= 0 || n <= 0) return 0;
     const size_t rows = (size_t)BC * xsq_plan_num_slices(P, n);
     FftPlan f;
-    if (get_fft(P, 0, (int)rows, &f)) return 0;
+    if (!lds_fft(P) && get_fft(P, 0, (int)rows, &f)) return 0;
     return al(rows * P->L * 4) + al(rows * P->nbins * 8) + al(f.work_bytes) + 256;
 }
 
@@ -428,7 +481,7 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
     XSQ_REQUIRE(S >= 2, "xsq_slicqt_forward: signal too short");
     XSQ_REQUIRE((int64_t)BC * S <= 65535, "xsq_slicqt_forward: BC*S=%lld rows exceed one launch", (long long)BC * S);
     FftPlan f;
-    int rc = get_fft(P, 0, rows, &f);
+    int rc = lds_fft(P) ? XSQ_OK : get_fft(P, 0, rows, &f);
     if (rc) return rc;
     char* w = (char*)ws;
     float* seg = (float*)w; w += al((size_t)rows * P->L * 4);
@@ -439,11 +492,16 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
                   (size_t)(w - (char*)ws) + f.work_bytes, ws_bytes);
         return XSQ_ERR_WORKSPACE;
     }
-    { XSQ_PROF("slice_window", stream);
-    hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
-                       S, n, P->L, P->h); }
-    { XSQ_PROF("rfft_L", stream); rc = run_fft(f, seg, U, fwork, stream); }
-    if (rc) return rc;
+    if (lds_fft(P)) {
+        XSQ_PROF("slice_rfft", stream);
+        hipLaunchKernelGGL(k_slice_rfft, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
+    } else {
+        { XSQ_PROF("slice_window", stream);
+        hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
+                           S, n, P->L, P->h); }
+        { XSQ_PROF("rfft_L", stream); rc = run_fft(f, seg, U, fwork, stream); }
+        if (rc) return rc;
+    }
     TileTable tt;
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
@@ -460,7 +518,7 @@ size_t xsq_slicqt_inverse_workspace(xsq_plan* P, int BC, int S) {
     if (!P || BC <= 0 || S <= 0) return 0;
     const size_t rows = (size_t)BC * S;
     FftPlan f;
-    if (get_fft(P, 1, (int)rows, &f)) return 0;
+    if (!lds_fft(P) && get_fft(P, 1, (int)rows, &f)) return 0;
     return al(rows * P->sumFT * 8) + al(rows * P->nbins * 8) + al(rows * P->L * 4) + al(f.work_bytes) + 256;
 }
 
@@ -475,7 +533,7 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     hipStream_t stream = (hipStream_t)stream_;
     const int rows = BC * S;
     FftPlan f;
-    int rc = get_fft(P, 1, rows, &f);
+    int rc = lds_fft(P) ? XSQ_OK : get_fft(P, 1, rows, &f);
     if (rc) return rc;
     char* w = (char*)ws;
     float* Z = (float*)w;    w += al((size_t)rows * P->sumFT * 8);
@@ -490,15 +548,23 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     TileTable tt;
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
-    BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S};
+    BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0};
     { XSQ_PROF("band_synthesis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
-    { XSQ_PROF("spectrum_gather", stream);
-    hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,
-                       P->d_bands, P->d_cov_ptr, P->d_cov_band, fr, BC, S, P->nbins); }
-    { XSQ_PROF("irfft_L", stream); rc = run_fft(f, fr, seg, fwork, stream); }
-    if (rc) return rc;
+    if (lds_fft(P)) {
+        XSQ_PROF("slice_irfft", stream);
+        GatherSched G;
+        G.tgt = P->d_tgt; G.row_len = (int)P->sumFT;
+        for (int i = 0; i < 5; ++i) G.begin[i] = P->phase_begin[i];
+        hipLaunchKernelGGL(k_slice_irfft, dim3(rows), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), seg);
+    } else {
+        { XSQ_PROF("spectrum_gather", stream);
+        hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,
+                           P->d_bands, P->d_cov_ptr, P->d_cov_band, fr, BC, S, P->nbins); }
+        { XSQ_PROF("irfft_L", stream); rc = run_fft(f, fr, seg, fwork, stream); }
+        if (rc) return rc;
+    }
     { XSQ_PROF("overlap_add", stream);
     hipLaunchKernelGGL(k_overlap_add, dim3((unsigned)((length + 255) / 256), BC), dim3(256), 0, stream, seg, y,
                        S, length, P->L, P->h); }

@@ -42,6 +42,13 @@ class SliCQEngine:
         self.table = BlockTable(plan.block_shapes())
         self._handles = {}
         self._ws = {}
+        self._fft_backend = 0
+
+    def set_fft_backend(self, backend: int):
+        """0 = hand-written LDS slice FFT when the plan allows it (default), 1 = rocFFT."""
+        self._fft_backend = int(backend)
+        for h in self._handles.values():
+            _lib.check(_lib.lib.xsq_plan_set_fft_backend(h, self._fft_backend), "xsq_plan_set_fft_backend")
 
     # -- handle management ---------------------------------------------------
     def handle(self, device: torch.device):
@@ -59,6 +66,7 @@ class SliCQEngine:
                     p.Lg.ctypes.data, p.c.ctypes.data, p.g.ctypes.data, p.gd.ctypes.data, p.tw.ctypes.data),
                     "xsq_plan_create")
             h = out
+            _lib.check(_lib.lib.xsq_plan_set_fft_backend(h, self._fft_backend), "xsq_plan_set_fft_backend")
             self._handles[idx] = h
         return h
 
