@@ -127,6 +127,22 @@ __device__ inline void split_row(int m, int Fo, int To, int& b, int& f, int& t) 
     t = r - f * To;
 }
 
+// BN shift + ReLU, channels-last store (layers 1-3): column n and n+32 of 52 padded channels
+__device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0, int n, const f32x16& a0,
+                                                    const f32x16& a1) {
+    const float s0 = g.shift[n];
+    const bool c1 = n + 32 < CS;
+    const float s1 = c1 ? g.shift[n + 32] : 0.f;
+    float* d0 = g.out + (int64_t)row0 * CS + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (row0 + acc_row(r) >= g.M) break;
+        float* d = d0 + acc_row(r) * CS;
+        d[0] = fmaxf(a0[r] + s0, 0.f);
+        if (c1) d[32] = fmaxf(a1[r] + s1, 0.f);
+    }
+}
+
 // ---- layer 1 -----------------------------------------------------------------------------
 struct CdaeL1Op {
     typedef CdaeGroup Group;
@@ -172,11 +188,8 @@ struct CdaeL1Op {
         if (t0 + 3 >= 0) v.w = p[3];
         return v;
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
-        if (m >= g.M) return;
-        float* d = g.out + (int64_t)m * CS;
-        d[n] = fmaxf(v0 + g.shift[n], 0.f);
-        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
+        relu_shift_epilogue(g, row0, n, a0, a1);
     }
 };
 
@@ -211,11 +224,8 @@ struct CdaeL2Op {
         const int df = k / (4 * CS), rem = k - df * 4 * CS;   // rem = dt*52 + c1, contiguous in memory
         return *reinterpret_cast<const float4*>(r.p + (int64_t)df * g.Ti * CS + rem);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
-        if (m >= g.M) return;
-        float* d = g.out + (int64_t)m * CS;
-        d[n] = fmaxf(v0 + g.shift[n], 0.f);
-        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
+        relu_shift_epilogue(g, row0, n, a0, a1);
     }
 };
 
@@ -253,11 +263,8 @@ struct CdaeL3Op {
         if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(r.p - (int64_t)df * g.Ti * CS + rem);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool) const {
-        if (m >= g.M) return;
-        float* d = g.out + (int64_t)m * CS;
-        d[n] = fmaxf(v0 + g.shift[n], 0.f);
-        if (n + 32 < CS) d[n + 32] = fmaxf(v1 + g.shift[n + 32], 0.f);
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
+        relu_shift_epilogue(g, row0, n, a0, a1);
     }
 };
 
@@ -297,24 +304,44 @@ struct CdaeL4Op {
         if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + tap) * CS + c3);
     }
-    __device__ void put(const Group& g, int b, int f, int u, int n, float acc) const {
-        const int c = n / g.hop, dt = n - c * g.hop;
-        const float mask = 1.f / (1.f + expf(-(acc + g.shift[c])));
+    // mask = sigmoid(acc + bias[c]);  Y[target] = mask * X.  Column n = c*hop + dt with n < 2*hop, so
+    // c is a compare; the row split (b, f, u) costs one division pair per lane and is then carried.
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
+        const bool v0 = n < g.N, v1 = wide && n + 32 < g.N;
+        const int n1 = n + 32;
+        const int ca = n >= g.hop, cb = n1 >= g.hop;
+        const int dta = n - ca * g.hop, dtb = n1 - cb * g.hop;
+        const float ba = g.shift[ca], bb = g.shift[cb];
         const int64_t ST = (int64_t)a.S * g.T;
-        const int64_t tau = (int64_t)u * g.hop + dt;
-        const int64_t xi = (int64_t)a.Bn * 2 * a.S * g.cum + ((int64_t)(b * 2 + c) * g.F + f) * ST + tau;
-        const int64_t yi = (int64_t)a.Bn * 8 * a.S * g.cum +
-                           ((int64_t)((g.tgt * a.Bn + b) * 2 + c) * g.F + f) * ST + tau;
-        const float2 x = reinterpret_cast<const float2*>(a.X)[xi];
-        reinterpret_cast<float2*>(a.Y)[yi] = make_float2(mask * x.x, mask * x.y);
-        if (a.masks) a.masks[yi] = mask;
-    }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
-        if (m >= g.M) return;
+        const int64_t FST = (int64_t)g.F * ST;
+        const int64_t xbase = (int64_t)a.Bn * 2 * a.S * g.cum;
+        const int64_t ybase = (int64_t)a.Bn * 8 * a.S * g.cum;
         int b, f, u;
-        split_row(m, g.Fo, g.To, b, f, u);
-        if (n < g.N) put(g, b, f, u, n, v0);
-        if (wide && n + 32 < g.N) put(g, b, f, u, n + 32, v1);
+        split_row(row0, g.Fo, g.To, b, f, u);
+        const float2* X2 = reinterpret_cast<const float2*>(a.X);
+        float2* Y2 = reinterpret_cast<float2*>(a.Y);
+        int prev = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            u += acc_row(r) - prev; prev = acc_row(r);
+            while (u >= g.To) { u -= g.To; if (++f == g.Fo) { f = 0; ++b; } }
+            if (row0 + acc_row(r) >= g.M) break;
+            const int64_t tau = (int64_t)f * ST + (int64_t)u * g.hop;
+            const int64_t xr = xbase + (int64_t)(b * 2) * FST + tau;
+            const int64_t yr = ybase + (int64_t)((g.tgt * a.Bn + b) * 2) * FST + tau;
+            if (v0) {
+                const float m = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
+                const float2 x = X2[xr + ca * FST + dta];
+                Y2[yr + ca * FST + dta] = make_float2(m * x.x, m * x.y);
+                if (a.masks) a.masks[yr + ca * FST + dta] = m;
+            }
+            if (v1) {
+                const float m = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
+                const float2 x = X2[xr + cb * FST + dtb];
+                Y2[yr + cb * FST + dtb] = make_float2(m * x.x, m * x.y);
+                if (a.masks) a.masks[yr + cb * FST + dtb] = m;
+            }
+        }
     }
 };
 

@@ -141,12 +141,10 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         cur ^= 1;
     }
 
-    // ---- epilogue -------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = t.m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        op.store_row(g, m, t.n0 + lrow, acc0[r], acc1[r], wide);
-    }
+    // ---- epilogue: accumulator register r of this lane is row row0 + acc_row(r), columns n and n+32 ----
+    op.epilogue(g, t.m0 + wave * 32 + 4 * lk, t.n0 + lrow, acc0, acc1, wide);
 }
+
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
 }  // namespace xsq

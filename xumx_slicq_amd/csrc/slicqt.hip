@@ -135,12 +135,19 @@ struct BandFwdOp {
         const float2 b = *reinterpret_cast<const float2*>(r.p + 2 * i1);
         return make_float4(a.x, a.y, b.x, b.y);
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
-        if (m >= g.M) return;
-        const int bc = m / S, s = m - bc * S;
-        float* d = coef + g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg);
-        if (n < g.N) d[n] = v0;
-        if (wide && n + 32 < g.N) d[n + 32] = v1;
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
+        const bool c0 = n < g.N, c1 = wide && n + 32 < g.N;
+        int bc = row0 / S, s = row0 - bc * S;          // one division per lane, then carry
+        int prev = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s += acc_row(r) - prev; prev = acc_row(r);
+            while (s >= S) { s -= S; ++bc; }
+            if (row0 + acc_row(r) >= g.M) break;
+            float* d = coef + g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg) + n;
+            if (c0) d[0] = a0[r];
+            if (c1) d[32] = a1[r];
+        }
     }
 };
 
@@ -178,11 +185,16 @@ struct BandInvOp {
         if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
     }
-    __device__ void store_row(const Group& g, int m, int n, float v0, float v1, bool wide) const {
-        if (m >= g.M) return;
-        float* d = row_len ? Z + 2 * ((int64_t)m * row_len + g.bin0) : Z + row_off(g, m);
-        if (n < g.N) d[n] = v0;
-        if (wide && n + 32 < g.N) d[n + 32] = v1;
+    __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
+        const bool c0 = n < g.N, c1 = wide && n + 32 < g.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = row0 + acc_row(r);
+            if (m >= g.M) break;
+            float* d = (row_len ? Z + 2 * ((int64_t)m * row_len + g.bin0) : Z + row_off(g, m)) + n;
+            if (c0) d[0] = a0[r];
+            if (c1) d[32] = a1[r];
+        }
     }
 };
 
