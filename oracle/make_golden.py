@@ -159,6 +159,31 @@ def main():
         d["chunk_size"] = 2621440 if n < 50000 else 60000
         np.savez_compressed(os.path.join(OUT, f"stems_{n}.npz"), **d)
 
+    # ---- (8) second plan: Mel-32 (the reference's small streaming models,
+    #      .github/pretrained_models_other/*/xumx_slicq_v2.json: fscale mel, fbins 32, fmin 115.5),
+    #      one demixui-sized chunk of next_pow2(sllen) = 32768 samples (demixui.py:49-51)
+    mbase = NSGTBase("mel", 32, 115.5, fs=44100.0, device="cpu")
+    menc, mdec = make_filterbanks(mbase, 44100.0)
+    mns = mbase.nsgt
+    mnb = mns.fbins_actual
+    n = 32768
+    x = synth_audio(n, seed=20260101 + n)
+    with torch.no_grad():
+        C = menc(x)
+        rng = np.random.default_rng(n)
+        P = [cb + torch.from_numpy((0.1 * rng.standard_normal(cb.shape)).astype(np.float32)) for cb in C]
+        y = mdec([p.clone() for p in P], n)
+    d = dict(L=mbase.sllen, tr=mbase.trlen, nbands=mnb, n=n, S=C[0].shape[3],
+             Lg=np.array([len(g) for g in mns.g[:mnb]], dtype=np.int32),
+             c=np.array([int(w[len(w) // 2]) for w in mns.wins[:mnb]], dtype=np.int32),
+             blocks=np.array([[b.shape[2], b.shape[4]] for b in C], dtype=np.int32),
+             g=np.concatenate([g.numpy() for g in mns.g[:mnb]]).astype(np.float32),
+             gd=np.concatenate([g.numpy() for g in mns.gd[:mnb]]).astype(np.float64),
+             inv=y.numpy())
+    for i, cb in enumerate(C):
+        d[f"fwd_{i}"] = cb.numpy()
+    np.savez_compressed(os.path.join(OUT, "mel32_32768.npz"), **d)
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

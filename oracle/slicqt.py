@@ -45,6 +45,22 @@ def bark_scale(fmin: float, fmax: float, bins: int):
     return f, q
 
 
+def mel_scale(fmin: float, fmax: float, bins: int):
+    """(f, q) of the Mel scale.  nsgt/fscale.py:131-161 (MelScale) with the generic
+    central-difference Q (fscale.py:15-23)."""
+    hz2mel = lambda f: math.log10(f / 700.0 + 1.0) * 2595.0
+    mmin, mmax = hz2mel(fmin), hz2mel(fmax)
+    mbnd = (mmax - mmin) / (bins - 1)
+    dbnd = 1.0e-8
+
+    def F(b):
+        return (math.pow(10.0, (b * mbnd + mmin) / 2595.0) - 1.0) * 700.0
+
+    f = torch.as_tensor([F(b) for b in range(bins)], dtype=torch.float32)
+    q = torch.as_tensor([F(b) * dbnd / (F(b + dbnd) - F(b - dbnd)) for b in range(bins)], dtype=torch.float32)
+    return f, q
+
+
 def suggested_sllen_trlen(f: torch.Tensor, q: torch.Tensor, sr: float):
     """nsgt/fscale.py:40-53."""
     Ls = int(torch.ceil(max((q * 8.0 * sr) / f)))
@@ -117,9 +133,12 @@ def make_plan(fscale="bark", fbins=262, fmin=32.9, fmax=22050.0, fs=44100.0,
               min_win=16) -> Plan:
     """transforms.py:21-71 (NSGTBase) -> nsgt/slicq.py:70-151 (NSGT_sliced
     with real=True, multichannel=True, Qvar=1, reducedform=0)."""
-    if fscale != "bark":
-        raise ValueError("oracle covers the Bark scale only (SURVEY.md 2, row 2)")
-    f, q = bark_scale(fmin, fmax, fbins)
+    if fscale == "bark":
+        f, q = bark_scale(fmin, fmax, fbins)
+    elif fscale == "mel":
+        f, q = mel_scale(fmin, fmax, fbins)
+    else:
+        raise ValueError("oracle covers the Bark and Mel scales (SURVEY.md 2, row 2; 8(f) rank 3)")
     L, tr = suggested_sllen_trlen(f, q, fs)
 
     # ---- nsgt/nsgfwin_sl.py:8-111 -------------------------------------
