@@ -1,0 +1,66 @@
+"""Audio front/back end: preprocess_audio shape rules
+(data.py:98-156) and wav I/O round trips without torchaudio."""
+import struct
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from xumx_slicq_amd import audio as A
+
+
+def test_preprocess_audio_shape_rules():
+    t = torch.arange(100, dtype=torch.float32)
+    assert A.preprocess_audio(t).shape == (1, 2, 100)                      # 1-D mono -> duplicated
+    assert torch.equal(A.preprocess_audio(t)[0, 0], A.preprocess_audio(t)[0, 1])
+    assert A.preprocess_audio(torch.zeros(2, 100)).shape == (1, 2, 100)    # (C, T)
+    assert A.preprocess_audio(torch.zeros(100, 2)).shape == (1, 2, 100)    # (T, C) -> swapped
+    assert A.preprocess_audio(torch.zeros(3, 2, 100)).shape == (3, 2, 100)
+    assert A.preprocess_audio(torch.zeros(5, 100)).shape == (5, 2, 100)    # all dims > 2: batch of mono
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = A.preprocess_audio(torch.arange(4 * 50, dtype=torch.float32).view(1, 4, 50))
+        assert out.shape == (1, 2, 50) and len(w) == 1
+        assert torch.equal(out[0, 1], torch.arange(50, 100, dtype=torch.float32))
+    with pytest.raises(ValueError):
+        A.preprocess_audio(t, rate=48000, model_rate=44100.0)
+    assert A.preprocess_audio(t, rate=44100, model_rate=torch.as_tensor(44100.0)).shape == (1, 2, 100)
+
+
+def test_float_wav_round_trip(tmp_path):
+    x = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, (2, 1234)).astype(np.float32))
+    p = str(tmp_path / "a.wav")
+    A.save_wav_float(p, x, 44100)
+    y, rate = A.load_audio(p)
+    assert rate == 44100 and torch.equal(x, y)
+    info = A.load_info(p)
+    assert info["samples"] == 1234 and info["channels"] == 2 and info["samplerate"] == 44100
+    seg, _ = A.load_audio(p, start=100 / 44100, dur=200 / 44100)
+    assert torch.equal(seg, x[:, 100:300])
+
+
+@pytest.mark.parametrize("bits", [8, 16, 24, 32])
+def test_pcm_wav_decoding(tmp_path, bits):
+    rng = np.random.default_rng(bits)
+    n, ch = 500, 2
+    if bits == 8:
+        v = rng.integers(0, 256, (n, ch)); raw = v.astype(np.uint8).tobytes(); want = (v - 128) / 128.0
+    elif bits == 16:
+        v = rng.integers(-32768, 32768, (n, ch)); raw = v.astype("<i2").tobytes(); want = v / 32768.0
+    elif bits == 24:
+        v = rng.integers(-(1 << 23), 1 << 23, (n, ch))
+        u = (v & 0xFFFFFF).astype(np.uint32)
+        raw = np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], -1).astype(np.uint8).tobytes()
+        want = v / 8388608.0
+    else:
+        v = rng.integers(-(1 << 31), 1 << 31, (n, ch)); raw = v.astype("<i4").tobytes(); want = v / 2147483648.0
+    fmt = struct.pack("<HHIIHH", 1, ch, 44100, 44100 * ch * bits // 8, ch * bits // 8, bits)
+    p = tmp_path / "p.wav"
+    junk = b"LISTxx"            # an odd-sized chunk before fmt must be skipped with its pad byte
+    body = struct.pack("<4sI", b"JUNK", 5) + b"12345" + b"\0" + struct.pack("<4sI", b"fmt ", 16) + fmt + \
+        struct.pack("<4sI", b"data", len(raw)) + raw
+    p.write_bytes(struct.pack("<4sI4s", b"RIFF", 4 + len(body), b"WAVE") + body)
+    y, rate = A.load_audio(str(p))
+    assert y.shape == (ch, n) and rate == 44100
+    assert np.allclose(y.numpy().T, want.astype(np.float32), atol=1e-7)

@@ -142,3 +142,27 @@ def test_full_chunk_properties(seps):
     tail = sep(x[..., 2621440:])
     assert torch.equal(a[..., 2621440:], tail), "chunks are independent work items"
     assert float(a.abs().max()) < 10.0 and float(a.pow(2).mean()) > 1e-4
+
+
+def test_inference_separate_and_cli(tmp_path, seps):
+    """inference.separate (inference.py:14-33) and the wav-in / wav-out CLI."""
+    from xumx_slicq_amd import audio as A
+    from xumx_slicq_amd.inference import inference_main, separate
+    sep = seps["offline_wiener"]
+    sep.chunk_size = 2621440
+    mono = synth_audio(30000, seed=5)[0, 0]                      # 1-D mono input
+    est, dt = separate(mono, sep, rate=44100, device="cuda")
+    assert list(est) == ["bass", "vocals", "other", "drums"] and dt > 0
+    assert est["vocals"].shape == (1, 2, 30000)
+    stereo = torch.stack([mono, mono])
+    est2, _ = separate(stereo, sep, rate=44100, device="cuda")
+    assert torch.equal(est["drums"], est2["drums"])             # mono is duplicated to stereo
+    with pytest.raises(Exception):
+        separate(mono, sep)
+    (tmp_path / "in").mkdir()
+    A.save_wav_float(str(tmp_path / "in" / "clip.wav"), stereo, 44100)
+    inference_main(["--input-dir", str(tmp_path / "in"), "--output-dir", str(tmp_path / "out")])
+    for t in ("bass", "vocals", "other", "drums"):
+        y, rate = A.load_audio(str(tmp_path / "out" / "clip" / f"{t}.wav"))
+        assert rate == 44100 and y.shape == (2, 30000)
+        assert float((y - est2[t][0].cpu()).abs().max()) < 1e-6
