@@ -138,9 +138,13 @@ int xsq_phasemix(int nblocks, const int32_t* F, const int32_t* T, const float* X
                  const float* mag, float* Y, int B, int S, void* stream);
 size_t xsq_wiener_workspace(int nblocks, const int32_t* F, const int32_t* T, int B, int S,
                             int win_len);                                   /* 0 on error */
+/*   batch_group: the window maximum max(1, 0.1*max|x|) of norbert :257 spans the batch dimension
+ *   (SURVEY.md quirk A13).  <= 0 or B: one group, the reference's behaviour for one call.  g < B
+ *   (g divides B): every run of g consecutive batch items is its own group -- lets a caller stack
+ *   independent chunks along the batch axis without changing any chunk's result.          */
 int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* X, float* Y,
-                  int B, int S, int win_len, void* workspace, size_t workspace_bytes,
-                  void* stream);
+                  int B, int S, int win_len, int batch_group, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on

@@ -166,3 +166,24 @@ def test_inference_separate_and_cli(tmp_path, seps):
         y, rate = A.load_audio(str(tmp_path / "out" / "clip" / f"{t}.wav"))
         assert rate == 44100 and y.shape == (2, 30000)
         assert float((y - est2[t][0].cpu()).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener"])
+def test_batched_chunks_equal_the_literal_chunk_loop(seps, name):
+    """Stacking the full chunks along the batch axis must not change a single bit, also with
+    nb_samples = 2 and Wiener-EM (per-chunk window maxima, quirk A13)."""
+    sep = seps[name]
+    sep.chunk_size = 60000
+    x = synth_audio(60000 * 3 + 12345, seed=77, nb_samples=2).cuda()
+    x[1] *= 7.0                                   # different loudness per batch item and per chunk
+    x[:, :, 60000:120000] *= 30.0
+    try:
+        sep.batch_chunks = False
+        a = sep(x)
+        sep.batch_chunks = True
+        b = sep(x)
+    finally:
+        sep.batch_chunks = True
+        sep.chunk_size = 2621440
+    assert a.shape == b.shape == (4, 2, 2, 60000 * 3 + 12345)
+    assert torch.equal(a, b)

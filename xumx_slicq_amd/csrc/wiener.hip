@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void k_wiener_apply(const float2* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, WTable* out) {
+static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, int group, WTable* out) {
     std::vector<int> key;
-    key.push_back(nblocks); key.push_back(Bn); key.push_back(S); key.push_back(win_len);
+    key.push_back(nblocks); key.push_back(Bn); key.push_back(S); key.push_back(win_len); key.push_back(group);
     for (int b = 0; b < nblocks; ++b) { key.push_back(F[b]); key.push_back(T[b]); }
     std::lock_guard<std::mutex> lk(g_wmu);
     auto it = g_wtables.find(key);
@@ -232,13 +232,16 @@ static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, i
         for (int b = 0; b < Bn; ++b)
             for (int f = 0; f < F[k]; ++f) {
                 WRow r;
-                r.F = F[k]; r.T = T[k]; r.b = b; r.f = f; r.nwin = nwin; r.first_row = first;
-                r.nrows = Bn * F[k]; r.pad = 0; r.cum = cum; r.stat = stat;
+                r.F = F[k]; r.T = T[k]; r.b = b; r.f = f; r.nwin = nwin;
+                // rows sharing one window maximum: the `group` consecutive batch items of this row's group
+                r.first_row = first + (b / group) * group * F[k];
+                r.nrows = group * F[k]; r.pad = 0; r.cum = cum; r.stat = stat;
                 for (int w = 0; w < nwin; ++w) { work.push_back((int)rows.size()); work.push_back(w); }
                 rows.push_back(r);
                 stat += (int64_t)nwin * STAT;
             }
-        for (int w = 0; w < nwin; ++w) { blockwin.push_back(first); blockwin.push_back(w); }
+        for (int gI = 0; gI < Bn / group; ++gI)
+            for (int w = 0; w < nwin; ++w) { blockwin.push_back(first + gI * group * F[k]); blockwin.push_back(w); }
         cum += (int64_t)F[k] * T[k];
     }
     WTable t;
@@ -279,7 +282,7 @@ int xsq_phasemix(int nblocks, const int32_t* F, const int32_t* T, const float* X
     if (rc) return rc;
     XSQ_REQUIRE(X && mag && Y, "xsq_phasemix: null argument");
     WTable t;
-    if ((rc = get_wtable(nblocks, F, T, Bn, S, 5000, &t))) return rc;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, 5000, Bn, &t))) return rc;
     hipLaunchKernelGGL(k_phasemix, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0,
                        (hipStream_t)stream_, (const float2*)X, mag, (float2*)Y, t.d_rows, Bn, S);
     XSQ_HIP(hipGetLastError());
@@ -295,15 +298,17 @@ size_t xsq_wiener_workspace(int nblocks, const int32_t* F, const int32_t* T, int
 }
 
 int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* X, float* Y, int Bn, int S,
-                  int win_len, void* ws, size_t ws_bytes, void* stream_) {
+                  int win_len, int batch_group, void* ws, size_t ws_bytes, void* stream_) {
     int rc = check_table("xsq_wiener_em", nblocks, F, T, Bn, S);
     if (rc) return rc;
     XSQ_REQUIRE(X && Y && ws, "xsq_wiener_em: null argument");
     XSQ_REQUIRE(win_len > 0, "xsq_wiener_em: win_len=%d", win_len);
+    if (batch_group <= 0) batch_group = Bn;
+    XSQ_REQUIRE(Bn % batch_group == 0, "xsq_wiener_em: batch_group=%d does not divide B=%d", batch_group, Bn);
     XSQ_REQUIRE(ws_bytes >= xsq_wiener_workspace(nblocks, F, T, Bn, S, win_len), "xsq_wiener_em: workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     WTable t;
-    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, &t))) return rc;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, batch_group, &t))) return rc;
     float* stats = (float*)ws;
     { XSQ_PROF("wiener_stats", stream);
     hipLaunchKernelGGL(k_wiener_stats, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, (const float2*)Y,

@@ -181,9 +181,11 @@ class Unmix(nn.Module):
         return ws
 
     # -- forward -----------------------------------------------------------------------
-    def forward(self, Xcomplex: List[Tensor], return_masks=False):
+    def forward(self, Xcomplex: List[Tensor], return_masks=False, wiener_batch_group: int = 0):
         """list over blocks of (B, 2, F_b, S, T_b, 2) -> list of (4, B, 2, F_b, S, T_b, 2)
-        [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82."""
+        [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82.  ``wiener_batch_group`` (extension):
+        runs of that many batch items share the Wiener window maximum (0 = the whole batch, the
+        reference's behaviour); Separator uses it to stack independent chunks along the batch."""
         from .phase import wiener_em_arena
         X, lead, S = self.table.as_arena(list(Xcomplex))
         if len(lead) != 2 or lead[1] != 2:
@@ -207,7 +209,7 @@ class Unmix(nn.Module):
                 h, X.data_ptr(), B, S, Y.data_ptr(), masks.data_ptr() if return_masks else None,
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
             if not phasemix:
-                wiener_em_arena(self.table, X, Y, B, S)
+                wiener_em_arena(self.table, X, Y, B, S, batch_group=wiener_batch_group)
         Ylist = self.table.views(Y, (4, B, 2), S)
         if return_masks:
             return Ylist, self.table.views(masks, (4, B, 2), S, complex_=False)

@@ -38,9 +38,11 @@ def _need_gpu(t: Tensor, who: str):
         raise _lib.XsqError(f"{who} runs on a ROCm device only (got '{t.device}'); there is no CPU fallback")
 
 
-def wiener_em_arena(table: BlockTable, X: Tensor, Y: Tensor, B: int, S: int, win_len: int = 5000):
+def wiener_em_arena(table: BlockTable, X: Tensor, Y: Tensor, B: int, S: int, win_len: int = 5000,
+                    batch_group: int = 0):
     """One EM iteration in place on the estimates arena Y (8B channels) given the
-    mix arena X (2B channels).  phase.py:43-59 + norbert/__init__.py:153-260."""
+    mix arena X (2B channels).  phase.py:43-59 + norbert/__init__.py:153-260.
+    ``batch_group``: runs of that many batch items share the window maximum (0 = whole batch)."""
     F, T = _tables(table)
     with torch.cuda.device(X.device):
         nbytes = _lib.lib.xsq_wiener_workspace(len(table), F.ctypes.data, T.ctypes.data, B, S, win_len)
@@ -48,7 +50,8 @@ def wiener_em_arena(table: BlockTable, X: Tensor, Y: Tensor, B: int, S: int, win
             raise _lib.XsqError("xsq_wiener_workspace: bad arguments")
         ws = _workspace(X.device, nbytes)
         _lib.check(_lib.lib.xsq_wiener_em(len(table), F.ctypes.data, T.ctypes.data, X.data_ptr(), Y.data_ptr(),
-                                          B, S, win_len, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                                          B, S, win_len, int(batch_group), ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr()),
                    "xsq_wiener_em")
 
 

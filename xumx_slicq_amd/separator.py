@@ -72,20 +72,33 @@ class Separator(nn.Module):
     @torch.no_grad()
     def forward(self, audio_big: Tensor) -> Tensor:
         """(nb_samples, 2, N) fp32 on a ROCm device -> (4, nb_samples, 2, N).  separator.py:133-232:
-        sequential chunks of chunk_size samples, short chunks zero-padded to sllen/2+1, hard concat."""
-        N = audio_big.shape[-1]
-        final_estimates = []
+        chunks of chunk_size samples, short chunks zero-padded to sllen/2+1, hard concat.
+
+        The reference walks the chunks one by one; no state crosses the loop, so here all FULL
+        chunks of the call are stacked along the batch axis and run as one pass (the Wiener
+        window maximum stays per chunk via ``wiener_batch_group``) -- same numbers, a fifth of the
+        launches.  ``batch_chunks = False`` restores the literal loop."""
+        nb, N, cs = audio_big.shape[0], audio_big.shape[-1], self.chunk_size
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
-        for start in range(0, N, self.chunk_size):
-            audio = audio_big[..., start:min(start + self.chunk_size, N)]
+        pieces = []
+        full = N // cs if getattr(self, "batch_chunks", True) else 0
+        if full >= 2:
+            a = audio_big[..., :full * cs].reshape(nb, 2, full, cs).permute(2, 0, 1, 3).reshape(full * nb, 2, cs)
+            est = self.insgt(self.xumx_model(self.nsgt(a), wiener_batch_group=nb), cs)     # (4, full*nb, 2, cs)
+            pieces.append(est.reshape(4, full, nb, 2, cs).permute(0, 2, 3, 1, 4).reshape(4, nb, 2, full * cs))
+            start0 = full * cs
+        else:
+            start0 = 0
+        for start in range(start0, N, cs):
+            audio = audio_big[..., start:min(start + cs, N)]
             n_samples = audio.shape[-1]
             if n_samples < min_samples:
                 audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
                                                       device=audio.device, dtype=audio.dtype)], dim=-1)
             X = self.nsgt(audio)
             Ycomplex_all = self.xumx_model(X)
-            final_estimates.append(self.insgt(Ycomplex_all, n_samples))
-        return final_estimates[0] if len(final_estimates) == 1 else torch.cat(final_estimates, axis=-1)
+            pieces.append(self.insgt(Ycomplex_all, n_samples))
+        return pieces[0] if len(pieces) == 1 else torch.cat(pieces, axis=-1)
 
     @staticmethod
     def to_dict(estimates: Tensor, aggregate_dict: Optional[dict] = None) -> dict:
