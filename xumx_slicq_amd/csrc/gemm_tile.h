@@ -73,12 +73,32 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
     const bool b_on = wide || s_row < 32;
 
-    float4 ga[RA];
-    float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Global loads run TWO K-steps ahead of the MFMAs (two register sets, loop unrolled by two so
+    // the set index is static): with 4 waves sharing a SIMD one K-step lasts about as long as an
+    // HBM/L2 round trip, so a distance of one left the loads on the critical path.
+    float4 ga[2][RA];
+    float4 gb[2];
+    auto load_set = [&](int set, int k) {          // set is a compile-time constant at every call site
+        if (k < K) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ga[i] = op.load_a4(g, ra[i], s_kq);
-    if (b_on) gb = *reinterpret_cast<const float4*>(bp);
-    float4 fa_lo = ga[0], fa_hi = ga[0], fb_lo = gb, fb_hi = gb;   // only used by ablation builds
+            for (int i = 0; i < RA; ++i)
+                if (!(XSQ_ABLATE & 2) || k == 0) ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
+            if (b_on && (!(XSQ_ABLATE & 4) || k == 0)) gb[set] = *reinterpret_cast<const float4*>(bp + k);
+        }
+    };
+    auto store_set = [&](int set, int buf) {
+        float* Aw = As0 + buf * BM * LD;
+        float* Bw = Bs0 + buf * BN * LD;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<float4*>(&Aw[(s_row + 64 * i) * LD + s_kq]) = ga[set][i];
+        *reinterpret_cast<float4*>(&Bw[s_row * LD + s_kq]) = gb[set];
+    };
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ga[0][i] = ga[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_set(0, 0);
+    const float4 fa_lo = ga[0][0], fa_hi = ga[0][0], fb_lo = gb[0], fb_hi = gb[0];   // ablation builds only
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -88,24 +108,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const int a_frag = (wave * 32 + lrow) * LD + 8 * lk;
     const int b_frag = lrow * LD + 8 * lk;
 
-    // prologue: stage K-step 0 into buffer 0
-#pragma unroll
-    for (int i = 0; i < RA; ++i)
-        *reinterpret_cast<float4*>(&As0[(s_row + 64 * i) * LD + s_kq]) = ga[i];
-    *reinterpret_cast<float4*>(&Bs0[s_row * LD + s_kq]) = gb;
-    __syncthreads();
-
-    int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = k0 + BK < K;
-        if (more) {   // next K-step's global loads; they land while the MFMAs run
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                if (!(XSQ_ABLATE & 2)) ga[i] = op.load_a4(g, ra[i], k0 + BK + s_kq);
-            if (b_on && !(XSQ_ABLATE & 4)) gb = *reinterpret_cast<const float4*>(bp + k0 + BK);
-        }
-        const float* As = As0 + cur * BM * LD;
-        const float* Bs = Bs0 + cur * BN * LD;
+    auto mfma_step = [&](int buf) {
+        const float* As = As0 + buf * BM * LD;
+        const float* Bs = Bs0 + buf * BN * LD;
         const float4 a_lo = (XSQ_ABLATE & 8) ? fa_lo : *reinterpret_cast<const float4*>(&As[a_frag]);
         const float4 a_hi = (XSQ_ABLATE & 8) ? fa_hi : *reinterpret_cast<const float4*>(&As[a_frag + 4]);
         const float4 b0_lo = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag]);
@@ -129,16 +134,26 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
             }
         }
-        if (more) {   // fill the other buffer (last read one K-step ago, behind the previous barrier)
-            float* Aw = As0 + (cur ^ 1) * BM * LD;
-            float* Bw = Bs0 + (cur ^ 1) * BN * LD;
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                *reinterpret_cast<float4*>(&Aw[(s_row + 64 * i) * LD + s_kq]) = ga[i];
-            *reinterpret_cast<float4*>(&Bw[s_row * LD + s_kq]) = gb;
-        }
+    };
+
+    // prologue: K-step 0 -> LDS buffer 0; K-steps 1 and 2 in flight in register sets 1 and 0
+    store_set(0, 0);
+    load_set(1, BK);
+    load_set(0, 2 * BK);
+    __syncthreads();
+
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+        // even K-step: compute buffer 0; set 1 (K-step k0+16) -> buffer 1; reload set 1 with k0+48
+        mfma_step(0);
+        if (k0 + BK < K) store_set(1, 1);
+        load_set(1, k0 + 3 * BK);
         __syncthreads();
-        cur ^= 1;
+        if (k0 + BK >= K) break;
+        // odd K-step: compute buffer 1; set 0 (K-step k0+32) -> buffer 0; reload set 0 with k0+64
+        mfma_step(1);
+        if (k0 + 2 * BK < K) store_set(0, 0);
+        load_set(0, k0 + 4 * BK);
+        __syncthreads();
     }
 
     // ---- epilogue: accumulator register r of this lane is row row0 + acc_row(r), columns n and n+32 ----
