@@ -58,7 +58,11 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         # rocFFT fallback path (other plans)
         add("slice_window", "hbm", 2 * B * n * 4 + r2 * L * 4)
         add("rfft_L", "hbm", r2 * L * 4 + r2 * nbins * 8)
-        add("band_analysis_gemm", "mfma", r2 * 8 * int((Lg * Lg).sum()))
+        # per-band DFTs: bands with Lg >= 64 on the radix-4 kernel (2*M*Lg^2 flops: four m-point DFTs),
+        # the short ones on the dense GEMM (8*M*Lg^2)
+        long_, short_ = Lg[Lg >= 64], Lg[Lg < 64]
+        add("band_analysis_dft4", "mfma", r2 * 2 * int((long_ * long_).sum()))
+        add("band_analysis_gemm", "mfma", r2 * 8 * int((short_ * short_).sum()))
         add("magnitude_whiten", "hbm", r2 * sumFT * 12)
         f1 = f2 = f3 = f4 = 0
         for (_, F, T) in plan.blocks:
@@ -72,7 +76,8 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         add("cdae_l2_gemm", "mfma", f2)
         add("cdae_l3_gemm", "mfma", f3)
         add("cdae_l4_gemm", "mfma", f4)
-        add("band_synthesis_gemm", "mfma", r8 * 8 * int((Lg * Lg).sum()))
+        add("band_synthesis_dft4", "mfma", r8 * 2 * int((long_ * long_).sum()))
+        add("band_synthesis_gemm", "mfma", r8 * 8 * int((short_ * short_).sum()))
         add("spectrum_gather", "hbm", r8 * sumFT * 8 + r8 * nbins * 8)
         add("irfft_L", "hbm", r8 * nbins * 8 + r8 * L * 4)
         add("overlap_add", "hbm", r8 * L * 4 + 8 * B * n * 4)

@@ -66,6 +66,10 @@ int xsq_plan_num_blocks(const xsq_plan* plan);
 /* slice-FFT backend: 0 (default) = the hand-written LDS-resident transform when L == 18060
  * (the Bark-262 plan of both pretrained models), rocFFT otherwise; 1 = always rocFFT.     */
 int xsq_plan_set_fft_backend(xsq_plan* plan, int backend);
+/* per-band DFTs: 1 (default) = bands with Lg >= 64 run on the radix-4 kernel (one decimation-in-
+ * frequency stage fused into the operand staging, 4x fewer MFMA flops); 0 = all bands on the
+ * dense grouped GEMM.                                                                      */
+int xsq_plan_set_band_radix4(xsq_plan* plan, int on);
 /* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
 int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);
 /* complex coefficients per channel-slice (sum_b F_b*T_b) */

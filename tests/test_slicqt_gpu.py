@@ -113,3 +113,34 @@ def test_rocfft_and_lds_fft_backends_agree(fb, oracle_plan):
         assert float((C_lds[i].cpu() - Co[i]).abs().max()) < 2e-4, i
     assert float((y_lds - y_roc).abs().max()) < 5e-6
     assert float((y_lds - x).abs().max()) < 1e-5
+
+
+def test_radix4_band_kernel_matches_dense_gemm(fb, oracle_plan):
+    """Bands with Lg >= 64 run on the radix-4 DFT kernel by default; the dense grouped GEMM is the
+    reference implementation of the same sums."""
+    from oracle import slicqt as O
+    base, enc, dec = fb
+    eng = base.nsgt
+    n = 100000
+    x = synth_audio(n, seed=9, nb_samples=2).cuda()
+    try:
+        eng.set_band_radix4(False)
+        C_dense = [c.clone() for c in enc(x)]
+        y_dense = dec(C_dense, n)
+    finally:
+        eng.set_band_radix4(True)
+    C_r4 = enc(x)
+    y_r4 = dec(C_dense, n)
+    Co = O.forward(oracle_plan, x.cpu())
+    for i in range(70):
+        assert float((C_r4[i] - C_dense[i]).abs().max()) < 1e-4, i
+        assert float((C_r4[i].cpu() - Co[i]).abs().max()) < 2e-4, i
+    assert float((y_r4 - y_dense).abs().max()) < 5e-6
+    assert float((y_r4 - x).abs().max()) < 1e-5
+    # rocFFT backend + radix-4 (arena-layout output of the synthesis kernel)
+    try:
+        eng.set_fft_backend(1)
+        y_roc = dec(C_dense, n)
+    finally:
+        eng.set_fft_backend(0)
+    assert float((y_roc - y_dense).abs().max()) < 5e-6

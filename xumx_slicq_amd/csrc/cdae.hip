@@ -60,30 +60,36 @@ struct xsq_model {
 namespace xsq {
 
 // ------------------------------------------------------------------------------------------
-// |X| + whitening.  One thread per complex coefficient of the 2B-channel arena.
+// |X| + whitening.  One thread per FOUR consecutive complex coefficients of the 2B-channel arena
+// (two 16-byte loads, one 16-byte store); block sizes are multiples of 4, so a quad never
+// straddles two blocks or two frequency rows.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_magnitude_whiten(const float2* __restrict__ X, float* __restrict__ xin,
+__global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restrict__ X, float4* __restrict__ xin,
                                                            const int64_t* __restrict__ cum,
-                                                           const int* __restrict__ blockF,
                                                            const CdaeBlockDev* __restrict__ blocks,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ scale, int nblocks,
-                                                           int BC, int S, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    // block lookup: arena offset of block b is BC*S*cum[b]
-    const int64_t per = (int64_t)BC * S;
+                                                           int BC, int S, int64_t nquads) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquads) return;
+    const int64_t i = 4 * q;
+    const int64_t per = (int64_t)BC * S;            // arena offset of block b is per*cum[b]
     int lo = 0, hi = nblocks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (per * cum[mid] <= i) lo = mid; else hi = mid - 1;
     }
-    const CdaeBlockDev b = blocks[lo];
+    const CdaeBlockDev& b = blocks[lo];
     const int64_t r = i - per * cum[lo];
     const int f = (int)((r / ((int64_t)S * b.T)) % b.F);
-    const float2 z = X[i];
-    const float mag = sqrtf(z.x * z.x + z.y * z.y);
-    xin[i] = (mag + mean[b.cumF + f]) * scale[b.cumF + f];
+    const float mu = mean[b.cumF + f], sc = scale[b.cumF + f];
+    const float4 z0 = X[2 * q], z1 = X[2 * q + 1];
+    float4 o;
+    o.x = (sqrtf(z0.x * z0.x + z0.y * z0.y) + mu) * sc;
+    o.y = (sqrtf(z0.z * z0.z + z0.w * z0.w) + mu) * sc;
+    o.z = (sqrtf(z1.x * z1.x + z1.y * z1.y) + mu) * sc;
+    o.w = (sqrtf(z1.z * z1.z + z1.w * z1.w) + mu) * sc;
+    xin[q] = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -557,9 +563,9 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act2 = (float*)w;
     const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
     { XSQ_PROF("magnitude_whiten", stream);
-    hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       (const float2*)X, xin, Mo->d_cum, Mo->d_blockF, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
-                       Mo->nblocks, Bn * 2, S, total); }
+    hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
+                       (const float4*)X, (float4*)xin, Mo->d_cum, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
+                       Mo->nblocks, Bn * 2, S, total / 4); }
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal};
     TileTable tt;
     int rc;

@@ -35,6 +35,12 @@ struct xsq_plan {
     std::vector<xsq::BandDev> bands;
     std::vector<xsq::BlockHost> blocks;
     // device tables
+    int band_radix4 = 1;            // 1: bands with Lg >= 64 run on the radix-4 kernel (band_dft4.h), 0: all on the dense GEMM
+    void* d_bands4 = nullptr;       // Band4Dev table of the eligible bands
+    float* d_pool4f = nullptr;      // DFT_m matrices, twiddles, windows: analysis direction
+    float* d_pool4i = nullptr;      //                                     synthesis direction
+    int nbands4 = 0;
+    std::vector<int> bands4_m, bands4_small;   // host copies: m of each eligible band; indices of the other bands
     int fft_backend = 0;            // 0: hand-written LDS FFT when L == 18060, else rocFFT; 1: always rocFFT
     float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)
     int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap

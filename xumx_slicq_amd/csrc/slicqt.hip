@@ -21,6 +21,7 @@
 #include "plan.h"
 #include "prof.h"
 #include "slice_fft.h"
+#include "band_dft4.h"
 
 namespace xsq {
 
@@ -201,21 +202,53 @@ struct BandInvOp {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static int upload_tiles(const std::vector<TileDev>& t, TileTable* tt) {
+    tt->ntiles = (int)t.size();
+    tt->d_tiles = nullptr;
+    if (t.empty()) return XSQ_OK;
+    XSQ_HIP(hipMalloc(&tt->d_tiles, t.size() * sizeof(TileDev)));
+    XSQ_HIP(hipMemcpy(tt->d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    return XSQ_OK;
+}
+
+// dense-GEMM tiles: all bands, or only the short ones when the radix-4 kernel takes the rest
 static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
     std::lock_guard<std::mutex> lk(P->mu);
-    auto key = std::make_tuple(0, rows, 0);
+    const bool r4 = P->band_radix4 && P->nbands4 > 0;
+    auto key = std::make_tuple(r4 ? 2 : 0, rows, 0);
     auto it = P->tiles.find(key);
-    if (it != P->tiles.end()) {
-        *out = it->second;
-        return XSQ_OK;
-    }
+    if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
     std::vector<TileDev> t;
     // longest tiles first (K = 2*Lg grows along the band table): the launch ends on short tiles
-    for (int j = P->nbands - 1; j >= 0; --j) push_group_tiles(t, j, rows, 2 * P->bands[j].Lg);
+    if (r4) {
+        for (int i = (int)P->bands4_small.size() - 1; i >= 0; --i)
+            push_group_tiles(t, P->bands4_small[i], rows, 2 * P->bands[P->bands4_small[i]].Lg);
+    } else {
+        for (int j = P->nbands - 1; j >= 0; --j) push_group_tiles(t, j, rows, 2 * P->bands[j].Lg);
+    }
     TileTable tt;
-    tt.ntiles = (int)t.size();
-    XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
-    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    int rc = upload_tiles(t, &tt);
+    if (rc) return rc;
+    P->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
+// radix-4 kernel tiles: 64 rows x 64 (or 32) real columns of the m-point DFT
+static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out) {
+    std::lock_guard<std::mutex> lk(P->mu);
+    auto key = std::make_tuple(1, rows, 0);
+    auto it = P->tiles.find(key);
+    if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
+    std::vector<TileDev> t;
+    for (int i = P->nbands4 - 1; i >= 0; --i) {
+        const int N = 2 * P->bands4_m[i];
+        for (int m0 = 0; m0 < rows; m0 += D4_BM)
+            for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{i, m0, n0, (N - n0 <= 32) ? 1 : 0});
+    }
+    TileTable tt;
+    int rc = upload_tiles(t, &tt);
+    if (rc) return rc;
     P->tiles[key] = tt;
     *out = tt;
     return XSQ_OK;
@@ -428,6 +461,71 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
             XSQ_HIP(hipMemcpy(P->d_bands, P->bands.data(), P->bands.size() * sizeof(BandDev), hipMemcpyHostToDevice));
         }
     }
+    {   // ---- radix-4 band kernel tables (band_dft4.h): bands with Lg >= 64 -------------------------
+        std::vector<Band4Dev> b4;
+        std::vector<float> pf, pi;      // analysis / synthesis pools
+        std::map<int, int64_t> doff, twoff;
+        auto alloc2 = [&](size_t n) { size_t o = pf.size(); pf.resize(o + n, 0.f); pi.resize(o + n, 0.f); return (int64_t)o; };
+        for (int j = 0; j < nbands; ++j) {
+            const BandDev& b = P->bands[j];
+            if (b.Lg < 64) { P->bands4_small.push_back(j); continue; }
+            const int n = b.Lg, m = n / 4;
+            Band4Dev d;
+            memset(&d, 0, sizeof(d));
+            d.Lg = n; d.m = m; d.bin0 = b.bin0; d.f = b.f; d.F = b.F; d.ent = b.ent; d.cum = b.cum;
+            d.ldd = (int)round_up(2 * m, 16);
+            if (!doff.count(m)) {       // Dt[n' = (k, ro)][kk = (t1, ri)] of exp(-+2 pi i k t1 / m)
+                const int64_t o = alloc2((size_t)round_up(2 * m, 64) * d.ldd);
+                doff[m] = o;
+                for (int k = 0; k < m; ++k)
+                    for (int t1 = 0; t1 < m; ++t1) {
+                        const int r = (int)(((int64_t)k * t1) % m);
+                        const double cr = std::cos(PI2 * r / m), si = std::sin(PI2 * r / m);
+                        for (int dir = 0; dir < 2; ++dir) {       // 0: analysis e^{+}, 1: synthesis e^{-}
+                            std::vector<float>& pool = dir ? pi : pf;
+                            const double dre = cr, dim = dir ? -si : si;
+                            pool[o + (size_t)(2 * k) * d.ldd + 2 * t1] = (float)dre;
+                            pool[o + (size_t)(2 * k) * d.ldd + 2 * t1 + 1] = (float)(-dim);
+                            pool[o + (size_t)(2 * k + 1) * d.ldd + 2 * t1] = (float)dim;
+                            pool[o + (size_t)(2 * k + 1) * d.ldd + 2 * t1 + 1] = (float)dre;
+                        }
+                    }
+            }
+            d.d_off = doff[m];
+            if (!twoff.count(n)) {      // twiddles w^(r t1), r = 1..3: [3][round_up(m, 8)] complex
+                const int mpad = (m + 7) & ~7;
+                const int64_t o = alloc2((size_t)3 * mpad * 2);
+                twoff[n] = o;
+                for (int r = 1; r <= 3; ++r)
+                    for (int t1 = 0; t1 < m; ++t1) {
+                        const int e = (r * t1) % n;
+                        const double cr = std::cos(PI2 * e / n), si = std::sin(PI2 * e / n);
+                        pf[o + 2 * ((size_t)(r - 1) * mpad + t1)] = (float)cr;
+                        pf[o + 2 * ((size_t)(r - 1) * mpad + t1) + 1] = (float)si;
+                        pi[o + 2 * ((size_t)(r - 1) * mpad + t1)] = (float)cr;
+                        pi[o + 2 * ((size_t)(r - 1) * mpad + t1) + 1] = (float)(-si);
+                    }
+            }
+            d.tw_off = twoff[n];
+            d.win_off = alloc2((size_t)round_up(n, 4));
+            const double sign = ((c[j] / 2) % 2 == 0) ? 1.0 : -1.0;
+            for (int q = 0; q < n; ++q) {
+                pf[d.win_off + q] = (float)((double)g[g_off[j] + q] * sign / n);
+                pi[d.win_off + q] = (float)(gd[g_off[j] + q] * n * sign / L);
+            }
+            b4.push_back(d);
+            P->bands4_m.push_back(m);
+        }
+        P->nbands4 = (int)b4.size();
+        if (P->nbands4) {
+            XSQ_HIP(hipMalloc(&P->d_bands4, b4.size() * sizeof(Band4Dev)));
+            XSQ_HIP(hipMemcpy(P->d_bands4, b4.data(), b4.size() * sizeof(Band4Dev), hipMemcpyHostToDevice));
+            XSQ_HIP(hipMalloc(&P->d_pool4f, pf.size() * sizeof(float)));
+            XSQ_HIP(hipMemcpy(P->d_pool4f, pf.data(), pf.size() * sizeof(float), hipMemcpyHostToDevice));
+            XSQ_HIP(hipMalloc(&P->d_pool4i, pi.size() * sizeof(float)));
+            XSQ_HIP(hipMemcpy(P->d_pool4i, pi.data(), pi.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     XSQ_HIP(hipMalloc(&P->d_tw, (size_t)L * sizeof(float)));
     XSQ_HIP(hipMemcpy(P->d_tw, tw, (size_t)L * sizeof(float), hipMemcpyHostToDevice));
     *out = P;
@@ -441,6 +539,7 @@ int xsq_plan_destroy(xsq_plan* P) {
         if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
     }
     for (auto& kv : P->tiles) (void)hipFree(kv.second.d_tiles);
+    (void)hipFree(P->d_bands4); (void)hipFree(P->d_pool4f); (void)hipFree(P->d_pool4i);
     (void)hipFree(P->d_T); (void)hipFree(P->d_tgt); (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
     (void)hipFree(P->d_cov_ptr); (void)hipFree(P->d_cov_band);
     delete P;
@@ -448,6 +547,12 @@ int xsq_plan_destroy(xsq_plan* P) {
 }
 
 int xsq_plan_num_blocks(const xsq_plan* P) { return P ? P->nblocks : XSQ_ERR_ARG; }
+
+int xsq_plan_set_band_radix4(xsq_plan* P, int on) {
+    XSQ_REQUIRE(P, "xsq_plan_set_band_radix4: null plan");
+    P->band_radix4 = on ? 1 : 0;
+    return XSQ_OK;
+}
 
 int xsq_plan_set_fft_backend(xsq_plan* P, int backend) {
     XSQ_REQUIRE(P && (backend == 0 || backend == 1), "xsq_plan_set_fft_backend: backend must be 0 (auto) or 1 (rocFFT)");
@@ -518,7 +623,15 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
     BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L};
-    { XSQ_PROF("band_analysis_gemm", stream);
+    if (P->band_radix4 && P->nbands4) {
+        TileTable t4;
+        rc = get_dft4_tiles(P, rows, &t4);
+        if (rc) return rc;
+        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0};
+        XSQ_PROF("band_analysis_dft4", stream);
+        hipLaunchKernelGGL(band_dft4_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+    }
+    if (tt.ntiles) { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     XSQ_HIP(hipGetLastError());
@@ -561,7 +674,16 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0};
-    { XSQ_PROF("band_synthesis_gemm", stream);
+    if (P->band_radix4 && P->nbands4) {
+        TileTable t4;
+        rc = get_dft4_tiles(P, rows, &t4);
+        if (rc) return rc;
+        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
+                     lds_fft(P) ? (int)P->sumFT : 0};
+        XSQ_PROF("band_synthesis_dft4", stream);
+        hipLaunchKernelGGL(band_dft4_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+    }
+    if (tt.ntiles) { XSQ_PROF("band_synthesis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     if (lds_fft(P)) {

@@ -50,6 +50,12 @@ class SliCQEngine:
         for h in self._handles.values():
             _lib.check(_lib.lib.xsq_plan_set_fft_backend(h, self._fft_backend), "xsq_plan_set_fft_backend")
 
+    def set_band_radix4(self, on: bool):
+        """True (default): long bands on the radix-4 DFT kernel; False: every band on the dense GEMM."""
+        self._band_radix4 = bool(on)
+        for h in self._handles.values():
+            _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(self._band_radix4)), "xsq_plan_set_band_radix4")
+
     # -- handle management ---------------------------------------------------
     def handle(self, device: torch.device):
         if device.type != "cuda":
@@ -67,6 +73,8 @@ class SliCQEngine:
                     "xsq_plan_create")
             h = out
             _lib.check(_lib.lib.xsq_plan_set_fft_backend(h, self._fft_backend), "xsq_plan_set_fft_backend")
+            _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(getattr(self, "_band_radix4", True))),
+                       "xsq_plan_set_band_radix4")
             self._handles[idx] = h
         return h
 
