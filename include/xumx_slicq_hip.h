@@ -96,6 +96,12 @@ int xsq_slicqt_forward(xsq_plan* plan, const float* x, int BC, int64_t n, float*
 size_t xsq_slicqt_inverse_workspace(xsq_plan* plan, int BC, int S);       /* 0 on error */
 int xsq_slicqt_inverse(xsq_plan* plan, const float* coef, int BC, int S, int64_t length,
                        float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, but packed channel r is written at y + row_offsets[r] (DEVICE array of BC int64 element
+ * offsets) instead of y + r*length: lets the caller place every chunk's stems directly in the
+ * final (4, nb_samples, 2, N) tensor -- the torch.cat of separator.py:231 without the copy.   */
+int xsq_slicqt_inverse_rows(xsq_plan* plan, const float* coef, int BC, int S, int64_t length,
+                            float* y, const int64_t* row_offsets, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ---- CDAE model ----------------------------------------------------------------
  * Replaces Unmix.forward (model.py:69-82) -> _SlicedUnmixCDAE.forward (model.py:213-271)

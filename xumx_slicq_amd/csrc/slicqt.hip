@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_spectrum_gather(const float* __restrict
 
 // grid (ceil(length/256), BC).  Each output sample is the sum of exactly two slices.
 __global__ __launch_bounds__(256) void k_overlap_add(const float* __restrict__ seg, float* __restrict__ y,
+                                                      const int64_t* __restrict__ row_off,
                                                       int S, int64_t length, int L, int h) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= length) return;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_overlap_add(const float* __restrict__ s
     const float* base = seg + (int64_t)bc * S * L;
     float v = base[(int64_t)s0 * L + p1 + 2 * h];
     if (s0 + 1 < S) v += base[(int64_t)(s0 + 1) * L + p1];
-    y[(int64_t)bc * length + i] = v;
+    y[(row_off ? row_off[bc] : (int64_t)bc * length) + i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -649,6 +650,11 @@ size_t xsq_slicqt_inverse_workspace(xsq_plan* P, int BC, int S) {
 
 int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t length, float* y, void* ws,
                        size_t ws_bytes, void* stream_) {
+    return xsq_slicqt_inverse_rows(P, coef, BC, S, length, y, nullptr, ws, ws_bytes, stream_);
+}
+
+int xsq_slicqt_inverse_rows(xsq_plan* P, const float* coef, int BC, int S, int64_t length, float* y,
+                            const int64_t* row_offsets, void* ws, size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(P && coef && y && ws, "xsq_slicqt_inverse: null argument");
     XSQ_REQUIRE(BC > 0 && S >= 2 && length > 0, "xsq_slicqt_inverse: BC=%d S=%d length=%lld", BC, S,
                 (long long)length);
@@ -701,7 +707,7 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     }
     { XSQ_PROF("overlap_add", stream);
     hipLaunchKernelGGL(k_overlap_add, dim3((unsigned)((length + 255) / 256), BC), dim3(256), 0, stream, seg, y,
-                       S, length, P->L, P->h); }
+                       row_offsets, S, length, P->L, P->h); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

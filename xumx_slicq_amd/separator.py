@@ -80,25 +80,34 @@ class Separator(nn.Module):
         launches.  ``batch_chunks = False`` restores the literal loop."""
         nb, N, cs = audio_big.shape[0], audio_big.shape[-1], self.chunk_size
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
-        pieces = []
+        eng = self.insgt.nsgt.nsgt
+        dev = audio_big.device
+        # every chunk's stems are written straight into their place of the result (the hard concat
+        # of separator.py:231 without a copy): packed channel (target, [chunk,] b, c) -> out row
+        out = torch.empty(4, nb, 2, N, dtype=torch.float32, device=dev)
+        rows = (torch.arange(4, device=dev).view(4, 1, 1, 1) * nb + torch.arange(nb, device=dev).view(1, 1, nb, 1)) * 2 \
+            + torch.arange(2, device=dev).view(1, 1, 1, 2)                       # (4, 1, nb, 2) row of `out`
+
+        def decode(Ylist, length, offsets):
+            arena, lead, S = eng.table.as_arena(list(Ylist))
+            eng.backward(arena, offsets.numel(), S, length, out=out, row_offsets=offsets.reshape(-1).contiguous())
+
         full = N // cs if getattr(self, "batch_chunks", True) else 0
+        start0 = 0
         if full >= 2:
             a = audio_big[..., :full * cs].reshape(nb, 2, full, cs).permute(2, 0, 1, 3).reshape(full * nb, 2, cs)
-            est = self.insgt(self.xumx_model(self.nsgt(a), wiener_batch_group=nb), cs)     # (4, full*nb, 2, cs)
-            pieces.append(est.reshape(4, full, nb, 2, cs).permute(0, 2, 3, 1, 4).reshape(4, nb, 2, full * cs))
+            Y = self.xumx_model(self.nsgt(a), wiener_batch_group=nb)             # batch = (chunk, b)
+            offs = rows * N + torch.arange(full, device=dev).view(1, full, 1, 1) * cs   # (4, full, nb, 2)
+            decode(Y, cs, offs)
             start0 = full * cs
-        else:
-            start0 = 0
         for start in range(start0, N, cs):
             audio = audio_big[..., start:min(start + cs, N)]
             n_samples = audio.shape[-1]
             if n_samples < min_samples:
                 audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
-                                                      device=audio.device, dtype=audio.dtype)], dim=-1)
-            X = self.nsgt(audio)
-            Ycomplex_all = self.xumx_model(X)
-            pieces.append(self.insgt(Ycomplex_all, n_samples))
-        return pieces[0] if len(pieces) == 1 else torch.cat(pieces, axis=-1)
+                                                      device=dev, dtype=audio.dtype)], dim=-1)
+            decode(self.xumx_model(self.nsgt(audio)), n_samples, rows * N + start)
+        return out
 
     @staticmethod
     def to_dict(estimates: Tensor, aggregate_dict: Optional[dict] = None) -> dict:

@@ -117,18 +117,25 @@ class SliCQEngine:
                                                    ws.numel(), _lib.stream_ptr()), "xsq_slicqt_forward")
         return arena, lead, S
 
-    def backward(self, arena: Tensor, BC: int, S: int, length: int) -> Tensor:
-        """arena for BC channels, S slices -> (BC, length) fp32.  `arena` is left untouched."""
+    def backward(self, arena: Tensor, BC: int, S: int, length: int, out: Tensor = None,
+                 row_offsets: Tensor = None) -> Tensor:
+        """arena for BC channels, S slices -> (BC, length) fp32.  `arena` is left untouched.
+        With ``out`` + ``row_offsets`` (device int64[BC], element offsets into ``out``) packed
+        channel r lands at out.view(-1)[row_offsets[r] : row_offsets[r] + length]."""
         h = self.handle(arena.device)
         with torch.cuda.device(arena.device):
-            y = torch.empty(BC, length, dtype=torch.float32, device=arena.device)
+            y = out if out is not None else torch.empty(BC, length, dtype=torch.float32, device=arena.device)
             nbytes = _lib.lib.xsq_slicqt_inverse_workspace(h, BC, S)
             if nbytes == 0:
                 raise _lib.XsqError("xsq_slicqt_inverse_workspace: " + _lib.last_error())
             ws = self.workspace(arena.device, nbytes)
-            _lib.check(_lib.lib.xsq_slicqt_inverse(h, arena.data_ptr(), BC, S, length, y.data_ptr(),
-                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
-                       "xsq_slicqt_inverse")
+            if out is not None:
+                assert row_offsets is not None and row_offsets.dtype == torch.int64 and row_offsets.numel() == BC
+                assert out.is_contiguous() and out.dtype == torch.float32
+            _lib.check(_lib.lib.xsq_slicqt_inverse_rows(
+                h, arena.data_ptr(), BC, S, length, y.data_ptr(),
+                row_offsets.data_ptr() if row_offsets is not None else None,
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_slicqt_inverse_rows")
         return y
 
 
