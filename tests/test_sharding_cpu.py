@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from xumx_slicq_amd.sharding import WorkItem, assign_lpt, chunk_items, demix_sharded
+from xumx_slicq_amd.sharding import (WorkItem, assign_lpt, assign_tracks_lpt, chunk_items, demix_sharded,
+                                     demix_tracks)
 
 
 def fake_separate(x):
@@ -39,6 +40,16 @@ def test_lpt_balances_and_is_deterministic():
     assert max(sum(i.length for i in r) for r in q8) / (sum(lengths) / 8) < 1.05
 
 
+def test_track_assignment_is_a_balanced_partition():
+    lengths = [150 * 44100 + 9973 * i for i in range(50)]
+    for world in (1, 2, 4, 8):
+        q = assign_tracks_lpt(lengths, world)
+        assert sorted(t for r in q for t in r) == list(range(50))
+        loads = [sum(lengths[t] for t in r) for r in q]
+        assert max(loads) - min(loads) <= max(lengths)
+    assert assign_tracks_lpt([10, 10, 10, 10], 4) == [[0], [1], [2], [3]]   # bench shape: one track per rank
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +65,14 @@ def _worker(rank, world, port, q):
         mine = assign_lpt(chunk_items([x.shape[-1] for x in tracks], 600), world)[rank]
         ok_part = all(torch.equal(part[i.track][..., i.start:i.start + i.length],
                                   ref[i.track][..., i.start:i.start + i.length]) for i in mine)
-        res = (rank, ok, ok_part)
+        # track-affine path: own tracks only, or everything with gather=True
+        whole = {t: fake_separate(x) for t, x in enumerate(tracks)}
+        own = demix_tracks(fake_separate, tracks)
+        mine_t = assign_tracks_lpt([x.shape[-1] for x in tracks], world)[rank]
+        ok_tracks = sorted(own) == sorted(mine_t) and all(torch.equal(own[t], whole[t]) for t in own)
+        allg = demix_tracks(fake_separate, tracks, gather=True)
+        ok_tracks = ok_tracks and sorted(allg) == [0, 1, 2, 3] and all(torch.equal(allg[t], whole[t]) for t in allg)
+        res = (rank, ok, ok_part and ok_tracks)
     finally:
         q.put(res)
         dist.destroy_process_group()

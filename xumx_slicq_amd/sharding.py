@@ -1,14 +1,20 @@
-"""Song-chunk sharding across the GPUs of one node.
+"""Sharding of demix work across the GPUs of one node.
 
 The reference is single-process; its chunk loop (separator.py:153-229) carries
 no state from one chunk to the next and ends in a hard ``torch.cat``
-(separator.py:231), so (track, chunk) pairs are independent work items.  Here
-they are spread over ``world_size`` ranks (one process per GPU) by
-longest-processing-time-first, each rank runs the full hot path on its items,
-and the only exchange step is an all-gather of the finished stems (RCCL over
-xGMI when the backend is ``nccl``), issued asynchronously per round so that it
-overlaps the next round's kernels.  Chunks are never merged into one Wiener
-batch (the window maximum spans the batch dimension).
+(separator.py:231), so tracks -- and, inside a track, (track, chunk) pairs -- are
+independent work items.  Two levels, one process per GPU:
+
+* ``demix_tracks`` (default, what ``bench.py --gpus N`` runs): whole tracks are dealt to
+  ranks longest-first; a rank runs ``Separator.forward`` on its tracks (full chunks stacked
+  along the batch axis) and keeps their stems.  No data-path collective: at ~9 ms per 240 s
+  track an all-gather of everybody's stems (339 MB per track) would cost several times the
+  compute, and nothing downstream needs every rank to hold every track.
+* ``demix_sharded``: (track, chunk) items dealt longest-first for batches whose track lengths
+  do not balance; the exchange step is an all-gather of the finished stems (RCCL over xGMI
+  with the ``nccl`` backend), issued ``async_op=True`` per round so it overlaps the next
+  round's kernels.  Chunks are never merged into one Wiener batch across tracks' statistics
+  (the window maximum spans the batch dimension).
 """
 from __future__ import annotations
 
@@ -47,6 +53,45 @@ def assign_lpt(items: Sequence[WorkItem], world_size: int) -> List[List[WorkItem
         queues[r].append(it)
         load[r] += it.length
     return queues
+
+
+def assign_tracks_lpt(track_lengths: Sequence[int], world_size: int) -> List[List[int]]:
+    """Whole tracks to ranks, longest first onto the least loaded rank.  Deterministic."""
+    queues: List[List[int]] = [[] for _ in range(world_size)]
+    load = [0] * world_size
+    for t in sorted(range(len(track_lengths)), key=lambda i: (-track_lengths[i], i)):
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        queues[r].append(t)
+        load[r] += track_lengths[t]
+    return queues
+
+
+def demix_tracks(separate: Callable[[Tensor], Tensor], tracks: Sequence[Tensor],
+                 group: Optional[dist.ProcessGroup] = None, gather: bool = False) -> Dict[int, Tensor]:
+    """Track-affine sharding: this rank demixes the tracks ``assign_tracks_lpt`` gives it and
+    returns {track: (4, nb_samples, 2, N_t)} for those.  ``gather=True`` additionally all-gathers
+    every track's stems to every rank (the north star's final waveform concat; off by default)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lengths = [int(t.shape[-1]) for t in tracks]
+    queues = assign_tracks_lpt(lengths, world)
+    out = {t: separate(tracks[t]) for t in queues[rank]}
+    if not gather or world == 1:
+        return out
+    rounds = max(len(q) for q in queues)
+    dev, dt, B = tracks[0].device, tracks[0].dtype, tracks[0].shape[0]
+    for k in range(rounds):
+        width = max(lengths[q[k]] for q in queues if k < len(q))
+        send = torch.zeros(4, B, 2, width, dtype=dt, device=dev)
+        if k < len(queues[rank]):
+            send[..., :lengths[queues[rank][k]]] = out[queues[rank][k]]
+        recv = torch.empty(world * 4, B, 2, width, dtype=dt, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        for r in range(world):
+            if k < len(queues[r]):
+                t = queues[r][k]
+                out[t] = recv[4 * r:4 * r + 4, ..., :lengths[t]].clone()
+    return out
 
 
 def demix_sharded(separate_chunk: Callable[[Tensor], Tensor], tracks: Sequence[Tensor],
