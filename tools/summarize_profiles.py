@@ -24,11 +24,12 @@ glob.glob = newest
 
 
 def short(n):
+    n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")
     n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("void xsq::grouped_gemm_kernel<128, xsq::", "gemm128<").replace("xsq::", "")
     return n.split("(")[0][:48]
 
 
-ours = "gemm<|k_|fft|bluestein|c2r|r2c"
+ours = "gemm|band_dft4|k_|fft|bluestein|c2r|r2c"
 st = pd.read_csv(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0])
 st["Kernel"] = st["Name"].map(short)
 st = st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"]]
@@ -51,7 +52,7 @@ for name, corr in (("fetch", 2.0), ("write", 1.0)):
     d = d[d.Kernel.str.contains(ours)]
     g = d.groupby("Kernel")["Counter_Value"].agg(["mean", "max", "count"])
     g.columns = [f"{name}_KB_mean_raw", f"{name}_KB_max_raw", "launches"]
-    g[f"{name}_MB_per_full_chunk_launch"] = g[f"{name}_KB_max_raw"] * corr / 1024.0
+    g[f"{name}_MB_largest_launch"] = g[f"{name}_KB_max_raw"] * corr / 1024.0
     rows.append(g)
 t = rows[0].join(rows[1], lsuffix="", rsuffix="_w")
 t.round(3).to_csv(f"{dst}/{tag}_hbm_traffic.csv")
