@@ -187,3 +187,41 @@ def test_batched_chunks_equal_the_literal_chunk_loop(seps, name):
         sep.chunk_size = 2621440
     assert a.shape == b.shape == (4, 2, 2, 60000 * 3 + 12345)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [1, 777, 9030, 9031])
+def test_clips_shorter_than_one_slice_are_zero_padded_like_the_reference(seps, oracle_plan, seeded_sd, n):
+    """separator.py:162-168: clips below sllen/2+1 samples are zero-padded, the stems cropped back."""
+    from oracle import separator as osep
+    sep = seps["offline_wiener"]
+    sep.chunk_size = 2621440
+    x = synth_audio(n, seed=1000 + n)
+    est = sep(x.cuda()).cpu()
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=True)
+    assert est.shape == ref.shape == (4, 1, 2, n)
+    assert float((est - ref).abs().max()) < 1e-4
+
+
+def test_c_abi_reports_errors_instead_of_crashing(seps):
+    """Status codes + xsq_last_error, never an exception across the ABI (include/xumx_slicq_hip.h)."""
+    import ctypes as C
+    from xumx_slicq_amd import _lib
+    sep = seps["offline_phasemix"]
+    eng = sep.nsgt.nsgt.nsgt
+    h = eng.handle(torch.device("cuda", 0))
+    x = synth_audio(20000, seed=2).cuda().view(2, -1).contiguous()
+    arena = torch.empty(eng.table.numel(2, eng.plan.num_slices(20000)), device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = _lib.lib.xsq_slicqt_inverse_rows(h, arena.data_ptr(), 2, 6, 20000, x.data_ptr(), None, ws.data_ptr(), 1024, None)
+    assert rc == -4 and "workspace too small" in _lib.last_error()
+    rc = _lib.lib.xsq_slicqt_forward(h, x.data_ptr(), 0, 20000, arena.data_ptr(), ws.data_ptr(), 1024, None)
+    assert rc == -1 and "BC=0" in _lib.last_error()
+    rc = _lib.lib.xsq_slicqt_inverse(h, arena.data_ptr(), 2, 6, 10 ** 9, x.data_ptr(), ws.data_ptr(), 1024, None)
+    assert rc == -1 and "exceeds" in _lib.last_error()
+    F = np.asarray([3], dtype=np.int32); T = np.asarray([8], dtype=np.int32)
+    out = C.c_void_p()
+    bad = np.zeros(5, dtype=np.float32)
+    rc = _lib.lib.xsq_model_create(C.byref(out), 1, F.ctypes.data, T.ctypes.data, 0, bad.ctypes.data, bad.size)
+    assert rc == -1 and "parameters" in _lib.last_error()
+    with pytest.raises(_lib.XsqError):
+        sep.xumx_model([torch.zeros(1, 2, Fb, 2, Tb, 2, device="cuda") for Fb, Tb in sep.xumx_model.table.shapes])

@@ -380,7 +380,16 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             case 3: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
             default: M = (int64_t)Bn * d.F * 2 * S; N = d.T; break;
         }
-        for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N);
+        if (layer == 1 || layer == 4) {
+            // the four targets read the same input (L1: whitened magnitude) / the same mix X (L4 epilogue):
+            // keep their tiles of one (row, column) patch adjacent so the re-reads hit the XCD's L2
+            for (int64_t m0 = 0; m0 < M; m0 += 128)
+                for (int n0 = 0; n0 < N; n0 += 64)
+                    for (int tgt = 0; tgt < NT; ++tgt)
+                        t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
+        } else {
+            for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N);
+        }
     }
     TileTable tt;
     tt.ntiles = (int)t.size();
