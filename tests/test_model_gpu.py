@@ -225,3 +225,30 @@ def test_c_abi_reports_errors_instead_of_crashing(seps):
     assert rc == -1 and "parameters" in _lib.last_error()
     with pytest.raises(_lib.XsqError):
         sep.xumx_model([torch.zeros(1, 2, Fb, 2, Tb, 2, device="cuda") for Fb, Tb in sep.xumx_model.table.shapes])
+
+
+def test_silence_loud_input_and_stack_cap(seps, oracle_plan, seeded_sd):
+    from oracle import separator as osep
+    # digital silence: every stem is exactly finite (the Wiener 2x2 solve is regularised by sqrt(eps))
+    for name in ("offline_phasemix", "offline_wiener", "realtime"):
+        sep = seps[name]
+        sep.chunk_size = 2621440
+        z = sep(torch.zeros(1, 2, 40000, device="cuda"))
+        assert bool(torch.isfinite(z).all()) and float(z.abs().max()) < 1e-3
+    # un-normalised (loud) float audio: the Wiener scaling max(1, 0.1*max|x|) is active
+    sep = seps["offline_wiener"]
+    x = 50.0 * synth_audio(60000, seed=31, nb_samples=3)
+    est = sep(x.cuda()).cpu()
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=True)
+    d = est - ref
+    assert float(d.pow(2).mean().sqrt()) < 1e-4 * 50 and float(d.abs().max()) < 1e-3 * 50
+    # many chunks: passes of at most max_stack stacked chunks + a single full chunk + a tail
+    try:
+        sep.chunk_size, sep.max_stack = 30000, 4
+        y = synth_audio(30000 * 9 + 777, seed=32).cuda()
+        a = sep(y)
+        sep.batch_chunks = False
+        b = sep(y)
+    finally:
+        sep.batch_chunks, sep.chunk_size, sep.max_stack = True, 2621440, 8
+    assert torch.equal(a, b)

@@ -94,12 +94,16 @@ class Separator(nn.Module):
 
         full = N // cs if getattr(self, "batch_chunks", True) else 0
         start0 = 0
-        if full >= 2:
-            a = audio_big[..., :full * cs].reshape(nb, 2, full, cs).permute(2, 0, 1, 3).reshape(full * nb, 2, cs)
+        # stack at most `max_stack` (chunk, sample) pairs per pass: bounds the workspaces (~1.8 GB per
+        # stacked full chunk) and keeps BC*S inside one launch for any track length
+        per_pass = max(1, getattr(self, "max_stack", 8) // nb)
+        while full - start0 // cs >= 2 and per_pass >= 2:
+            k = min(per_pass, full - start0 // cs)
+            a = audio_big[..., start0:start0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
             Y = self.xumx_model(self.nsgt(a), wiener_batch_group=nb)             # batch = (chunk, b)
-            offs = rows * N + torch.arange(full, device=dev).view(1, full, 1, 1) * cs   # (4, full, nb, 2)
+            offs = rows * N + start0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
             decode(Y, cs, offs)
-            start0 = full * cs
+            start0 += k * cs
         for start in range(start0, N, cs):
             audio = audio_big[..., start:min(start + cs, N)]
             n_samples = audio.shape[-1]
