@@ -354,6 +354,8 @@ struct CdaeL4Op {
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
+static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 VGPR -> 2 waves per SIMD (L3 1.51 -> 1.74 ms)
+
 static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
 
 static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
@@ -388,7 +390,7 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
                     for (int tgt = 0; tgt < NT; ++tgt)
                         t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
         } else {
-            for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N);
+            for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N, 128 * L23_MT);
         }
     }
     TileTable tt;
@@ -584,11 +586,11 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
                        CdaeL1Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 2, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l2_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL2Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 3, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l3_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op>), dim3(tt.ntiles), dim3(256), 0, stream,
+    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream,
                        CdaeL3Op{a}, tt.d_tiles, tt.ntiles); }
     if ((rc = get_cdae_tiles(Mo, 4, Bn, S, &tt))) return rc;
     { XSQ_PROF("cdae_l4_gemm", stream);

@@ -37,8 +37,8 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 struct TileDev;
 // tiles of one group: 128-row x 64-column tiles, plus a 32-column tile when the N tail is <= 32
 template <class Vec>
-static inline void push_group_tiles(Vec& out, int group, int64_t M, int N) {
-    for (int64_t m0 = 0; m0 < M; m0 += 128)          // n fastest: the N-tiles of one M-tile run back
+static inline void push_group_tiles(Vec& out, int group, int64_t M, int N, int BM = 128) {
+    for (int64_t m0 = 0; m0 < M; m0 += BM)           // n fastest: the N-tiles of one M-tile run back
         for (int n0 = 0; n0 < N; n0 += 64)           // to back and re-read the same A rows from L2
             out.push_back({group, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
 }

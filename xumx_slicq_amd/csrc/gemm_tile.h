@@ -46,10 +46,14 @@ __device__ inline int xcd_remap(int bid, int nblocks) {
 
 constexpr int GEMM_BM = 128, GEMM_BN = 64, GEMM_BK = 16, GEMM_LD = 20;
 
-template <class Op>
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// MT = 32-row MFMA tiles per wave along M: tile height BM = 128 * MT (MT = 2 for the long, regular
+// CDAE layers: twice the MFMAs per barrier and per B-tile load).
+template <class Op, int MT = 1>
 __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
                                                             int ntiles) {
-    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
+    constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
     constexpr int RA = BM / 64;     // A rows staged per thread
 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LD];
@@ -100,39 +104,50 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     load_set(0, 0);
     const float4 fa_lo = ga[0][0], fa_hi = ga[0][0], fb_lo = gb[0], fb_hi = gb[0];   // ablation builds only
 
-    f32x16 acc0, acc1;
+    f32x16 acc0[MT], acc1[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.f; acc1[i][r] = 0.f; }
 
     const int lrow = lane & 31, lk = lane >> 5;
-    const int a_frag = (wave * 32 + lrow) * LD + 8 * lk;
+    const int a_frag = (wave * 32 * MT + lrow) * LD + 8 * lk;
     const int b_frag = lrow * LD + 8 * lk;
 
     auto mfma_step = [&](int buf) {
         const float* As = As0 + buf * BM * LD;
         const float* Bs = Bs0 + buf * BN * LD;
-        const float4 a_lo = (XSQ_ABLATE & 8) ? fa_lo : *reinterpret_cast<const float4*>(&As[a_frag]);
-        const float4 a_hi = (XSQ_ABLATE & 8) ? fa_hi : *reinterpret_cast<const float4*>(&As[a_frag + 4]);
+        float a[MT][8];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float4 lo = (XSQ_ABLATE & 8) ? fa_lo : *reinterpret_cast<const float4*>(&As[a_frag + i * 32 * LD]);
+            const float4 hi = (XSQ_ABLATE & 8) ? fa_hi : *reinterpret_cast<const float4*>(&As[a_frag + i * 32 * LD + 4]);
+            a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = lo.z; a[i][3] = lo.w;
+            a[i][4] = hi.x; a[i][5] = hi.y; a[i][6] = hi.z; a[i][7] = hi.w;
+        }
         const float4 b0_lo = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag]);
         const float4 b0_hi = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 4]);
-        const float a[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
         const float b0[8] = {b0_lo.x, b0_lo.y, b0_lo.z, b0_lo.w, b0_hi.x, b0_hi.y, b0_hi.z, b0_hi.w};
         if (wide) {
             const float4 b1_lo = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD]);
             const float4 b1_hi = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD + 4]);
             const float b1[8] = {b1_lo.x, b1_lo.y, b1_lo.z, b1_lo.w, b1_hi.x, b1_hi.y, b1_hi.z, b1_hi.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (XSQ_ABLATE & 1) { acc0[i] += a[i] * b0[i]; acc1[i] += a[i] * b1[i]; continue; }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1[i], acc1, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (XSQ_ABLATE & 1) { acc0[i][kk] += a[i][kk] * b0[kk]; acc1[i][kk] += a[i][kk] * b1[kk]; continue; }
+                    acc0[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b0[kk], acc0[i], 0, 0, 0);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b1[kk], acc1[i], 0, 0, 0);
+                }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (XSQ_ABLATE & 1) { acc0[i] += a[i] * b0[i]; continue; }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (XSQ_ABLATE & 1) { acc0[i][kk] += a[i][kk] * b0[kk]; continue; }
+                    acc0[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b0[kk], acc0[i], 0, 0, 0);
+                }
         }
     };
 
@@ -157,9 +172,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     }
 
     // ---- epilogue: accumulator register r of this lane is row row0 + acc_row(r), columns n and n+32 ----
-    op.epilogue(g, t.m0 + wave * 32 + 4 * lk, t.n0 + lrow, acc0, acc1, wide);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+        op.epilogue(g, t.m0 + (wave * MT + i) * 32 + 4 * lk, t.n0 + lrow, acc0[i], acc1[i], wide);
 }
-
-__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
 
 }  // namespace xsq
