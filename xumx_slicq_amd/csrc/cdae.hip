@@ -422,8 +422,19 @@ int64_t xsq_model_num_params(int nblocks, const int32_t* F, const int32_t* T) {
     return n;
 }
 
+static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
+                       const float* params, int64_t nparams, xsq_model** partial);
+
 int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
                      const float* params, int64_t nparams) {
+    xsq_model* partial = nullptr;
+    const int rc = model_build(out, nblocks, F, T, causal, params, nparams, &partial);
+    if (rc != XSQ_OK && partial) xsq_model_destroy(partial);   // frees whatever was allocated before the failure
+    return rc;
+}
+
+static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
+                       const float* params, int64_t nparams, xsq_model** partial) {
     XSQ_REQUIRE(out && F && T && params && nblocks > 0, "xsq_model_create: null argument");
     XSQ_REQUIRE(nparams == xsq_model_num_params(nblocks, F, T),
                 "xsq_model_create: got %lld parameters, the block table needs %lld", (long long)nparams,
@@ -438,6 +449,7 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
     }
     PlanLike* P = &PL;
     xsq_model* Mo = new xsq_model();
+    *partial = Mo;
     Mo->causal = causal ? 1 : 0; Mo->nblocks = nblocks; Mo->sumFT = PL.sumFT; Mo->table = PL.blocks;
     const double eps = 1e-5;
     std::vector<float> pool, mean, scale;
@@ -524,7 +536,6 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
     Mo->sumF = cumF; Mo->sumF1 = cumF1; Mo->sumF2 = cumF2;
     if (p - params != nparams) {
         set_error("xsq_model_create: internal parameter walk mismatch");
-        delete Mo;
         return XSQ_ERR_ARG;
     }
 #define UP(dst, vec, T)                                                                           \
@@ -539,6 +550,7 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
     UP(Mo->d_cum, cum, int64_t);
     UP(Mo->d_blockF, blockF, int);
 #undef UP
+    *partial = nullptr;
     *out = Mo;
     return XSQ_OK;
 }

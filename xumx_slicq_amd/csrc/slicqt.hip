@@ -322,11 +322,25 @@ extern "C" {
 int xsq_abi_version(void) { return XSQ_ABI_VERSION; }
 const char* xsq_last_error(void) { return g_err; }
 
+static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg, const int32_t* c,
+                      const float* g, const double* gd, const float* tw);
+
 int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg, const int32_t* c,
                     const float* g, const double* gd, const float* tw) {
     XSQ_REQUIRE(out && Lg && c && g && gd && tw, "xsq_plan_create: null argument");
     XSQ_REQUIRE(L > 0 && L % 4 == 0 && tr % 2 == 0 && nbands >= 2, "xsq_plan_create: bad L/tr/nbands");
     xsq_plan* P = new xsq_plan();
+    const int rc = plan_build(P, L, tr, nbands, Lg, c, g, gd, tw);
+    if (rc != XSQ_OK) {          // frees whatever was allocated before the failure
+        xsq_plan_destroy(P);
+        return rc;
+    }
+    *out = P;
+    return XSQ_OK;
+}
+
+static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg, const int32_t* c,
+                      const float* g, const double* gd, const float* tw) {
     P->L = L; P->tr = tr; P->h = L / 4; P->nbins = L / 2 + 1; P->nbands = nbands;
     // blocks = runs of equal band length (nsgt/nsgtf.py:66-78)
     int64_t cum = 0;
@@ -346,7 +360,6 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
             const int j = b.first_band + f;
             if (Lg[j] % 4 != 0 || c[j] % 2 != 0 || Lg[j] > L / 2) {
                 set_error("xsq_plan_create: band %d has Lg=%d c=%d (need Lg%%4==0, c even, Lg<=L/2)", j, Lg[j], c[j]);
-                delete P;
                 return XSQ_ERR_ARG;
             }
             BandDev d;
@@ -529,7 +542,6 @@ int xsq_plan_create(xsq_plan** out, int L, int tr, int nbands, const int32_t* Lg
     }
     XSQ_HIP(hipMalloc(&P->d_tw, (size_t)L * sizeof(float)));
     XSQ_HIP(hipMemcpy(P->d_tw, tw, (size_t)L * sizeof(float), hipMemcpyHostToDevice));
-    *out = P;
     return XSQ_OK;
 }
 
