@@ -12,6 +12,6 @@ for v in ${VARIANTS:-0 1 2 4 6 8 14 15}; do
   python3 -c "
 import json
 d=json.loads(open('/tmp/ab_out.json').read().strip().splitlines()[-1]); k=d['kernels']
-print(' ms/step', d['ms_per_step'], {n: round(v['ms_per_step'],2) for n,v in k.items() if 'gemm' in n})" || tail -5 /tmp/ab_err.txt
+print(' ms/step', d['ms_per_step'], {n: round(v['ms_per_step'],2) for n,v in k.items() if 'gemm' in n or 'fft' in n or 'dft4' in n})" || tail -5 /tmp/ab_err.txt
 done
 /opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 $R/tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && /tmp/mfma_peak

@@ -20,6 +20,10 @@
 #include "common.h"
 #include "dft_tables.h"
 
+#ifndef XSQ_ABLATE
+#define XSQ_ABLATE 0      // diagnostic builds (tools/ablate.sh): 16 no gather, 32 no radix-43, 64 no steps 2/3, 128 no output
+#endif
+
 namespace xsq {
 
 constexpr int FFT_L = 18060, FFT_N = 9030, FFT_R1 = 43, FFT_R2 = 14, FFT_R3 = 15, FFT_M1 = 210;
@@ -198,25 +202,40 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
     __syncthreads();
     // gather-sum of the band spectra, one phase of mutually disjoint bands at a time
     const float2* zr = Zrow + (int64_t)row * G.row_len;
+    // Two phases per memory round trip: all loads of phases (0,1), then (2,3), are issued before any
+    // is consumed (they are independent -- ~19 entries per lane and phase); the accumulation itself
+    // stays phase by phase with a barrier in between, because neighbouring phases overlap in bins.
+    constexpr int UN = 19;                 // ceil(4864 / 256): covers a whole phase of the Bark-262 plan
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-        const int e0 = G.begin[ph], e1 = G.begin[ph + 1];
-        constexpr int UN = 8;              // independent loads in flight per lane
-        for (int e = e0 + tid; e < e1; e += 256 * UN) {
-            float2 z[UN];
-            int k[UN];
+    for (int pp = 0; pp < ((XSQ_ABLATE & 16) ? 0 : 4); pp += 2) {
+        const int lo0 = G.begin[pp], hi0 = G.begin[pp + 1], hi1 = G.begin[pp + 2];
+        const int span = (hi0 - lo0) > (hi1 - hi0) ? (hi0 - lo0) : (hi1 - hi0);
+        for (int off = tid; off < span; off += 256 * UN) {
+            float2 z[2][UN];
+            int k[2][UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int ee = e + 256 * u;
-                k[u] = -1;
-                z[u] = make_float2(0.f, 0.f);
-                if (ee < e1) { k[u] = G.tgt[ee]; z[u] = zr[ee]; }
+            for (int h = 0; h < 2; ++h) {
+                const int e0 = h ? hi0 : lo0, e1 = h ? hi1 : hi0;
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int ee = e0 + off + 256 * u;
+                    k[h][u] = -1;
+                    z[h][u] = make_float2(0.f, 0.f);
+                    if (ee < e1) { k[h][u] = G.tgt[ee]; z[h][u] = zr[ee]; }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (k[u] >= 0) { float2 a = Z[k[u]]; a.x += z[u].x; a.y += z[u].y; Z[k[u]] = a; }
+            for (int h = 0; h < 2; ++h) {
+                // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
+                float2 acc[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) acc[u] = Z[k[h][u] >= 0 ? k[h][u] : 0];
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (k[h][u] >= 0) Z[k[h][u]] = make_float2(acc[u].x + z[h][u].x, acc[u].y + z[h][u].y);
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
     // real pre-processing in place: Zin[k] = E + i O, Zin[N-k] = conj(E) + i conj(O),
     // E = U[k] + conj U[N-k], O = (U[k] - conj U[N-k]) * conj(W_L^k)   (no 1/2: output = L * irfft)
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
         if (k != 0) Z[FFT_N - k] = make_float2(E.x + O.y, O.x - E.y);
     }
     __syncthreads();
-    if (tid < FFT_M1) {
+    if (tid < FFT_M1 && !(XSQ_ABLATE & 32)) {
         const int m = tid;
         float2 v[FFT_R1];
 #pragma unroll
@@ -238,9 +257,10 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
         dft_small<FFT_R1, +1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
     }
     __syncthreads();
-    fft_steps_2_3<+1>(Z, T.w1, w2s, tid);
+    if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1>(Z, T.w1, w2s, tid);
     float2* out = reinterpret_cast<float2*>(seg + (int64_t)row * FFT_L);
-    for (int nn = tid; nn < FFT_N; nn += 256) out[nn] = Z[fft_pos(nn)];
+    if (!(XSQ_ABLATE & 128))
+        for (int nn = tid; nn < FFT_N; nn += 256) out[nn] = Z[fft_pos(nn)];
 }
 
 }  // namespace xsq
