@@ -156,6 +156,17 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
                   int B, int S, int win_len, int batch_group, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* ---- loss forward (validation half of training.loop, training.py:34-112 with train=False) -------
+ * Replaces ComplexMSELossCriterion (loss.py:37-76) and MaskSumLossCriterion (loss.py:79-96).
+ *   pred, target  complex arenas, 8*B channels (4 targets, B, 2, ...)
+ *   masks         real arena, 8*B channels, or NULL
+ *   out           DEVICE double[2*nblocks]: per block (complex-MSE mean over the 14 combinations,
+ *                 mask-sum mean); the criteria average these over the blocks.                  */
+size_t xsq_loss_workspace(int nblocks, const int32_t* F, const int32_t* T, int B, int S);
+int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const float* pred,
+                     const float* target, const float* masks, int B, int S, double* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on
  * its own launch stream.  xsq_profile_read synchronises the outstanding events and

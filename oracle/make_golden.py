@@ -159,6 +159,23 @@ def main():
         d["chunk_size"] = 2621440 if n < 50000 else 60000
         np.savez_compressed(os.path.join(OUT, f"stems_{n}.npz"), **d)
 
+    # ---- (7) validation half of one training.loop step (training.py:66-103, train=False, SDR term off):
+    #      B = 2 clips of 2 s, mix = sum of four seeded sources, offline model in eval mode
+    import types
+    sys.modules.setdefault("auraloss", types.SimpleNamespace(time=types.SimpleNamespace(SDSDRLoss=lambda: None)))
+    from xumx_slicq_v2.loss import ComplexMSELossCriterion, MaskSumLossCriterion
+    n = 88200
+    y_t = torch.stack([0.5 * synth_audio(n, seed=500 + j, nb_samples=2) for j in range(4)])      # (4, 2, 2, n)
+    x = y_t.sum(0)
+    with torch.no_grad():
+        Xc = enc(x)
+        Yest, Ymask = models["offline_wiener"]([c.clone() for c in Xc], return_masks=True)
+        Ytgt = enc(y_t)
+        mse = float(ComplexMSELossCriterion()(Yest, Ytgt))
+        msk = float(MaskSumLossCriterion()(Ymask))
+    np.savez_compressed(os.path.join(OUT, "validation_step.npz"), n=n, mse=mse, mask=msk, loss=mse + msk)
+    print("validation step: mse", mse, "mask", msk)
+
     # ---- (8) second plan: Mel-32 (the reference's small streaming models,
     #      .github/pretrained_models_other/*/xumx_slicq_v2.json: fscale mel, fbins 32, fmin 115.5),
     #      one demixui-sized chunk of next_pow2(sllen) = 32768 samples (demixui.py:49-51)

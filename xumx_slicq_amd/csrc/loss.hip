@@ -1,0 +1,139 @@
+// Loss forward of the reference's training/validation loop on the coefficient arenas, gfx950.
+//
+// Reference: xumx_slicq_v2/loss.py:37-76 (ComplexMSELossCriterion: per block the mean squared error of
+// the 4 + 6 + 4 one-, two- and three-target sums of estimates vs targets, /14, averaged over blocks) and
+// loss.py:79-96 (MaskSumLossCriterion: per block mean((sum_j mask_j - 1)^2), averaged over blocks);
+// training.py:86-103 adds the two.  With e_j = pred_j - target_j per real element, s1 = sum_j e_j and
+// s2 = sum_j e_j^2, the 14 squared sums add up to 4*s2 + 3*s1^2 (pairs: 2*s2 + s1^2, triples: 2*s1^2 + s2).
+// One streaming pass, fp64 partial sums, fixed-order reductions (bitwise reproducible, no atomics).
+#include <vector>
+
+#include "../../include/xumx_slicq_hip.h"
+#include "plan.h"
+#include "prof.h"
+
+namespace xsq {
+
+struct LossWork {     // one workgroup: `count` float4 quads of one block's per-target sub-arena
+    int block;
+    int pad;
+    int64_t first;    // first quad (in floats / 4) inside the per-target sub-arena of the block
+    int64_t count;
+    int64_t base_c;   // float offset of the block in a complex arena holding 8B channels
+    int64_t base_r;   // float offset of the block in the real (mask) arena
+    int64_t tstride_c, tstride_r;   // floats between consecutive targets (complex / real arena)
+    int64_t nreal;    // floats per target in the real arena (complex has 2x)
+};
+
+__global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       const float* __restrict__ masks,
+                                                       const LossWork* __restrict__ work, double* __restrict__ partial) {
+    const LossWork w = work[blockIdx.x];
+    double mse = 0.0, msk = 0.0;
+    for (int64_t q = threadIdx.x; q < w.count; q += 256) {
+        const int64_t i = 4 * (w.first + q);                 // float index inside the per-target complex sub-arena
+        float4 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 p = *reinterpret_cast<const float4*>(pred + w.base_c + j * w.tstride_c + i);
+            const float4 t = *reinterpret_cast<const float4*>(tgt + w.base_c + j * w.tstride_c + i);
+            e[j] = make_float4(p.x - t.x, p.y - t.y, p.z - t.z, p.w - t.w);
+        }
+        const float s1x = e[0].x + e[1].x + e[2].x + e[3].x, s1y = e[0].y + e[1].y + e[2].y + e[3].y;
+        const float s1z = e[0].z + e[1].z + e[2].z + e[3].z, s1w = e[0].w + e[1].w + e[2].w + e[3].w;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s2 += e[j].x * e[j].x + e[j].y * e[j].y + e[j].z * e[j].z + e[j].w * e[j].w;
+        mse += (double)(4.f * s2 + 3.f * (s1x * s1x + s1y * s1y + s1z * s1z + s1w * s1w));
+        if (masks && i < w.nreal) {       // the real arena is half as long: quads [0, nreal/4) of this block
+            float4 m = *reinterpret_cast<const float4*>(masks + w.base_r + i);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const float4 mj = *reinterpret_cast<const float4*>(masks + w.base_r + j * w.tstride_r + i);
+                m.x += mj.x; m.y += mj.y; m.z += mj.z; m.w += mj.w;
+            }
+            m.x -= 1.f; m.y -= 1.f; m.z -= 1.f; m.w -= 1.f;
+            msk += (double)(m.x * m.x + m.y * m.y + m.z * m.z + m.w * m.w);
+        }
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = mse;
+    red[1][threadIdx.x] = msk;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+// one thread per block: fixed-order sum of its workgroups' partials, scaled to the block's mean
+__global__ void k_loss_combine(const double* __restrict__ partial, const int* __restrict__ first_wg,
+                               const double* __restrict__ inv_n, double* __restrict__ out, int nblocks) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    double a = 0.0, m = 0.0;
+    for (int g = first_wg[b]; g < first_wg[b + 1]; ++g) { a += partial[2 * g]; m += partial[2 * g + 1]; }
+    out[2 * b] = a * inv_n[2 * b];          // / (14 * elements)
+    out[2 * b + 1] = m * inv_n[2 * b + 1];  // / mask elements
+}
+
+}  // namespace xsq
+
+using namespace xsq;
+
+extern "C" {
+
+size_t xsq_loss_workspace(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S) {
+    if (nblocks <= 0 || !F || !T || Bn <= 0 || S <= 0) return 0;
+    size_t nwg = 0;
+    for (int b = 0; b < nblocks; ++b) nwg += ((size_t)Bn * 2 * F[b] * S * T[b] * 2 / 4 + 4095) / 4096;
+    return nwg * (sizeof(LossWork) + 16) + (size_t)nblocks * 64 + 1024;
+}
+
+int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
+                     const float* masks, int Bn, int S, double* out, void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(nblocks > 0 && F && T && pred && target && out && ws, "xsq_loss_forward: null argument");
+    XSQ_REQUIRE(Bn > 0 && S > 0, "xsq_loss_forward: B=%d S=%d", Bn, S);
+    XSQ_REQUIRE(ws_bytes >= xsq_loss_workspace(nblocks, F, T, Bn, S), "xsq_loss_forward: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<LossWork> work;
+    std::vector<int> first(nblocks + 1, 0);
+    std::vector<double> inv(2 * nblocks);
+    int64_t cum = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int64_t per_t_real = (int64_t)Bn * 2 * F[b] * S * T[b];      // floats per target, real arena
+        const int64_t quads = per_t_real * 2 / 4;                         // complex sub-arena in float4
+        first[b] = (int)work.size();
+        for (int64_t q0 = 0; q0 < quads; q0 += 4096) {
+            LossWork w;
+            w.block = b; w.pad = 0; w.first = q0; w.count = quads - q0 < 4096 ? quads - q0 : 4096;
+            w.base_c = 2 * (int64_t)Bn * 8 * S * cum; w.base_r = (int64_t)Bn * 8 * S * cum;
+            w.tstride_c = 2 * per_t_real; w.tstride_r = per_t_real; w.nreal = per_t_real;
+            work.push_back(w);
+        }
+        inv[2 * b] = 1.0 / (14.0 * (double)(2 * per_t_real));
+        inv[2 * b + 1] = 1.0 / (double)per_t_real;
+        cum += (int64_t)F[b] * T[b];
+    }
+    first[nblocks] = (int)work.size();
+    char* p = (char*)ws;
+    LossWork* d_work = (LossWork*)p; p += work.size() * sizeof(LossWork);
+    double* d_partial = (double*)p;  p += work.size() * 16;
+    double* d_inv = (double*)p;      p += (size_t)nblocks * 16;
+    int* d_first = (int*)p;
+    XSQ_HIP(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(LossWork), hipMemcpyHostToDevice, stream));
+    XSQ_HIP(hipMemcpyAsync(d_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    XSQ_HIP(hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    XSQ_HIP(hipStreamSynchronize(stream));     // the host vectors go out of scope; loss evaluation is not on the hot path
+    { XSQ_PROF("loss_partial", stream);
+    hipLaunchKernelGGL(k_loss_partial, dim3((unsigned)work.size()), dim3(256), 0, stream, pred, target, masks, d_work, d_partial); }
+    hipLaunchKernelGGL(k_loss_combine, dim3((nblocks + 63) / 64), dim3(64), 0, stream, d_partial, d_first, d_inv, out, nblocks);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+}  // extern "C"
