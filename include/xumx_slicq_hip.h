@@ -167,6 +167,14 @@ int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const floa
                      const float* target, const float* masks, int B, int S, double* out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- dataset statistics (training.get_statistics, training.py:115-154) ---------------------------
+ * Per block and frequency bin: sum and sum of squares over the S*T_b frames of the channel-mean
+ * magnitude of X (C packed channels of ONE track).  out: DEVICE double[2 * sum_b F_b] (sum, sumsq per
+ * bin, blocks back to back); the host merges tracks and forms mean / std like sklearn's
+ * StandardScaler.partial_fit.  workspace >= 32 * sum_b F_b bytes.                              */
+int xsq_magnitude_stats(int nblocks, const int32_t* F, const int32_t* T, const float* X, int C, int S,
+                        double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on
  * its own launch stream.  xsq_profile_read synchronises the outstanding events and

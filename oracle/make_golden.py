@@ -176,6 +176,48 @@ def main():
     np.savez_compressed(os.path.join(OUT, "validation_step.npz"), n=n, mse=mse, mask=msk, loss=mse + msk)
     print("validation step: mse", mse, "mask", msk)
 
+    # ---- (9) dataset statistics: the reference's training.get_statistics on three seeded "tracks"
+    # training.py pulls in packages that are absent offline; none of them is touched by get_statistics
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Stub(self.__name__ + "." + k)
+        def __call__(self, *a, **k):
+            return None
+    for name in ("torchaudio", "torchaudio.transforms", "torchinfo", "torch.utils.tensorboard", "tensorboard",
+                 "musdb", "museval"):
+        sys.modules.setdefault(name, _Stub(name))
+    import importlib
+    try:
+        tr = importlib.import_module("xumx_slicq_v2.training")
+        have_training = True
+    except Exception as e:  # training.py drags in data.py / torchaudio / torchinfo / tensorboard
+        have_training = False
+        print("training.py not importable here (", type(e).__name__, e, "): restating get_statistics' loop inline")
+    lens = (50000, 80000, 30000)
+
+    class _DS:
+        random_chunks = True; seq_duration = 1.0; samples_per_track = 2; augmentations = 1
+        random_track_mix = True; random_interferer_mix = True
+        def __len__(self): return len(lens)
+        def __getitem__(self, i): return synth_audio(lens[i], seed=900 + i)[0], None
+
+    if have_training:
+        means, stds = tr.get_statistics(types.SimpleNamespace(quiet=True), (enc, dec, cnorm), _DS(), len(jag))
+    else:
+        import sklearn.preprocessing
+        scalers = [sklearn.preprocessing.StandardScaler() for _ in jag]
+        for i in range(len(lens)):
+            X = cnorm(enc(_DS()[i][0][None, ...]))
+            for k, Xb in enumerate(X):       # training.py:141-149, verbatim semantics
+                flat = np.squeeze(torch.flatten(Xb, start_dim=-2, end_dim=-1).mean(1, keepdim=False).permute(0, 2, 1), axis=0)
+                scalers[k].partial_fit(flat)
+        stds = [np.maximum(sc.scale_, 1e-4 * np.max(sc.scale_)) for sc in scalers]
+        means = [sc.mean_ for sc in scalers]
+    np.savez_compressed(os.path.join(OUT, "statistics.npz"), lens=np.array(lens), via_reference_function=have_training,
+                        means=np.concatenate(means), stds=np.concatenate(stds))
+
     # ---- (8) second plan: Mel-32 (the reference's small streaming models,
     #      .github/pretrained_models_other/*/xumx_slicq_v2.json: fscale mel, fbins 32, fmin 115.5),
     #      one demixui-sized chunk of next_pow2(sllen) = 32768 samples (demixui.py:49-51)

@@ -137,3 +137,62 @@ int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const floa
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Dataset statistics (training.get_statistics, training.py:115-154): per block and frequency bin the
+// count, sum and sum of squares over frames of the channel-mean magnitude  m = mean_c |X[c, f, frame]|.
+// One workgroup per (block, bin) row, fp64 accumulation, fixed-order reduction.
+// ------------------------------------------------------------------------------------------------
+namespace xsq {
+struct StatRow {
+    int F, T, f, pad;
+    int64_t cum;       // sum over earlier blocks of F*T
+    int64_t out;       // index of the row in the output (sum over earlier blocks of F, plus f)
+};
+
+__global__ __launch_bounds__(256) void k_magnitude_stats(const float2* __restrict__ X, const StatRow* __restrict__ rows,
+                                                          double* __restrict__ out, int C, int S) {
+    const StatRow r = rows[blockIdx.x];
+    const int64_t N = (int64_t)S * r.T;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        float m = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float2 z = X[(int64_t)C * S * r.cum + ((int64_t)c * r.F + r.f) * N + n];
+            m += sqrtf(z.x * z.x + z.y * z.y);
+        }
+        m /= (float)C;
+        s1 += (double)m;
+        s2 += (double)m * (double)m;
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[2 * r.out] = red[0][0]; out[2 * r.out + 1] = red[1][0]; }
+}
+}  // namespace xsq
+
+extern "C" int xsq_magnitude_stats(int nblocks, const int32_t* F, const int32_t* T, const float* X, int C, int S,
+                                   double* out, void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(nblocks > 0 && F && T && X && out && ws, "xsq_magnitude_stats: null argument");
+    XSQ_REQUIRE(C > 0 && S > 0, "xsq_magnitude_stats: C=%d S=%d", C, S);
+    std::vector<xsq::StatRow> rows;
+    int64_t cum = 0, o = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        for (int f = 0; f < F[b]; ++f) rows.push_back(xsq::StatRow{F[b], T[b], f, 0, cum, o++});
+        cum += (int64_t)F[b] * T[b];
+    }
+    XSQ_REQUIRE(ws_bytes >= rows.size() * sizeof(xsq::StatRow), "xsq_magnitude_stats: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    XSQ_HIP(hipMemcpyAsync(ws, rows.data(), rows.size() * sizeof(xsq::StatRow), hipMemcpyHostToDevice, stream));
+    XSQ_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(xsq::k_magnitude_stats, dim3((unsigned)rows.size()), dim3(256), 0, stream, (const float2*)X,
+                       (const xsq::StatRow*)ws, out, C, S);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
