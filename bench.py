@@ -88,6 +88,33 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
     return w
 
 
+_PMC_NAMES = {"cdae_l1_gemm": "gemm<CdaeL1Op>", "cdae_l2_gemm": "gemm<CdaeL2Op>", "cdae_l3_gemm": "gemm<CdaeL3Op>",
+              "cdae_l4_gemm": "gemm<CdaeL4Op>", "band_synthesis_gemm": "gemm<BandInvOp>",
+              "band_analysis_gemm": "gemm<BandFwdOp>", "band_synthesis_dft4": "band_dft4<inverse>",
+              "band_analysis_dft4": "band_dft4<forward>", "slice_irfft": "k_slice_irfft", "slice_rfft": "k_slice_rfft",
+              "overlap_add": "k_overlap_add", "magnitude_whiten": "k_magnitude_whiten"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/collect_profiles.sh -> tools/summarize_profiles.py; FETCH_SIZE doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes, WRITE_SIZE as is; both are KB per dispatch, averaged over the
+    launches of a step).  None when no profile of the current kernels is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    if not files or kernel not in _PMC_NAMES:
+        return None
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if row["Kernel"] == _PMC_NAMES[kernel]:
+                try:
+                    return int((2.0 * float(row["fetch_KB_mean_raw"]) + float(row["write_KB_mean_raw"])) * 1024)
+                except (KeyError, ValueError):
+                    return None
+    return None
+
+
 def cpu_baseline(threads):
     """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this
     box's host cores on a bounded sample: one 30 s clip through the same configuration."""
@@ -206,7 +233,7 @@ def main():
             else:
                 ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
             roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                         "avg_launch_ms": round(ms / launches, 4), "launches": launches,
                         "share_of_step": round(ms / (dt * 1e3), 4)}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps}
