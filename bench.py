@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (Separator.forward_graphed)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: all-gather every track's stems to every rank inside the timed region")
     args = ap.parse_args()
@@ -187,9 +189,10 @@ def main():
                   for t in range(world)]
 
     def step():
+        run = sep.forward_graphed if args.graph else sep
         if world == 1:
-            return sep(tracks[0])
-        return demix_tracks(sep, tracks, gather=args.gather)
+            return run(tracks[0])
+        return demix_tracks(run, tracks, gather=args.gather)
 
     for _ in range(args.warmup):
         step()
