@@ -40,3 +40,23 @@ def validation_step(plan, sd, x, y_targets):
         Yt = oslicqt.forward(plan, y_targets)
         mse, msk = float(complex_mse(Y, Yt)), float(mask_sum(masks))
     return mse + msk, mse, msk
+
+
+TRAINABLE_SUFFIXES = ("input_mean", "input_scale", ".weight", ".bias")
+
+
+def training_gradients(plan, sd, x, y_targets, causal: bool, wiener: bool):
+    """One forward + backward of training.loop (training.py:66-108, train=True, SDR term off, fp32):
+    BatchNorm on batch statistics, loss = ComplexMSE + MaskSum, torch autograd.  Returns
+    (loss, mse, mask, {key: grad}) for every trainable tensor of the state_dict."""
+    params = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and k.endswith(TRAINABLE_SUFFIXES)) else v)
+              for k, v in sd.items()}
+    with torch.no_grad():
+        X = oslicqt.forward(plan, x)
+        Yt = oslicqt.forward(plan, y_targets)
+    Y, masks = omodel.unmix(params, X, causal=causal, wiener=wiener, training=True)
+    mse, msk = complex_mse(Y, Yt), mask_sum(masks)
+    loss = mse + msk
+    loss.backward()
+    grads = {k: v.grad for k, v in params.items() if isinstance(v, torch.Tensor) and v.requires_grad}
+    return float(loss), float(mse), float(msk), grads

@@ -176,6 +176,42 @@ def main():
     np.savez_compressed(os.path.join(OUT, "validation_step.npz"), n=n, mse=mse, mask=msk, loss=mse + msk)
     print("validation step: mse", mse, "mask", msk)
 
+    # ---- (7b) one TRAINING step of the reference (training.py:66-108): unmix.train(), loss.backward().
+    #       B = 2 clips of 1 s (S = 6), realtime (causal + mix-phase) and offline (Wiener-EM) models.
+    n = 44100
+    y_t = torch.stack([0.5 * synth_audio(n, seed=600 + j, nb_samples=2) for j in range(4)])
+    x = y_t.sum(0)
+    d = dict(n=n)
+    keep_keys = ["sliced_umx.0.input_mean", "sliced_umx.0.input_scale", "sliced_umx.0.cdaes.1.0.weight",
+                 "sliced_umx.0.cdaes.1.1.weight", "sliced_umx.0.cdaes.1.1.bias", "sliced_umx.0.cdaes.2.3.weight",
+                 "sliced_umx.0.cdaes.2.6.weight", "sliced_umx.0.cdaes.3.9.weight", "sliced_umx.0.cdaes.3.9.bias",
+                 "sliced_umx.1.cdaes.0.3.weight", "sliced_umx.2.cdaes.1.6.weight", "sliced_umx.33.cdaes.2.0.weight",
+                 "sliced_umx.69.cdaes.3.9.weight", "sliced_umx.1.input_scale", "sliced_umx.69.cdaes.0.7.bias"]
+    for tag, rt in (("realtime", True), ("offline", False)):
+        m = Unmix(cnorm(jag), realtime=rt)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        Xc = enc(x)
+        Yest, Ymask = m([c.clone() for c in Xc], return_masks=True)
+        with torch.no_grad():
+            Ytgt = enc(y_t)
+        mse = ComplexMSELossCriterion()(Yest, Ytgt)
+        msk = MaskSumLossCriterion()(Ymask)
+        (mse + msk).backward()
+        d[f"{tag}_mse"], d[f"{tag}_mask"] = float(mse), float(msk)
+        names, norms = [], []
+        for k, p_ in m.named_parameters():
+            names.append(k); norms.append(float(p_.grad.double().norm()))
+        d[f"{tag}_grad_norms"] = np.array(norms)
+        d["param_names"] = np.array(names)
+        for k in keep_keys:
+            d[f"{tag}_grad::{k}"] = dict(m.named_parameters())[k].grad.numpy()
+        rm = dict(m.named_buffers())
+        d[f"{tag}_running_mean::sliced_umx.1.cdaes.0.4"] = rm["sliced_umx.1.cdaes.0.4.running_mean"].numpy()
+        d[f"{tag}_running_var::sliced_umx.1.cdaes.0.4"] = rm["sliced_umx.1.cdaes.0.4.running_var"].numpy()
+        print("training step", tag, "mse", float(mse), "mask", float(msk))
+    np.savez_compressed(os.path.join(OUT, "training_step.npz"), **d)
+
     # ---- (9) dataset statistics: the reference's training.get_statistics on three seeded "tracks"
     # training.py pulls in packages that are absent offline; none of them is touched by get_statistics
     class _Stub(types.ModuleType):
