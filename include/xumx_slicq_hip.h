@@ -175,6 +175,30 @@ int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const floa
 int xsq_magnitude_stats(int nblocks, const int32_t* F, const int32_t* T, const float* X, int C, int S,
                         double* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training step (training.loop with train=True, training.py:34-112; BASELINE config 5) -------
+ * One handle owns the parameters, their gradients and the AdamW moments as flat fp32 pools in the
+ * xsq_model_create order (the reference's state_dict order), plus the GEMM-layout weights the
+ * forward needs (re-gathered on the device every step).
+ *   xsq_train_step: forward with BatchNorm on BATCH statistics (nn.BatchNorm2d.train(), running
+ *   statistics updated with momentum 0.1 when apply_update != 0), loss = ComplexMSE + MaskSum
+ *   (loss.py:37-96, SDR term off as in the published training), backward of every trainable tensor
+ *   (what loss.backward() at training.py:107 produces), AdamW update (training.py:391-393).
+ *     X        mix arena (2B channels, complex)      Yt   target arena (8B channels, complex)
+ *     wiener   0: mix-phase (realtime model)         1: differentiable Wiener-EM (offline model)
+ *     apply_update 0: gradients only (parameters and running statistics untouched)
+ *     loss_out HOST double[2]: complex-MSE term, mask-sum term (the step synchronises the stream,
+ *              as loss.item() at training.py:110 does)
+ *   xsq_train_read: what = 0 parameters, 1 gradients -> HOST float[nparams].                    */
+typedef struct xsq_train xsq_train;
+int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
+                     const float* params, int64_t nparams);
+int xsq_train_destroy(xsq_train* t);
+size_t xsq_train_workspace(const xsq_train* t, int B, int S, int wiener);      /* 0 on error */
+int xsq_train_step(xsq_train* t, const float* X, const float* Yt, int B, int S, int wiener,
+                   float lr, float weight_decay, int apply_update, double* loss_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int xsq_train_read(xsq_train* t, int what, float* host_out);
+
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on
  * its own launch stream.  xsq_profile_read synchronises the outstanding events and

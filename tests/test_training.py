@@ -14,7 +14,16 @@ def _inputs(n):
     return y_t.sum(0), y_t
 
 
-def _check(g, tag, mse, msk, grads, rtol):
+# One BatchNorm-2 pre-activation of block 32 / target 1 sits ON the ReLU kink for this fixture: -1.28e-6 in the
+# reference's fp32, -4.7e-7 in fp64 (test_fixture_has_a_relu_kink pins that).  Any other summation order can
+# land on the other side, which switches one of that group's 36 rows on or off: the gradients upstream of that
+# ReLU (layers 1-2 of the group and the block's whitening) then move by a few percent -- a subgradient choice,
+# not an error.  Those tensors get a loose bound for the HIP path; every other tensor keeps rtol.
+KINK = ("sliced_umx.32.input_", "sliced_umx.32.cdaes.1.0.", "sliced_umx.32.cdaes.1.1.", "sliced_umx.32.cdaes.1.3.",
+        "sliced_umx.32.cdaes.1.4.")
+
+
+def _check(g, tag, mse, msk, grads, rtol, kink_rtol=None):
     assert abs(mse - float(g[f"{tag}_mse"])) < 1e-4 * float(g[f"{tag}_mse"])
     assert abs(msk - float(g[f"{tag}_mask"])) < 1e-4 * float(g[f"{tag}_mask"])
     names = [str(k) for k in g["param_names"]]
@@ -22,14 +31,19 @@ def _check(g, tag, mse, msk, grads, rtol):
     worst = 0.0
     for k in names:
         got = float(grads[k].double().norm())
-        assert abs(got - norms[k]) <= rtol * norms[k] + 2e-7, (k, got, norms[k])
+        tol = kink_rtol if (kink_rtol and k.startswith(KINK)) else rtol
+        assert abs(got - norms[k]) <= tol * norms[k] + 2e-7, (k, got, norms[k])
     for key in g.files:
         if key.startswith(f"{tag}_grad::"):
             k = key.split("::", 1)[1]
             ref = torch.from_numpy(g[key])
             err = float((grads[k].cpu() - ref).abs().max())
             scale = float(ref.abs().max()) + 1e-12
-            worst = max(worst, err / scale)
+            if kink_rtol and k.startswith(KINK):
+                assert err <= kink_rtol * scale + 2e-7, (k, err, scale)
+                continue
+            if scale > 1e-6:
+                worst = max(worst, err / scale)
             # (with batch-statistics BN the loss is invariant to input_scale of single-bin blocks: those
             #  gradients are pure rounding noise around 1e-9, hence the absolute floor)
             assert err <= rtol * scale + 2e-7, (k, err, scale)
@@ -43,3 +57,83 @@ def test_oracle_training_gradients_match_reference(oracle_plan, seeded_sd, tag, 
     x, y_t = _inputs(int(g["n"]))
     loss, mse, msk, grads = oloss.training_gradients(oracle_plan, seeded_sd, x, y_t, causal=causal, wiener=wiener)
     _check(g, tag, mse, msk, grads, rtol=2e-3)
+
+
+def test_fixture_has_a_relu_kink(oracle_plan, seeded_sd):
+    """Pins the premise of KINK above on the oracle (block 32 only, fp32 and fp64)."""
+    import torch.nn.functional as F
+    from oracle import model as omodel
+    from oracle import slicqt as oslicqt
+    g = load_golden("training_step.npz")
+    x, _ = _inputs(int(g["n"]))
+    b, p = 32, "sliced_umx.32.cdaes.1."
+    Xb = oslicqt.forward(oracle_plan, x)[b]
+    for dt, bound in ((torch.float32, 5e-6), (torch.float64, 5e-6)):
+        sd = {k: v.to(dt) for k, v in seeded_sd.items() if k.startswith("sliced_umx.32.") and v.dtype.is_floating_point}
+        mag = omodel.abs_of_real_complex(Xb.to(dt))
+        B, C, Fb, S, T = mag.shape
+        xx = (mag.reshape(B, C, Fb, S * T) + sd["sliced_umx.32.input_mean"][None, None, :, None]) \
+            * sd["sliced_umx.32.input_scale"][None, None, :, None]
+        y = F.conv2d(F.pad(xx, (T - 1, 0)), sd[p + "0.weight"], stride=(1, T // 2))
+        y = F.conv2d(F.relu(omodel._bn(y, sd, p + "1", True)), sd[p + "3.weight"])
+        pre = omodel._bn(y, sd, p + "4", True).abs().flatten().sort().values
+        assert pre[0] < bound and pre[1] > 1e-4, pre[:3]
+
+
+def _trainer(realtime):
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.training import Trainer
+    sep = seeded_separator(realtime=realtime)
+    return sep, Trainer(sep.xumx_model, (sep.nsgt, sep.insgt, sep.cnorm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,realtime", [("realtime", True)])
+def test_hip_training_gradients_match_reference(tag, realtime):
+    """xsq_train_step (gradients only) vs the reference's loss.backward(): loss terms, the gradient norm of
+    every one of the 3500 trainable tensors and fifteen full gradient tensors."""
+    g = load_golden("training_step.npz")
+    x, y_t = _inputs(int(g["n"]))
+    sep, tr = _trainer(realtime)
+    before = tr.state_dict()
+    loss, mse, msk = tr.step(x, y_t, apply_update=False)
+    worst = _check(g, tag, mse, msk, tr.gradients(), rtol=2e-3, kink_rtol=0.15)
+    assert worst < 2e-3
+    after = tr.state_dict()
+    for k in before:      # gradients-only leaves parameters and running statistics alone
+        assert torch.equal(before[k], after[k]), k
+
+
+@pytest.mark.gpu
+def test_hip_training_step_updates_like_adamw():
+    """One full step: running statistics follow nn.BatchNorm2d.train() (reference fixture), the parameter
+    update equals torch.optim.AdamW(lr=1e-3, weight_decay=1e-5) applied to the same gradients, and a few
+    steps on one batch bring the loss down."""
+    g = load_golden("training_step.npz")
+    x, y_t = _inputs(int(g["n"]))
+    sep, tr = _trainer(True)
+    before = tr.state_dict()
+    loss0, _, _ = tr.step(x, y_t, apply_update=True)
+    grads = tr.gradients()
+    after = tr.state_dict()
+    k = "sliced_umx.1.cdaes.0.4"
+    assert np.allclose(after[k + ".running_mean"].numpy(), g[f"realtime_running_mean::{k}"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(after[k + ".running_var"].numpy(), g[f"realtime_running_var::{k}"], rtol=1e-4, atol=1e-7)
+    keys = ["sliced_umx.0.input_mean", "sliced_umx.0.cdaes.1.0.weight", "sliced_umx.1.cdaes.0.3.weight",
+            "sliced_umx.2.cdaes.1.6.weight", "sliced_umx.69.cdaes.3.9.weight", "sliced_umx.69.cdaes.0.7.bias",
+            "sliced_umx.33.cdaes.2.9.bias"]
+    ps = [torch.nn.Parameter(before[k_].clone()) for k_ in keys]
+    opt = torch.optim.AdamW(ps, lr=1e-3, weight_decay=1e-5)
+    for p, k_ in zip(ps, keys):
+        p.grad = grads[k_].clone()
+    opt.step()
+    for p, k_ in zip(ps, keys):
+        # (the first AdamW step moves every weight by ~lr * sign(g); tiny |g| next to eps = 1e-8 is where
+        #  fp32 rounding of the gradient shows, hence the absolute term)
+        assert torch.allclose(after[k_], p.detach(), rtol=1e-5, atol=2e-6), k_
+    losses = [loss0] + [tr.step(x, y_t)[0] for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    # the trained tensors load back into the inference module
+    tr.sync_to(sep.xumx_model)
+    est = sep(x[:1].cuda())
+    assert torch.isfinite(est).all()

@@ -65,6 +65,11 @@ _SIGS = {
     "xsq_loss_workspace": (C.c_size_t, [C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "xsq_loss_forward": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "xsq_magnitude_stats": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_train_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64]),
+    "xsq_train_destroy": (C.c_int, [_vp]),
+    "xsq_train_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int, C.c_int]),
+    "xsq_train_step": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_train_read": (C.c_int, [_vp, C.c_int, _vp]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),
     "xsq_profile_read": (C.c_int, [C.c_char_p, C.c_size_t, _vp, _vp, C.c_int]),

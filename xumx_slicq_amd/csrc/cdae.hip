@@ -23,39 +23,7 @@
 #include "plan.h"
 #include "prof.h"
 
-namespace xsq {
-
-static const int H1 = 50, H2 = 51, CS = 52;  // hidden sizes (model.py:92-93), padded channel stride
-static const int NT = 4;                      // targets
-
-struct CdaeBlockDev {
-    int F, T, hop, kf, F1, F2;
-    int cumF1, cumF2;     // sums over earlier blocks of F1, F2 (activation arena offsets)
-    int ld1, ld4;         // row lengths of the transposed layer-1 / layer-4 matrices (K padded to 16)
-    int64_t cum;          // sum over earlier blocks of F*T
-    int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
-    int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
-    int64_t s1[NT], s2[NT], s3[NT], b4[NT];   // float offsets of shift vectors (64) / output bias (2)
-};
-
-}  // namespace xsq
-
-struct xsq_model {
-    int causal = 0;
-    int nblocks = 0;
-    int64_t sumFT = 0;             // complex coefficients per channel-slice
-    std::vector<xsq::BlockHost> table;
-    std::vector<xsq::CdaeBlockDev> blocks;
-    int64_t sumF = 0, sumF1 = 0, sumF2 = 0;
-    xsq::CdaeBlockDev* d_blocks = nullptr;
-    float* d_pool = nullptr;       // all folded weights / shifts
-    float* d_mean = nullptr;       // (sumF) input_mean  (stored as -mean by the reference)
-    float* d_scale = nullptr;      // (sumF) input_scale (stored as 1/std)
-    int64_t* d_cum = nullptr;      // (nblocks+1) cumulative F*T, for the elementwise kernels
-    int* d_blockF = nullptr;       // (nblocks)
-    std::mutex mu;
-    std::map<std::tuple<int, int, int>, xsq::TileTable> tiles;   // (layer, B, S)
-};
+#include "cdae_api.h"
 
 namespace xsq {
 
@@ -107,19 +75,6 @@ struct CdaeGroup {
     int64_t cum;
 };
 
-struct CdaeArgs {
-    const CdaeBlockDev* blocks;
-    const float* pool;
-    const float* xin;     // whitened magnitude, arena layout (2B channels, real)
-    float* act1;          // (block, target, B, F1, T1, 52)
-    float* act2;          // (block, target, B, F2, T2, 52)
-    float* act3;          // (block, target, B, F1, T1, 52)
-    const float* X;       // mix coefficients (complex arena, 2B channels)
-    float* Y;             // estimates (complex arena, 8B channels, targets first)
-    float* masks;         // optional real arena (8B channels), nullptr to skip
-    int Bn, S, T1, T2, causal;
-};
-
 struct RowFT {
     const float* p;   // row base pointer (may be out of range for transposed convs; checked per load)
     int f, t;         // row's frequency / time coordinate
@@ -135,7 +90,7 @@ __device__ inline void split_row(int m, int Fo, int To, int& b, int& f, int& t) 
 
 // BN shift + ReLU, channels-last store (layers 1-3): column n and n+32 of 52 padded channels
 __device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0, int n, const f32x16& a0,
-                                                    const f32x16& a1) {
+                                                    const f32x16& a1, bool raw) {
     const float s0 = g.shift[n];
     const bool c1 = n + 32 < CS;
     const float s1 = c1 ? g.shift[n + 32] : 0.f;
@@ -144,8 +99,8 @@ __device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0
     for (int r = 0; r < 16; ++r) {
         if (row0 + acc_row(r) >= g.M) break;
         float* d = d0 + acc_row(r) * CS;
-        d[0] = fmaxf(a0[r] + s0, 0.f);
-        if (c1) d[32] = fmaxf(a1[r] + s1, 0.f);
+        d[0] = raw ? a0[r] : fmaxf(a0[r] + s0, 0.f);
+        if (c1) d[32] = raw ? a1[r] : fmaxf(a1[r] + s1, 0.f);
     }
 }
 
@@ -195,7 +150,7 @@ struct CdaeL1Op {
         return v;
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
     }
 };
 
@@ -231,7 +186,7 @@ struct CdaeL2Op {
         return *reinterpret_cast<const float4*>(r.p + (int64_t)df * g.Ti * CS + rem);
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
     }
 };
 
@@ -270,7 +225,7 @@ struct CdaeL3Op {
         return *reinterpret_cast<const float4*>(r.p - (int64_t)df * g.Ti * CS + rem);
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
     }
 };
 
@@ -544,6 +499,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
         XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); \
     } while (0)
     UP(Mo->d_pool, pool, float);
+    Mo->pool_floats = (int64_t)pool.size();
     UP(Mo->d_mean, mean, float);
     UP(Mo->d_scale, scale, float);
     UP(Mo->d_blocks, Mo->blocks, CdaeBlockDev);
@@ -572,6 +528,41 @@ size_t xsq_cdae_workspace(const xsq_model* Mo, int Bn, int S) {
            al((size_t)CS * Bn * T2 * 4 * Mo->sumF2 * 4) + 256;
 }
 
+}  // extern "C"
+
+namespace xsq {
+
+int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
+                          int Bn, int S, hipStream_t stream) {
+    const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
+    XSQ_PROF("magnitude_whiten", stream);
+    hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
+                       (const float4*)X, (float4*)xin, Mo->d_cum, Mo->d_blocks, mean, scale, Mo->nblocks, Bn * 2, S,
+                       total / 4);
+    return XSQ_OK;
+}
+
+int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream) {
+    TileTable tt;
+    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt);
+    if (rc) return rc;
+    switch (layer) {
+        case 1: { XSQ_PROF("cdae_l1_gemm", stream);
+            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL1Op{a}, tt.d_tiles, tt.ntiles); } break;
+        case 2: { XSQ_PROF("cdae_l2_gemm", stream);
+            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL2Op{a}, tt.d_tiles, tt.ntiles); } break;
+        case 3: { XSQ_PROF("cdae_l3_gemm", stream);
+            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL3Op{a}, tt.d_tiles, tt.ntiles); } break;
+        default: { XSQ_PROF("cdae_l4_gemm", stream);
+            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL4Op{a}, tt.d_tiles, tt.ntiles); } break;
+    }
+    return XSQ_OK;
+}
+
+}  // namespace xsq
+
+extern "C" {
+
 int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, float* masks, void* ws,
                      size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(Mo && X && Y && ws, "xsq_cdae_forward: null argument");
@@ -584,30 +575,12 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act1 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
-    const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
-    { XSQ_PROF("magnitude_whiten", stream);
-    hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
-                       (const float4*)X, (float4*)xin, Mo->d_cum, Mo->d_blocks, Mo->d_mean, Mo->d_scale,
-                       Mo->nblocks, Bn * 2, S, total / 4); }
-    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal};
-    TileTable tt;
-    int rc;
-    if ((rc = get_cdae_tiles(Mo, 1, Bn, S, &tt))) return rc;
-    { XSQ_PROF("cdae_l1_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL1Op{a}, tt.d_tiles, tt.ntiles); }
-    if ((rc = get_cdae_tiles(Mo, 2, Bn, S, &tt))) return rc;
-    { XSQ_PROF("cdae_l2_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL2Op{a}, tt.d_tiles, tt.ntiles); }
-    if ((rc = get_cdae_tiles(Mo, 3, Bn, S, &tt))) return rc;
-    { XSQ_PROF("cdae_l3_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL3Op{a}, tt.d_tiles, tt.ntiles); }
-    if ((rc = get_cdae_tiles(Mo, 4, Bn, S, &tt))) return rc;
-    { XSQ_PROF("cdae_l4_gemm", stream);
-    hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream,
-                       CdaeL4Op{a}, tt.d_tiles, tt.ntiles); }
+    cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream);
+    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0};
+    for (int layer = 1; layer <= 4; ++layer) {
+        const int rc = cdae_launch_layer(Mo, layer, a, stream);
+        if (rc) return rc;
+    }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

@@ -1,0 +1,69 @@
+// Shared declarations of the CDAE kernels (csrc/cdae.hip) for the training step (csrc/train.hip).
+#pragma once
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "plan.h"
+
+namespace xsq {
+
+static const int H1 = 50, H2 = 51, CS = 52;  // hidden sizes (model.py:92-93), padded channel stride
+static const int NT = 4;                      // targets
+
+struct CdaeBlockDev {
+    int F, T, hop, kf, F1, F2;
+    int cumF1, cumF2;     // sums over earlier blocks of F1, F2 (activation arena offsets)
+    int ld1, ld4;         // row lengths of the transposed layer-1 / layer-4 matrices (K padded to 16)
+    int64_t cum;          // sum over earlier blocks of F*T
+    int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
+    int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
+    int64_t s1[NT], s2[NT], s3[NT], b4[NT];   // float offsets of shift vectors (64) / output bias (2)
+};
+
+}  // namespace xsq
+
+struct xsq_model {
+    int causal = 0;
+    int nblocks = 0;
+    int64_t sumFT = 0;             // complex coefficients per channel-slice
+    std::vector<xsq::BlockHost> table;
+    std::vector<xsq::CdaeBlockDev> blocks;
+    int64_t sumF = 0, sumF1 = 0, sumF2 = 0;
+    xsq::CdaeBlockDev* d_blocks = nullptr;
+    float* d_pool = nullptr;       // all folded weights / shifts
+    int64_t pool_floats = 0;
+    float* d_mean = nullptr;       // (sumF) input_mean  (stored as -mean by the reference)
+    float* d_scale = nullptr;      // (sumF) input_scale (stored as 1/std)
+    int64_t* d_cum = nullptr;      // (nblocks+1) cumulative F*T, for the elementwise kernels
+    int* d_blockF = nullptr;       // (nblocks)
+    std::mutex mu;
+    std::map<std::tuple<int, int, int>, xsq::TileTable> tiles;   // (layer, B, S)
+};
+
+namespace xsq {
+
+struct CdaeArgs {
+    const CdaeBlockDev* blocks;
+    const float* pool;
+    const float* xin;     // whitened magnitude, arena layout (2B channels, real)
+    float* act1;          // (block, target, B, F1, T1, 52)
+    float* act2;          // (block, target, B, F2, T2, 52)
+    float* act3;          // (block, target, B, F1, T1, 52)
+    const float* X;       // mix coefficients (complex arena, 2B channels)
+    float* Y;             // estimates (complex arena, 8B channels, targets first)
+    float* masks;         // optional real arena (8B channels), nullptr to skip
+    int Bn, S, T1, T2, causal;
+    int raw;              // 1: layers 1-3 store the raw convolution (training: BatchNorm on batch statistics follows)
+};
+
+
+// one grouped launch of CDAE layer 1..4 over all blocks x targets (tile table cached per (layer, B, S))
+int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream);
+// |X| -> whitened magnitude with explicit mean / scale tables (sum_b F_b floats each)
+int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
+                          int Bn, int S, hipStream_t stream);
+
+}  // namespace xsq

@@ -1,0 +1,744 @@
+// Training step of the CDAE (BASELINE config 5; reference training.py:66-108) for gfx950.
+//
+//   forward   |X| whitening -> L1..L3 (MFMA engine of cdae.hip, raw outputs) each followed by BatchNorm on
+//             BATCH statistics + ReLU -> L4 + sigmoid -> masks, Y = mask * X [-> Wiener-EM, wiener.hip]
+//   loss      ComplexMSE over the 14 target combinations + MaskSum (loss.hip), and their gradients
+//   backward  direct-form kernels for every layer (weight, bias, BatchNorm affine, input whitening and
+//             data gradients) -- correctness first: one thread per output element, no tiling; the MFMA
+//             forms (the data gradients are the forward operators of the mirrored layers) are the next step
+//   update    AdamW (training.py:391-393: lr 1e-3, weight decay 1e-5) on the canonical parameter pool
+//
+// Parameters, gradients and optimizer moments live in ONE flat fp32 pool each, in the reference's
+// state_dict order (the order xsq_model_create consumes), so gradients compare key by key with the
+// reference's autograd and a checkpoint is a single copy.  The GEMM-layout weights the MFMA forward
+// needs are re-gathered from the pool on the device every step through an index map.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xumx_slicq_hip.h"
+#include "cdae_api.h"
+#include "prof.h"
+
+namespace xsq {
+
+static const float BN_EPS_F = 1e-5f;
+
+struct TrainGroup {     // one (block, target)
+    int block, tgt, F, T, hop, kf, F1, F2;
+    int cumF1, cumF2;
+    int C1, C2;         // real channel counts (50, 51)
+    int64_t cum, cumF;
+    int64_t p_w1, p_bn1, p_w2, p_bn2, p_w3, p_bn3, p_w4, p_b4;   // canonical pool offsets; bn: weight, bias, rm, rv
+    int64_t p_mean, p_scale;
+};
+
+struct TrainDims {
+    int Bn, S, T1, T2, causal;
+};
+
+__device__ __forceinline__ int64_t act1_off(const TrainGroup& g, const TrainDims& d) {
+    return (int64_t)CS * d.Bn * d.T1 * (4 * (int64_t)g.cumF1 + (int64_t)g.tgt * g.F1);
+}
+__device__ __forceinline__ int64_t act2_off(const TrainGroup& g, const TrainDims& d) {
+    return (int64_t)CS * d.Bn * d.T2 * (4 * (int64_t)g.cumF2 + (int64_t)g.tgt * g.F2);
+}
+// real arena (8B channels): element (tgt, b, c, f, tau) of the group's block
+__device__ __forceinline__ int64_t r8_idx(const TrainGroup& g, const TrainDims& d, int b, int c, int f, int64_t tau) {
+    const int64_t ST = (int64_t)d.S * g.T;
+    return (int64_t)d.Bn * 8 * d.S * g.cum + ((int64_t)((g.tgt * d.Bn + b) * 2 + c) * g.F + f) * ST + tau;
+}
+// real arena (2B channels): element (b, c, f, tau)
+__device__ __forceinline__ int64_t r2_idx(const TrainGroup& g, const TrainDims& d, int b, int c, int f, int64_t tau) {
+    const int64_t ST = (int64_t)d.S * g.T;
+    return (int64_t)d.Bn * 2 * d.S * g.cum + ((int64_t)(b * 2 + c) * g.F + f) * ST + tau;
+}
+
+// ---- gather: dst[i] = map[i] >= 0 ? src[map[i]] : 0 -----------------------------------------------
+__global__ void k_gather(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
+}
+
+// ---- BatchNorm (train mode) -----------------------------------------------------------------------
+// stats layout per (group, layer): mean[64] | invstd[64] | sum_g[64] | sum_gz[64]
+__device__ __forceinline__ float* bn_slot(float* stats, int group, int layer) { return stats + ((int64_t)group * 3 + layer) * 256; }
+
+// one workgroup per group: batch mean / biased variance per channel, running-stat update (momentum 0.1)
+__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ z, const TrainGroup* __restrict__ groups,
+                                                   TrainDims d, int layer, float* __restrict__ stats,
+                                                   float* __restrict__ pool, int update_running) {
+    const TrainGroup g = groups[blockIdx.x];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const float* zz = z + (layer == 1 ? act2_off(g, d) : act1_off(g, d));
+    const int C = layer == 1 ? g.C2 : g.C1;
+    const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int64_t m = rs; m < M; m += 4) { const double v = zz[m * CS + c]; s1 += v; s2 += v * v; }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        const double a = (r1[c] + r1[c + 64]) + (r1[c + 128] + r1[c + 192]);
+        const double b = (r2[c] + r2[c + 64]) + (r2[c + 128] + r2[c + 192]);
+        const double mean = a / (double)M;
+        double var = b / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float* st = bn_slot(stats, blockIdx.x, layer);
+        st[c] = (float)mean;
+        st[64 + c] = (float)(1.0 / sqrt(var + (double)BN_EPS_F));
+        if (update_running) {
+            const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+            float* rm = pool + pb + 2 * C;
+            float* rv = pool + pb + 3 * C;
+            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            rm[c] = (float)(0.9 * (double)rm[c] + 0.1 * mean);
+            rv[c] = (float)(0.9 * (double)rv[c] + 0.1 * unbiased);
+        }
+    }
+}
+
+// a = relu((z - mean) * invstd * gamma + beta); pad channels -> 0.  grid (ceil(M*52/256), groups)
+__global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ z, float* __restrict__ a,
+                                                        const TrainGroup* __restrict__ groups, TrainDims d, int layer,
+                                                        const float* __restrict__ stats, const float* __restrict__ pool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * CS) return;
+    const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
+    const int c = (int)(i % CS);
+    const int C = layer == 1 ? g.C2 : g.C1;
+    float v = 0.f;
+    if (c < C) {
+        const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
+        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+        v = fmaxf((z[off + i] - st[c]) * st[64 + c] * pool[pb + c] + pool[pb + C + c], 0.f);
+    }
+    a[off + i] = v;
+}
+
+// backward, step 1: per channel sum(g_bn) and sum(g_bn * zhat), g_bn = g_a * [a > 0]; writes the affine
+// gradients into the gradient pool.  One workgroup per group.
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ z, const float* __restrict__ a,
+                                                        const float* __restrict__ ga, const TrainGroup* __restrict__ groups,
+                                                        TrainDims d, int layer, float* __restrict__ stats,
+                                                        float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.x];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
+    const int C = layer == 1 ? g.C2 : g.C1;
+    const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    float* st = bn_slot(stats, blockIdx.x, layer);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float mean = st[c], inv = st[64 + c];
+        for (int64_t m = rs; m < M; m += 4) {
+            const int64_t i = off + m * CS + c;
+            const float gb = a[i] > 0.f ? ga[i] : 0.f;
+            s1 += gb;
+            s2 += (double)gb * (double)((z[i] - mean) * inv);
+        }
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        const double sg = (r1[c] + r1[c + 64]) + (r1[c + 128] + r1[c + 192]);
+        const double sgz = (r2[c] + r2[c + 64]) + (r2[c + 128] + r2[c + 192]);
+        st[128 + c] = (float)(sg / (double)M);
+        st[192 + c] = (float)(sgz / (double)M);
+        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+        gpool[pb + c] = (float)sgz;        // d gamma
+        gpool[pb + C + c] = (float)sg;     // d beta
+    }
+}
+
+// backward, step 2 (in place on ga): g_z = gamma * invstd * (g_bn - mean(g_bn) - zhat * mean(g_bn * zhat))
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ z, const float* __restrict__ a,
+                                                       float* __restrict__ ga, const TrainGroup* __restrict__ groups,
+                                                       TrainDims d, int layer, const float* __restrict__ stats,
+                                                       const float* __restrict__ pool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * CS) return;
+    const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
+    const int c = (int)(i % CS);
+    const int C = layer == 1 ? g.C2 : g.C1;
+    float v = 0.f;
+    if (c < C) {
+        const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
+        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+        const float zh = (z[off + i] - st[c]) * st[64 + c];
+        const float gb = a[off + i] > 0.f ? ga[off + i] : 0.f;
+        v = pool[pb + c] * st[64 + c] * (gb - st[128 + c] - zh * st[192 + c]);
+    }
+    ga[off + i] = v;
+}
+
+// ---- loss gradients ---------------------------------------------------------------------------------
+// grid (ceil(per-target complex floats / 256), nblocks): gY_j = (8 e_j + 6 s1) / (14 * n_b * nblocks);
+// the mask-sum gradient 2 (sum_j m_j - 1) / (n'_b * nblocks) is written to gM (same for the 4 targets).
+struct BlockGeo { int F, T; int64_t cum; };
+__global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ Y, const float* __restrict__ Yt,
+                                                   const float* __restrict__ masks, float* __restrict__ gY,
+                                                   float* __restrict__ gM, const BlockGeo* __restrict__ geo, int nblocks,
+                                                   int Bn, int S) {
+    const BlockGeo b = geo[blockIdx.y];
+    const int64_t per_r = (int64_t)Bn * 2 * b.F * S * b.T;     // real elements per target
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // float index in the per-target complex sub-arena
+    if (i >= 2 * per_r) return;
+    const int64_t base_c = 2 * (int64_t)Bn * 8 * S * b.cum, base_r = (int64_t)Bn * 8 * S * b.cum;
+    float e[4], s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e[j] = Y[base_c + j * 2 * per_r + i] - Yt[base_c + j * 2 * per_r + i]; s1 += e[j]; }
+    const float cb = 1.f / (14.f * (float)(2 * per_r) * (float)nblocks);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gY[base_c + j * 2 * per_r + i] = (8.f * e[j] + 6.f * s1) * cb;
+    if (i < per_r) {
+        float sm = -1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += masks[base_r + j * per_r + i];
+        const float gm = 2.f * sm / ((float)per_r * (float)nblocks);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gM[base_r + j * per_r + i] = gm;
+    }
+}
+
+// g_p4 = (Re(conj(X) * gY0) + gM) * m * (1 - m), in place on gM.  grid (ceil(per-target reals/256), groups)
+__global__ __launch_bounds__(256) void k_mask_bwd(const float2* __restrict__ X, const float2* __restrict__ gY0,
+                                                   const float* __restrict__ masks, float* __restrict__ gM,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t ST = (int64_t)d.S * g.T;
+    const int64_t per = (int64_t)d.Bn * 2 * g.F * ST;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int64_t yi = (int64_t)d.Bn * 8 * d.S * g.cum + (int64_t)g.tgt * per + i;
+    const int64_t xi = (int64_t)d.Bn * 2 * d.S * g.cum + i;
+    const float2 x = X[xi], gy = gY0[yi];
+    const float m = masks[yi];
+    gM[yi] = (x.x * gy.x + x.y * gy.y + gM[yi]) * m * (1.f - m);
+}
+
+// ---- layer 4 backward ---------------------------------------------------------------------------------
+// bias: one workgroup per group, both output channels
+__global__ __launch_bounds__(256) void k_l4_bias_grad(const float* __restrict__ gp4, const TrainGroup* __restrict__ groups,
+                                                       TrainDims d, float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.x];
+    const int64_t ST = (int64_t)d.S * g.T, n = (int64_t)g.F * ST;
+    double s[2] = {0.0, 0.0};
+    for (int b = 0; b < d.Bn; ++b)
+        for (int c = 0; c < 2; ++c) {
+            const float* p = gp4 + r8_idx(g, d, b, c, 0, 0);
+            for (int64_t i = threadIdx.x; i < n; i += 256) s[c] += p[i];
+        }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s[0]; red[1][threadIdx.x] = s[1];
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) gpool[g.p_b4 + threadIdx.x] = (float)red[threadIdx.x][0];
+}
+
+// weight: thread per element of w4 (in=50, out=2, kf, W):  sum_{b,f3,t3} a3[b,f3,t3,c3] * gp4[b,c,f3+df,t3*hop+dt]
+__global__ __launch_bounds__(256) void k_l4_wgrad(const float* __restrict__ a3, const float* __restrict__ gp4,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d,
+                                                   float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.C1 * 2 * g.kf * g.T) return;
+    const int dt = e % g.T, df = (e / g.T) % g.kf, c = (e / (g.T * g.kf)) % 2, c3 = e / (g.T * g.kf * 2);
+    const float* A = a3 + act1_off(g, d);
+    const int64_t ST = (int64_t)d.S * g.T;
+    float acc = 0.f;
+    for (int b = 0; b < d.Bn; ++b)
+        for (int f3 = 0; f3 < g.F1; ++f3) {
+            const float* gp = gp4 + r8_idx(g, d, b, c, f3 + df, 0);
+            const float* ar = A + ((int64_t)(b * g.F1 + f3) * d.T1) * CS + c3;
+            for (int t3 = 0; t3 < d.T1; ++t3) {
+                const int64_t tau = (int64_t)t3 * g.hop + dt;
+                if (tau < ST) acc += ar[(int64_t)t3 * CS] * gp[tau];
+            }
+        }
+    gpool[g.p_w4 + e] = acc;
+}
+
+// data: thread per (row (b,f3,t3), c3):  sum_{c,df,dt} w4[c3,c,df,dt] * gp4[b,c,f3+df,t3*hop+dt]
+__global__ __launch_bounds__(256) void k_l4_dgrad(const float* __restrict__ gp4, const float* __restrict__ pool,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga3) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t M = (int64_t)d.Bn * g.F1 * d.T1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * CS) return;
+    const int c3 = (int)(i % CS);
+    const int64_t m = i / CS;
+    float acc = 0.f;
+    if (c3 < g.C1) {
+        const int t3 = (int)(m % d.T1), f3 = (int)((m / d.T1) % g.F1), b = (int)(m / ((int64_t)d.T1 * g.F1));
+        const int64_t ST = (int64_t)d.S * g.T;
+        const float* w = pool + g.p_w4 + (int64_t)c3 * 2 * g.kf * g.T;
+        for (int c = 0; c < 2; ++c)
+            for (int df = 0; df < g.kf; ++df) {
+                const float* gp = gp4 + r8_idx(g, d, b, c, f3 + df, (int64_t)t3 * g.hop);
+                const float* ww = w + (int64_t)(c * g.kf + df) * g.T;
+                const int64_t lim = ST - (int64_t)t3 * g.hop;          // causal model: the crop cuts the last window
+                const int n = lim < g.T ? (int)lim : g.T;
+                for (int dt = 0; dt < n; ++dt) acc += ww[dt] * gp[dt];
+            }
+    }
+    ga3[act1_off(g, d) + i] = acc;
+}
+
+// ---- layer 3 backward (ConvTranspose2d 51 -> 50, (kf, 4)) -----------------------------------------------
+// z3[b,f3,t3,c3] = sum w3[c2,c3,df,dt] a2[b,f3-df,t3-dt,c2]
+__global__ __launch_bounds__(256) void k_l3_wgrad(const float* __restrict__ a2, const float* __restrict__ gz3,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.C2 * g.C1 * g.kf * 4) return;
+    const int dt = e % 4, df = (e / 4) % g.kf, c3 = (e / (4 * g.kf)) % g.C1, c2 = e / (4 * g.kf * g.C1);
+    const float* A = a2 + act2_off(g, d);
+    const float* G = gz3 + act1_off(g, d);
+    float acc = 0.f;
+    for (int b = 0; b < d.Bn; ++b)
+        for (int f2 = 0; f2 < g.F2; ++f2) {
+            const float* ar = A + ((int64_t)(b * g.F2 + f2) * d.T2) * CS + c2;
+            const float* gr = G + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + dt) * CS + c3;
+            for (int t2 = 0; t2 < d.T2; ++t2) acc += ar[(int64_t)t2 * CS] * gr[(int64_t)t2 * CS];
+        }
+    gpool[g.p_w3 + e] = acc;
+}
+
+// ga2[b,f2,t2,c2] = sum_{c3,df,dt} w3[c2,c3,df,dt] gz3[b,f2+df,t2+dt,c3]
+__global__ __launch_bounds__(256) void k_l3_dgrad(const float* __restrict__ gz3, const float* __restrict__ pool,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga2) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t M = (int64_t)d.Bn * g.F2 * d.T2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * CS) return;
+    const int c2 = (int)(i % CS);
+    const int64_t m = i / CS;
+    float acc = 0.f;
+    if (c2 < g.C2) {
+        const int t2 = (int)(m % d.T2), f2 = (int)((m / d.T2) % g.F2), b = (int)(m / ((int64_t)d.T2 * g.F2));
+        const float* G = gz3 + act1_off(g, d);
+        const float* w = pool + g.p_w3 + (int64_t)c2 * g.C1 * g.kf * 4;
+        for (int df = 0; df < g.kf; ++df)
+            for (int dt = 0; dt < 4; ++dt) {
+                const float* gr = G + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + t2 + dt) * CS;
+                for (int c3 = 0; c3 < g.C1; ++c3) acc += w[(c3 * g.kf + df) * 4 + dt] * gr[c3];
+            }
+    }
+    ga2[act2_off(g, d) + i] = acc;
+}
+
+// ---- layer 2 backward (Conv2d 50 -> 51, (kf, 4)) ----------------------------------------------------------
+// z2[b,f2,t2,c2] = sum w2[c2,c1,df,dt] a1[b,f2+df,t2+dt,c1]
+__global__ __launch_bounds__(256) void k_l2_wgrad(const float* __restrict__ a1, const float* __restrict__ gz2,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.C2 * g.C1 * g.kf * 4) return;
+    const int dt = e % 4, df = (e / 4) % g.kf, c1 = (e / (4 * g.kf)) % g.C1, c2 = e / (4 * g.kf * g.C1);
+    const float* A = a1 + act1_off(g, d);
+    const float* G = gz2 + act2_off(g, d);
+    float acc = 0.f;
+    for (int b = 0; b < d.Bn; ++b)
+        for (int f2 = 0; f2 < g.F2; ++f2) {
+            const float* gr = G + ((int64_t)(b * g.F2 + f2) * d.T2) * CS + c2;
+            const float* ar = A + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + dt) * CS + c1;
+            for (int t2 = 0; t2 < d.T2; ++t2) acc += gr[(int64_t)t2 * CS] * ar[(int64_t)t2 * CS];
+        }
+    gpool[g.p_w2 + e] = acc;
+}
+
+// ga1[b,f1,t1,c1] = sum_{c2,df,dt} w2[c2,c1,df,dt] gz2[b,f1-df,t1-dt,c2]   (zero outside)
+__global__ __launch_bounds__(256) void k_l2_dgrad(const float* __restrict__ gz2, const float* __restrict__ pool,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga1) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t M = (int64_t)d.Bn * g.F1 * d.T1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * CS) return;
+    const int c1 = (int)(i % CS);
+    const int64_t m = i / CS;
+    float acc = 0.f;
+    if (c1 < g.C1) {
+        const int t1 = (int)(m % d.T1), f1 = (int)((m / d.T1) % g.F1), b = (int)(m / ((int64_t)d.T1 * g.F1));
+        const float* G = gz2 + act2_off(g, d);
+        const float* w = pool + g.p_w2;
+        for (int df = 0; df < g.kf; ++df) {
+            const int f2 = f1 - df;
+            if (f2 < 0 || f2 >= g.F2) continue;
+            for (int dt = 0; dt < 4; ++dt) {
+                const int t2 = t1 - dt;
+                if (t2 < 0 || t2 >= d.T2) continue;
+                const float* gr = G + ((int64_t)(b * g.F2 + f2) * d.T2 + t2) * CS;
+                for (int c2 = 0; c2 < g.C2; ++c2) acc += w[((c2 * g.C1 + c1) * g.kf + df) * 4 + dt] * gr[c2];
+            }
+        }
+    }
+    ga1[act1_off(g, d) + i] = acc;
+}
+
+// ---- layer 1 backward (Conv2d 2 -> 50, (kf, W), stride hop; causal: left pad W-1) ---------------------------
+__global__ __launch_bounds__(256) void k_l1_wgrad(const float* __restrict__ xin, const float* __restrict__ gz1,
+                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.C1 * 2 * g.kf * g.T) return;
+    const int dt = e % g.T, df = (e / g.T) % g.kf, ci = (e / (g.T * g.kf)) % 2, co = e / (g.T * g.kf * 2);
+    const float* G = gz1 + act1_off(g, d);
+    const int pad = d.causal ? g.T - 1 : 0;
+    float acc = 0.f;
+    for (int b = 0; b < d.Bn; ++b)
+        for (int f1 = 0; f1 < g.F1; ++f1) {
+            const float* xr = xin + r2_idx(g, d, b, ci, f1 + df, 0);
+            const float* gr = G + ((int64_t)(b * g.F1 + f1) * d.T1) * CS + co;
+            for (int t1 = 0; t1 < d.T1; ++t1) {
+                const int64_t tau = (int64_t)t1 * g.hop + dt - pad;
+                if (tau >= 0) acc += gr[(int64_t)t1 * CS] * xr[tau];
+            }
+        }
+    gpool[g.p_w1 + e] = acc;
+}
+
+// input whitening: xin = (|X| + mean_f) * scale_f.  One workgroup per (block, f): g_xin on the fly (sum over the 4
+// targets of the layer-1 data gradient), reduced to d mean_f = sum g_xin * scale_f, d scale_f = sum g_xin * xin / scale_f.
+// `groups4` points at the block's first group (target 0); the 4 targets are consecutive.
+__global__ __launch_bounds__(256) void k_l1_input_grad(const float* __restrict__ xin, const float* __restrict__ gz1,
+                                                        const float* __restrict__ pool, const TrainGroup* __restrict__ groups,
+                                                        const int2* __restrict__ rows, TrainDims d, float* __restrict__ gpool) {
+    const int2 r = rows[blockIdx.x];           // (first group of the block, f)
+    const TrainGroup g0 = groups[r.x];
+    const int f = r.y;
+    const int64_t ST = (int64_t)d.S * g0.T;
+    const int pad = d.causal ? g0.T - 1 : 0;
+    const float sc = pool[g0.p_scale + f];
+    double sm = 0.0, ss = 0.0;
+    for (int64_t q = threadIdx.x; q < (int64_t)d.Bn * 2 * ST; q += 256) {
+        const int64_t tau = q % ST;
+        const int ci = (int)((q / ST) % 2), b = (int)(q / (2 * ST));
+        // windows t1 that contain tau: tau + pad - t1*hop in [0, W)
+        const int64_t tp = tau + pad;
+        int t_hi = (int)(tp / g0.hop);
+        if (t_hi > d.T1 - 1) t_hi = d.T1 - 1;
+        int t_lo = (int)((tp - g0.T + g0.hop) / g0.hop);       // ceil((tp - W + 1) / hop)
+        if (tp - g0.T + 1 <= 0) t_lo = 0;
+        float gx = 0.f;
+        for (int tg = 0; tg < 4; ++tg) {
+            const TrainGroup g = groups[r.x + tg];
+            const float* G = gz1 + act1_off(g, d);
+            const float* w = pool + g.p_w1;
+            for (int df = 0; df < g.kf; ++df) {
+                const int f1 = f - df;
+                if (f1 < 0 || f1 >= g.F1) continue;
+                for (int t1 = t_lo; t1 <= t_hi; ++t1) {
+                    const int dt = (int)(tp - (int64_t)t1 * g.hop);
+                    if (dt < 0 || dt >= g.T) continue;
+                    const float* gr = G + ((int64_t)(b * g.F1 + f1) * d.T1 + t1) * CS;
+                    for (int co = 0; co < g.C1; ++co) gx += w[((co * 2 + ci) * g.kf + df) * g.T + dt] * gr[co];
+                }
+            }
+        }
+        const float xv = xin[r2_idx(g0, d, b, ci, f, tau)];
+        sm += (double)gx * sc;
+        ss += (double)gx * (double)(xv / sc);
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = sm; red[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { gpool[g0.p_mean + f] = (float)red[0][0]; gpool[g0.p_scale + f] = (float)red[1][0]; }
+}
+
+// ---- AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments) ----------------------
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        const unsigned char* __restrict__ trainable, int64_t n, float lr, float wd, float b1, float b2,
+                        float eps, float bc1, float bc2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !trainable[i]) return;
+    float w = p[i] * (1.f - lr * wd);
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+}
+
+}  // namespace xsq
+
+// =====================================================================================================
+struct xsq_train {
+    xsq_model* model = nullptr;             // GEMM-layout forward (tables, tile caches); its pool is re-gathered every step
+    int nblocks = 0, causal = 0, ngroups = 0;
+    int64_t nparams = 0, pool_floats = 0, sumF = 0;
+    std::vector<xsq::TrainGroup> groups;
+    xsq::TrainGroup* d_groups = nullptr;
+    xsq::BlockGeo* d_geo = nullptr;
+    int2* d_rows = nullptr;                 // (first group, f) per whitening row
+    float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr;
+    unsigned char* d_trainable = nullptr;
+    int *d_map_pool = nullptr, *d_map_mean = nullptr, *d_map_scale = nullptr;
+    int64_t step = 0;
+    std::vector<int32_t> Fv, Tv;
+};
+
+using namespace xsq;
+
+static inline size_t alt(size_t x) { return (x + 255) / 256 * 256; }
+static int kf_of_t(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }
+
+extern "C" {
+
+int xsq_train_destroy(xsq_train* T) {
+    if (!T) return XSQ_OK;
+    if (T->model) xsq_model_destroy(T->model);
+    (void)hipFree(T->d_groups); (void)hipFree(T->d_geo); (void)hipFree(T->d_rows); (void)hipFree(T->d_params);
+    (void)hipFree(T->d_grads); (void)hipFree(T->d_m); (void)hipFree(T->d_v); (void)hipFree(T->d_trainable);
+    (void)hipFree(T->d_map_pool); (void)hipFree(T->d_map_mean); (void)hipFree(T->d_map_scale);
+    delete T;
+    return XSQ_OK;
+}
+
+static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32_t* T, int causal, const float* params,
+                       int64_t nparams) {
+    int rc = xsq_model_create(&Tr->model, nblocks, F, T, causal, params, nparams);
+    if (rc) return rc;
+    xsq_model* Mo = Tr->model;
+    Tr->nblocks = nblocks; Tr->causal = causal ? 1 : 0; Tr->nparams = nparams;
+    Tr->Fv.assign(F, F + nblocks); Tr->Tv.assign(T, T + nblocks);
+    // walk the canonical order once more: offsets of every tensor, trainable mask, gather maps
+    std::vector<unsigned char> trainable((size_t)nparams, 1);
+    std::vector<BlockGeo> geo;
+    std::vector<int2> rows;
+    std::vector<int> map_mean, map_scale;
+    int64_t p = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const CdaeBlockDev& cb = Mo->blocks[b];
+        const int kf = cb.kf, W = cb.T;
+        geo.push_back(BlockGeo{cb.F, cb.T, cb.cum});
+        const int64_t p_mean = p, p_scale = p + cb.F;
+        for (int f = 0; f < cb.F; ++f) { map_mean.push_back((int)(p_mean + f)); map_scale.push_back((int)(p_scale + f)); }
+        for (int f = 0; f < cb.F; ++f) rows.push_back(make_int2((int)Tr->groups.size(), f));
+        p += 2 * cb.F;
+        for (int t = 0; t < NT; ++t) {
+            TrainGroup g;
+            memset(&g, 0, sizeof(g));
+            g.block = b; g.tgt = t; g.F = cb.F; g.T = cb.T; g.hop = cb.hop; g.kf = kf; g.F1 = cb.F1; g.F2 = cb.F2;
+            g.cumF1 = cb.cumF1; g.cumF2 = cb.cumF2; g.C1 = H1; g.C2 = H2; g.cum = cb.cum; g.cumF = cb.cumF;
+            g.p_mean = p_mean; g.p_scale = p_scale;
+            g.p_w1 = p; p += (int64_t)H1 * 2 * kf * W;
+            g.p_bn1 = p; for (int64_t i = p + 2 * H1; i < p + 4 * H1; ++i) trainable[i] = 0; p += 4 * H1;
+            g.p_w2 = p; p += (int64_t)H2 * H1 * kf * 4;
+            g.p_bn2 = p; for (int64_t i = p + 2 * H2; i < p + 4 * H2; ++i) trainable[i] = 0; p += 4 * H2;
+            g.p_w3 = p; p += (int64_t)H2 * H1 * kf * 4;
+            g.p_bn3 = p; for (int64_t i = p + 2 * H1; i < p + 4 * H1; ++i) trainable[i] = 0; p += 4 * H1;
+            g.p_w4 = p; p += (int64_t)H1 * 2 * kf * W;
+            g.p_b4 = p; p += 2;
+            Tr->groups.push_back(g);
+        }
+    }
+    XSQ_REQUIRE(p == nparams, "xsq_train_create: parameter walk mismatch");
+    Tr->ngroups = (int)Tr->groups.size();
+    Tr->sumF = Mo->sumF;
+    // GEMM-pool gather map: the same placement as xsq_model_create, without the BatchNorm fold
+    const int64_t extent = Mo->pool_floats;
+    Tr->pool_floats = extent;
+    std::vector<int> map((size_t)extent, -1);
+    for (int b = 0; b < nblocks; ++b) {
+        const CdaeBlockDev& cb = Mo->blocks[b];
+        const int kf = cb.kf, W = cb.T, hop = cb.hop;
+        const int K1 = 2 * kf * W, K2 = kf * 4 * CS;
+        for (int t = 0; t < NT; ++t) {
+            const TrainGroup& g = Tr->groups[b * 4 + t];
+            for (int co = 0; co < H1; ++co)
+                for (int k = 0; k < K1; ++k) map[cb.w1[t] + (int64_t)co * cb.ld1 + k] = (int)(g.p_w1 + (int64_t)co * K1 + k);
+            for (int co = 0; co < H2; ++co)
+                for (int ci = 0; ci < H1; ++ci)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            map[cb.w2[t] + (int64_t)co * K2 + (df * 4 + dt) * CS + ci] =
+                                (int)(g.p_w2 + (((int64_t)co * H1 + ci) * kf + df) * 4 + dt);
+            for (int co = 0; co < H1; ++co)
+                for (int ci = 0; ci < H2; ++ci)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            map[cb.w3[t] + (int64_t)co * K2 + (df * 4 + (3 - dt)) * CS + ci] =
+                                (int)(g.p_w3 + (((int64_t)ci * H1 + co) * kf + df) * 4 + dt);
+            for (int ci = 0; ci < H1; ++ci)
+                for (int c = 0; c < 2; ++c)
+                    for (int df = 0; df < kf; ++df)
+                        for (int tap = 0; tap < 2; ++tap)
+                            for (int dt = 0; dt < hop; ++dt)
+                                map[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + tap) * CS + ci] =
+                                    (int)(g.p_w4 + (((int64_t)ci * 2 + c) * kf + df) * W + dt + tap * hop);
+            map[cb.b4[t]] = (int)g.p_b4;
+            map[cb.b4[t] + 1] = (int)(g.p_b4 + 1);
+        }
+    }
+#define UPV(dst, vec, TY)                                                                         \
+    do {                                                                                          \
+        XSQ_HIP(hipMalloc(&(dst), (vec).size() * sizeof(TY)));                                    \
+        XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(TY), hipMemcpyHostToDevice)); \
+    } while (0)
+    UPV(Tr->d_groups, Tr->groups, TrainGroup);
+    UPV(Tr->d_geo, geo, BlockGeo);
+    UPV(Tr->d_rows, rows, int2);
+    UPV(Tr->d_trainable, trainable, unsigned char);
+    UPV(Tr->d_map_pool, map, int);
+    UPV(Tr->d_map_mean, map_mean, int);
+    UPV(Tr->d_map_scale, map_scale, int);
+#undef UPV
+    XSQ_HIP(hipMalloc(&Tr->d_params, (size_t)nparams * 4));
+    XSQ_HIP(hipMemcpy(Tr->d_params, params, (size_t)nparams * 4, hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&Tr->d_grads, (size_t)nparams * 4));
+    XSQ_HIP(hipMalloc(&Tr->d_m, (size_t)nparams * 4));
+    XSQ_HIP(hipMalloc(&Tr->d_v, (size_t)nparams * 4));
+    XSQ_HIP(hipMemset(Tr->d_grads, 0, (size_t)nparams * 4));
+    XSQ_HIP(hipMemset(Tr->d_m, 0, (size_t)nparams * 4));
+    XSQ_HIP(hipMemset(Tr->d_v, 0, (size_t)nparams * 4));
+    return XSQ_OK;
+}
+
+int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32_t* T, int causal, const float* params,
+                     int64_t nparams) {
+    XSQ_REQUIRE(out && F && T && params && nblocks > 0, "xsq_train_create: null argument");
+    xsq_train* Tr = new xsq_train();
+    const int rc = train_build(Tr, nblocks, F, T, causal, params, nparams);
+    if (rc) { xsq_train_destroy(Tr); return rc; }
+    *out = Tr;
+    return XSQ_OK;
+}
+
+int xsq_train_read(xsq_train* Tr, int what, float* host_out) {
+    XSQ_REQUIRE(Tr && host_out && what >= 0 && what <= 1, "xsq_train_read: bad argument");
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpy(host_out, what == 0 ? Tr->d_params : Tr->d_grads, (size_t)Tr->nparams * 4, hipMemcpyDeviceToHost));
+    return XSQ_OK;
+}
+
+// workspace (floats): xin | z1 a1 g1 | z2 a2 g2 | z3 a3 g3 | masks gM | Y gY [Y0] | bn stats | mean scale | loss
+size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
+    if (!Tr || Bn <= 0 || S < 3) return 0;
+    const xsq_model* Mo = Tr->model;
+    const int64_t T1 = Tr->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
+    const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
+    size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
+    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4);
+    b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
+    if (wiener) b += 2 * xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000) + 4096;
+    return b;
+}
+
+// One step.  X: mix arena (2B ch), Yt: target arena (8B ch).  apply_update = 0 leaves the parameters untouched
+// (gradients stay readable through xsq_train_read).  loss_out: HOST double[2] (complex MSE, mask sum).
+int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S, int wiener, float lr, float wd,
+                   int apply_update, double* loss_out, void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(Tr && X && Yt && ws && loss_out, "xsq_train_step: null argument");
+    XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_train_step: B=%d S=%d", Bn, S);
+    XSQ_REQUIRE(!wiener, "xsq_train_step: the Wiener-EM backward is not built yet (train the mix-phase model)");
+    XSQ_REQUIRE(ws_bytes >= xsq_train_workspace(Tr, Bn, S, wiener), "xsq_train_step: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    xsq_model* Mo = Tr->model;
+    const int T1 = Tr->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    const TrainDims d{Bn, S, T1, T2, Tr->causal};
+    const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
+    const size_t na1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, na2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
+    char* w = (char*)ws;
+    auto take = [&](size_t bytes) { void* p = w; w += alt(bytes); return p; };
+    float* xin = (float*)take(n2 * 4);
+    float *z1 = (float*)take(na1 * 4), *a1 = (float*)take(na1 * 4), *g1 = (float*)take(na1 * 4);
+    float *z2 = (float*)take(na2 * 4), *a2 = (float*)take(na2 * 4), *g2 = (float*)take(na2 * 4);
+    float *z3 = (float*)take(na1 * 4), *a3 = (float*)take(na1 * 4), *g3 = (float*)take(na1 * 4);
+    float *masks = (float*)take(n8 * 4), *gM = (float*)take(n8 * 4);
+    float *Y = (float*)take(n8 * 8), *gY = (float*)take(n8 * 8);
+    float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
+    float *mean = (float*)take((size_t)Tr->sumF * 4), *scale = (float*)take((size_t)Tr->sumF * 4);
+    double* d_loss = (double*)take((size_t)Tr->nblocks * 16);
+    void* loss_ws = w;
+    const size_t loss_ws_bytes = xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S);
+
+    auto grid1 = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    // ---- parameters -> GEMM layouts -------------------------------------------------------------
+    hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_pool, Mo->d_pool, Tr->pool_floats);
+    hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_mean, mean, Tr->sumF);
+    hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_scale, scale, Tr->sumF);
+    // ---- forward ----------------------------------------------------------------------------------
+    int rc;
+    cdae_launch_magnitude(Mo, X, xin, mean, scale, Bn, S, stream);
+    int64_t maxM1 = 0, maxM2 = 0, maxP = 0, maxW14 = 0, maxW23 = 0;
+    for (const TrainGroup& g : Tr->groups) {
+        maxM1 = std::max<int64_t>(maxM1, (int64_t)Bn * g.F1 * T1 * CS);
+        maxM2 = std::max<int64_t>(maxM2, (int64_t)Bn * g.F2 * T2 * CS);
+        maxP = std::max<int64_t>(maxP, (int64_t)Bn * 2 * g.F * S * g.T);
+        maxW14 = std::max<int64_t>(maxW14, (int64_t)H1 * 2 * g.kf * g.T);
+        maxW23 = std::max<int64_t>(maxW23, (int64_t)H2 * H1 * g.kf * 4);
+    }
+    const unsigned G = (unsigned)Tr->ngroups;
+    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1};
+    if ((rc = cdae_launch_layer(Mo, 1, a, stream))) return rc;                       // z1
+    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z1, Tr->d_groups, d, 0, stats, Tr->d_params, apply_update);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, Tr->d_groups, d, 0, stats, Tr->d_params);
+    a.act1 = a1; a.act2 = z2;
+    if ((rc = cdae_launch_layer(Mo, 2, a, stream))) return rc;                       // z2 from a1
+    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z2, Tr->d_groups, d, 1, stats, Tr->d_params, apply_update);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, Tr->d_groups, d, 1, stats, Tr->d_params);
+    a.act2 = a2; a.act3 = z3;
+    if ((rc = cdae_launch_layer(Mo, 3, a, stream))) return rc;                       // z3 from a2
+    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z3, Tr->d_groups, d, 2, stats, Tr->d_params, apply_update);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, Tr->d_groups, d, 2, stats, Tr->d_params);
+    a.act3 = a3;
+    if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks, Y = mask * X
+    // ---- loss + its gradients ---------------------------------------------------------------------
+    if ((rc = xsq_loss_forward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, loss_ws, loss_ws_bytes, stream))) return rc;
+    int64_t maxC = 0;
+    for (int b = 0; b < Tr->nblocks; ++b) maxC = std::max<int64_t>(maxC, (int64_t)Bn * 2 * Tr->Fv[b] * S * Tr->Tv[b] * 2);
+    hipLaunchKernelGGL(k_loss_bwd, dim3(grid1(maxC).x, (unsigned)Tr->nblocks), dim3(256), 0, stream, Y, Yt, masks, gY, gM, Tr->d_geo, Tr->nblocks, Bn, S);
+    hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d);
+    // ---- backward -----------------------------------------------------------------------------------
+    float* gp = Tr->d_grads;
+    hipLaunchKernelGGL(k_l4_bias_grad, dim3(G), dim3(256), 0, stream, gM, Tr->d_groups, d, gp);
+    hipLaunchKernelGGL(k_l4_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, a3, gM, Tr->d_groups, d, gp);
+    hipLaunchKernelGGL(k_l4_dgrad, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, gM, Tr->d_params, Tr->d_groups, d, g3);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, gp);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, Tr->d_params);
+    hipLaunchKernelGGL(k_l3_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a2, g3, Tr->d_groups, d, gp);
+    hipLaunchKernelGGL(k_l3_dgrad, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, g3, Tr->d_params, Tr->d_groups, d, g2);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, gp);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, Tr->d_params);
+    hipLaunchKernelGGL(k_l2_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a1, g2, Tr->d_groups, d, gp);
+    hipLaunchKernelGGL(k_l2_dgrad, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, g2, Tr->d_params, Tr->d_groups, d, g1);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, gp);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, Tr->d_params);
+    hipLaunchKernelGGL(k_l1_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, xin, g1, Tr->d_groups, d, gp);
+    hipLaunchKernelGGL(k_l1_input_grad, dim3((unsigned)Tr->sumF), dim3(256), 0, stream, xin, g1, Tr->d_params, Tr->d_groups, Tr->d_rows, d, gp);
+    // ---- update ---------------------------------------------------------------------------------------
+    if (apply_update) {
+        Tr->step += 1;
+        const float b1 = 0.9f, b2 = 0.999f;
+        hipLaunchKernelGGL(k_adamw, grid1(Tr->nparams), dim3(256), 0, stream, Tr->d_params, gp, Tr->d_m, Tr->d_v, Tr->d_trainable,
+                           Tr->nparams, lr, wd, b1, b2, 1e-8f, 1.f - powf(b1, (float)Tr->step), 1.f - powf(b2, (float)Tr->step));
+    }
+    XSQ_HIP(hipGetLastError());
+    // loss scalars (the reference calls loss.item() every step as well, training.py:110)
+    std::vector<double> per((size_t)Tr->nblocks * 2);
+    XSQ_HIP(hipMemcpyAsync(per.data(), d_loss, per.size() * 8, hipMemcpyDeviceToHost, stream));
+    XSQ_HIP(hipStreamSynchronize(stream));
+    loss_out[0] = loss_out[1] = 0.0;
+    for (int b = 0; b < Tr->nblocks; ++b) { loss_out[0] += per[2 * b]; loss_out[1] += per[2 * b + 1]; }
+    loss_out[0] /= Tr->nblocks; loss_out[1] /= Tr->nblocks;
+    return XSQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""Mirror of the training half of /root/reference/xumx_slicq_v2/training.py:34-112 (``loop`` with
+``train=True``) on the HIP library: one call = forward with BatchNorm on batch statistics, ComplexMSE +
+MaskSum loss, backward of every trainable tensor, AdamW update (training.py:391-393 defaults).
+
+The reference hands the step to torch autograd + ``torch.optim.AdamW``; here the whole step is
+``xsq_train_step`` (csrc/train.hip) over flat parameter / gradient / moment pools that keep the
+reference's state_dict order, so a checkpoint of the reference loads, trains and saves unchanged.
+The SDR term (auraloss, off by default: ``--sdr-mcoef -1``), the LSTM variant, the LR scheduler /
+early stopping / tensorboard logging around the loop are outside the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from .model import Unmix
+
+
+class Trainer:
+    """Owns the device-side training state of one ``Unmix``.
+
+    ``step(x, y_targets)`` = the body of ``for x, y in pbar`` (training.py:66-110) and returns
+    ``(loss, mse_loss, mask_loss)`` as python floats; ``gradients()`` exposes what
+    ``loss.backward()`` would have left in ``.grad``; ``state_dict()`` / ``sync_to(unmix)`` hand
+    the trained tensors back in the reference's layout."""
+
+    def __init__(self, unmix: Unmix, encoder, lr: float = 1e-3, weight_decay: float = 1e-5,
+                 device: str | torch.device = "cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.XsqError("training runs on a ROCm device only; there is no CPU fallback")
+        self.nsgt, self.insgt, self.cnorm = encoder
+        self.lr, self.weight_decay = float(lr), float(weight_decay)
+        self.table = unmix.table
+        self._F, self._T = unmix._F, unmix._T
+        causal = {blk.causal for blk in unmix.sliced_umx}
+        wiener = {not blk.realtime for blk in unmix.sliced_umx}
+        if len(causal) != 1 or len(wiener) != 1:
+            raise _lib.XsqError("all blocks must share the same first-layer type and post-filter")
+        self.causal, self.wiener = causal.pop(), wiener.pop()
+        self._spec = [(k, tuple(v.shape)) for k, v in unmix.state_dict().items() if not k.endswith("num_batches_tracked")]
+        params = unmix.packed_parameters()
+        self.nparams = int(params.size)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.xsq_train_create(C.byref(self._h), len(self.table), self._F.ctypes.data,
+                                                 self._T.ctypes.data, 1 if self.causal else 0,
+                                                 params.ctypes.data, params.size), "xsq_train_create")
+        self._ws = None
+        self.steps = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib.xsq_train_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- one step ------------------------------------------------------------------------
+    def step_arena(self, X: Tensor, Yt: Tensor, B: int, S: int, apply_update: bool = True) -> Tuple[float, float, float]:
+        """X: mix arena (2B channels), Yt: target arena (8B channels), both flat fp32 on the device."""
+        with torch.cuda.device(self.device):
+            need = _lib.lib.xsq_train_workspace(self._h, B, S, 1 if self.wiener else 0)
+            if need == 0:
+                raise _lib.XsqError("xsq_train_workspace: bad shape")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            out = (C.c_double * 2)()
+            _lib.check(_lib.lib.xsq_train_step(self._h, X.data_ptr(), Yt.data_ptr(), B, S, 1 if self.wiener else 0,
+                                               self.lr, self.weight_decay, 1 if apply_update else 0, out,
+                                               self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()),
+                       "xsq_train_step")
+        if apply_update:
+            self.steps += 1
+        mse, mask = float(out[0]), float(out[1])
+        return mse + mask, mse, mask
+
+    @torch.no_grad()
+    def step(self, x: Tensor, y_targets: Tensor, apply_update: bool = True) -> Tuple[float, float, float]:
+        """x (B, 2, N) mix, y_targets (4, B, 2, N): training.py:66-108."""
+        x = x.to(self.device, torch.float32)
+        y_targets = y_targets.to(self.device, torch.float32)
+        Xc = self.nsgt(x)
+        Yt = self.nsgt(y_targets)
+        X, lead, S = self.table.as_arena(list(Xc))
+        Ytg, lead_t, S_t = self.table.as_arena(list(Yt))
+        if len(lead) != 2 or lead[1] != 2 or lead_t != (4, lead[0], 2) or S != S_t:
+            raise ValueError(f"expected x (B, 2, N) and y_targets (4, B, 2, N); got arenas {lead} / {lead_t}")
+        return self.step_arena(X, Ytg, lead[0], S, apply_update)
+
+    # -- state ---------------------------------------------------------------------------
+    def _read(self, what: int) -> "OrderedDict[str, Tensor]":
+        buf = np.empty(self.nparams, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.xsq_train_read(self._h, what, buf.ctypes.data), "xsq_train_read")
+        out, o = OrderedDict(), 0
+        for k, shp in self._spec:
+            n = int(np.prod(shp)) if shp else 1
+            out[k] = torch.from_numpy(buf[o:o + n].reshape(shp).copy())
+            o += n
+        return out
+
+    def state_dict(self) -> "OrderedDict[str, Tensor]":
+        """Parameters and BatchNorm running statistics, reference key layout (num_batches_tracked left out)."""
+        return self._read(0)
+
+    def gradients(self) -> Dict[str, Tensor]:
+        """Gradients of the last step for every trainable tensor (the running statistics have none)."""
+        return OrderedDict((k, v) for k, v in self._read(1).items()
+                           if not k.endswith(("running_mean", "running_var")))
+
+    def sync_to(self, unmix: Unmix) -> Unmix:
+        sd = unmix.state_dict()
+        for k, v in self.state_dict().items():
+            sd[k] = v
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                sd[k] = sd[k] + self.steps
+        unmix.load_state_dict(sd, strict=True)
+        return unmix
