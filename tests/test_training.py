@@ -14,16 +14,20 @@ def _inputs(n):
     return y_t.sum(0), y_t
 
 
-# One BatchNorm-2 pre-activation of block 32 / target 1 sits ON the ReLU kink for this fixture: -1.28e-6 in the
-# reference's fp32, -4.7e-7 in fp64 (test_fixture_has_a_relu_kink pins that).  Any other summation order can
-# land on the other side, which switches one of that group's 36 rows on or off: the gradients upstream of that
-# ReLU (layers 1-2 of the group and the block's whitening) then move by a few percent -- a subgradient choice,
+# Each fixture has ONE pre-activation of a small block sitting ON a ReLU kink: realtime model, block 32 / target 1,
+# BatchNorm-2 output -1.28e-6 in the reference's fp32 and -4.7e-7 in fp64; offline model, block 36 / target 0,
+# BatchNorm-3 output 5.5e-8 in fp32 and 1.2e-7 in fp64 (test_fixture_has_a_relu_kink pins both).  Any other summation
+# order can land on the other side, which switches one of that group's 36-48 rows on or off: the gradients upstream of
+# that ReLU (the group's earlier layers and the block's whitening) then move by a few percent -- a subgradient choice,
 # not an error.  Those tensors get a loose bound for the HIP path; every other tensor keeps rtol.
-KINK = ("sliced_umx.32.input_", "sliced_umx.32.cdaes.1.0.", "sliced_umx.32.cdaes.1.1.", "sliced_umx.32.cdaes.1.3.",
-        "sliced_umx.32.cdaes.1.4.")
+KINKS = {
+    "realtime": (32, 1, 2, ("sliced_umx.32.input_",) + tuple(f"sliced_umx.32.cdaes.1.{i}." for i in (0, 1, 3, 4))),
+    "offline": (36, 0, 3, ("sliced_umx.36.input_",) + tuple(f"sliced_umx.36.cdaes.0.{i}." for i in (0, 1, 3, 4, 6, 7))),
+}
 
 
 def _check(g, tag, mse, msk, grads, rtol, kink_rtol=None):
+    KINK = KINKS[tag][3]
     assert abs(mse - float(g[f"{tag}_mse"])) < 1e-4 * float(g[f"{tag}_mse"])
     assert abs(msk - float(g[f"{tag}_mask"])) < 1e-4 * float(g[f"{tag}_mask"])
     names = [str(k) for k in g["param_names"]]
@@ -59,25 +63,29 @@ def test_oracle_training_gradients_match_reference(oracle_plan, seeded_sd, tag, 
     _check(g, tag, mse, msk, grads, rtol=2e-3)
 
 
-def test_fixture_has_a_relu_kink(oracle_plan, seeded_sd):
-    """Pins the premise of KINK above on the oracle (block 32 only, fp32 and fp64)."""
+@pytest.mark.parametrize("tag,causal", [("realtime", True), ("offline", False)])
+def test_fixture_has_a_relu_kink(oracle_plan, seeded_sd, tag, causal):
+    """Pins the premise of KINKS above on the oracle (one block, fp32 and fp64)."""
     import torch.nn.functional as F
     from oracle import model as omodel
     from oracle import slicqt as oslicqt
     g = load_golden("training_step.npz")
     x, _ = _inputs(int(g["n"]))
-    b, p = 32, "sliced_umx.32.cdaes.1."
+    b, t, layer, _ = KINKS[tag]
+    pre_b, p = f"sliced_umx.{b}.", f"sliced_umx.{b}.cdaes.{t}."
     Xb = oslicqt.forward(oracle_plan, x)[b]
-    for dt, bound in ((torch.float32, 5e-6), (torch.float64, 5e-6)):
-        sd = {k: v.to(dt) for k, v in seeded_sd.items() if k.startswith("sliced_umx.32.") and v.dtype.is_floating_point}
+    for dt in (torch.float32, torch.float64):
+        sd = {k: v.to(dt) for k, v in seeded_sd.items() if k.startswith(pre_b) and v.dtype.is_floating_point}
         mag = omodel.abs_of_real_complex(Xb.to(dt))
         B, C, Fb, S, T = mag.shape
-        xx = (mag.reshape(B, C, Fb, S * T) + sd["sliced_umx.32.input_mean"][None, None, :, None]) \
-            * sd["sliced_umx.32.input_scale"][None, None, :, None]
-        y = F.conv2d(F.pad(xx, (T - 1, 0)), sd[p + "0.weight"], stride=(1, T // 2))
-        y = F.conv2d(F.relu(omodel._bn(y, sd, p + "1", True)), sd[p + "3.weight"])
-        pre = omodel._bn(y, sd, p + "4", True).abs().flatten().sort().values
-        assert pre[0] < bound and pre[1] > 1e-4, pre[:3]
+        xx = (mag.reshape(B, C, Fb, S * T) + sd[pre_b + "input_mean"][None, None, :, None]) \
+            * sd[pre_b + "input_scale"][None, None, :, None]
+        y = F.conv2d(F.pad(xx, (T - 1, 0)) if causal else xx, sd[p + "0.weight"], stride=(1, T // 2))
+        y = omodel._bn(F.conv2d(F.relu(omodel._bn(y, sd, p + "1", True)), sd[p + "3.weight"]), sd, p + "4", True)
+        if layer == 3:
+            y = omodel._bn(F.conv_transpose2d(F.relu(y), sd[p + "6.weight"]), sd, p + "7", True)
+        pre = y.abs().flatten().sort().values
+        assert pre[0] < 5e-6 and pre[1] > 1e-4, pre[:3]
 
 
 def _trainer(realtime):
@@ -88,7 +96,7 @@ def _trainer(realtime):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,realtime", [("realtime", True)])
+@pytest.mark.parametrize("tag,realtime", [("realtime", True), ("offline", False)])
 def test_hip_training_gradients_match_reference(tag, realtime):
     """xsq_train_step (gradients only) vs the reference's loss.backward(): loss terms, the gradient norm of
     every one of the 3500 trainable tensors and fifteen full gradient tensors."""
@@ -105,20 +113,21 @@ def test_hip_training_gradients_match_reference(tag, realtime):
 
 
 @pytest.mark.gpu
-def test_hip_training_step_updates_like_adamw():
+@pytest.mark.parametrize("tag,realtime", [("realtime", True), ("offline", False)])
+def test_hip_training_step_updates_like_adamw(tag, realtime):
     """One full step: running statistics follow nn.BatchNorm2d.train() (reference fixture), the parameter
     update equals torch.optim.AdamW(lr=1e-3, weight_decay=1e-5) applied to the same gradients, and a few
     steps on one batch bring the loss down."""
     g = load_golden("training_step.npz")
     x, y_t = _inputs(int(g["n"]))
-    sep, tr = _trainer(True)
+    sep, tr = _trainer(realtime)
     before = tr.state_dict()
     loss0, _, _ = tr.step(x, y_t, apply_update=True)
     grads = tr.gradients()
     after = tr.state_dict()
     k = "sliced_umx.1.cdaes.0.4"
-    assert np.allclose(after[k + ".running_mean"].numpy(), g[f"realtime_running_mean::{k}"], rtol=1e-4, atol=1e-6)
-    assert np.allclose(after[k + ".running_var"].numpy(), g[f"realtime_running_var::{k}"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(after[k + ".running_mean"].numpy(), g[f"{tag}_running_mean::{k}"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(after[k + ".running_var"].numpy(), g[f"{tag}_running_var::{k}"], rtol=1e-4, atol=1e-7)
     keys = ["sliced_umx.0.input_mean", "sliced_umx.0.cdaes.1.0.weight", "sliced_umx.1.cdaes.0.3.weight",
             "sliced_umx.2.cdaes.1.6.weight", "sliced_umx.69.cdaes.3.9.weight", "sliced_umx.69.cdaes.0.7.bias",
             "sliced_umx.33.cdaes.2.9.bias"]

@@ -454,7 +454,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
         bool ok = true;
         for (int ph = 0; ph < 4; ++ph) {
             P->phase_begin[ph] = (int)tgt.size();
-            int last_end = -1 << 30;
+            int last_end = -(1 << 30);
             for (int j = ph; j < nbands; j += 4) {
                 BandDev& b = P->bands[j];
                 b.ent = (int)tgt.size();

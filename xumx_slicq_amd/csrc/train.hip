@@ -637,7 +637,7 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
     b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
-    if (wiener) b += 2 * xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000) + 4096;
+    if (wiener) b += 2 * alt(xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000)) + 4096;
     return b;
 }
 
@@ -647,7 +647,6 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
                    int apply_update, double* loss_out, void* ws, size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(Tr && X && Yt && ws && loss_out, "xsq_train_step: null argument");
     XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_train_step: B=%d S=%d", Bn, S);
-    XSQ_REQUIRE(!wiener, "xsq_train_step: the Wiener-EM backward is not built yet (train the mix-phase model)");
     XSQ_REQUIRE(ws_bytes >= xsq_train_workspace(Tr, Bn, S, wiener), "xsq_train_step: workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     xsq_model* Mo = Tr->model;
@@ -663,6 +662,10 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     float *z3 = (float*)take(na1 * 4), *a3 = (float*)take(na1 * 4), *g3 = (float*)take(na1 * 4);
     float *masks = (float*)take(n8 * 4), *gM = (float*)take(n8 * 4);
     float *Y = (float*)take(n8 * 8), *gY = (float*)take(n8 * 8);
+    float* Y0 = wiener ? (float*)take(n8 * 8) : nullptr;
+    const size_t wst_bytes = wiener ? xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000) : 0;
+    void* wst = wiener ? take(wst_bytes) : nullptr;
+    void* wbst = wiener ? take(wst_bytes) : nullptr;
     float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
     float *mean = (float*)take((size_t)Tr->sumF * 4), *scale = (float*)take((size_t)Tr->sumF * 4);
     double* d_loss = (double*)take((size_t)Tr->nblocks * 16);
@@ -700,11 +703,17 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, Tr->d_groups, d, 2, stats, Tr->d_params);
     a.act3 = a3;
     if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks, Y = mask * X
+    if (wiener) {       // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69)
+        XSQ_HIP(hipMemcpyAsync(Y0, Y, n8 * 8, hipMemcpyDeviceToDevice, stream));
+        if ((rc = xsq_wiener_em(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, Y, Bn, S, 5000, Bn, wst, wst_bytes, stream))) return rc;
+    }
     // ---- loss + its gradients ---------------------------------------------------------------------
     if ((rc = xsq_loss_forward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, loss_ws, loss_ws_bytes, stream))) return rc;
     int64_t maxC = 0;
     for (int b = 0; b < Tr->nblocks; ++b) maxC = std::max<int64_t>(maxC, (int64_t)Bn * 2 * Tr->Fv[b] * S * Tr->Tv[b] * 2);
     hipLaunchKernelGGL(k_loss_bwd, dim3(grid1(maxC).x, (unsigned)Tr->nblocks), dim3(256), 0, stream, Y, Yt, masks, gY, gM, Tr->d_geo, Tr->nblocks, Bn, S);
+    if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, Y0, gY, Bn, S, 5000, Bn, wst, wbst, stream)))
+        return rc;
     hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d);
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;

@@ -25,7 +25,8 @@
 
 namespace xsq {
 
-static const int STAT = 20;   // floats per (row, window): 4 sources x (C00, C11, Re C01, Im C01), max|x|^2, pad
+static const int STAT = 24;   // floats per (row, window): 4 sources x (C00, C11, Re C01, Im C01), max|x|^2, pad[3],
+                              // 4 x 1/(sum_n v + eps) (kept for the backward pass)
 
 struct WRow {          // one (block, batch item, bin) row of the arena
     int F, T;          // block geometry
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void k_wiener_finalize(const WRow* __restrict_
             st[4 * j + 1] = c11 * den;
             st[4 * j + 2] = st[4 * j + 2] * inv_ma2 * den;
             st[4 * j + 3] = st[4 * j + 3] * inv_ma2 * den;
+            st[20 + j] = den;
         }
         st[16] = inv_ma2;
     }
@@ -210,6 +212,174 @@ __global__ __launch_bounds__(256) void k_wiener_apply(const float2* __restrict__
         const float2 b = cmulc(z0, R01[j]);      // conj(R01) * z0
         Y[yi[j]] = make_float2(v[j] * (R00[j] * z0.x + a.x), v[j] * (R00[j] * z0.y + a.y));
         Y[yi[j] + (int64_t)r.F * N] = make_float2(v[j] * (b.x + R11[j] * z1.x), v[j] * (b.y + R11[j] * z1.y));
+    }
+}
+
+// ---- backward of the EM iteration (training: loss.backward() through norbert, training.py:107) --------
+// Notation of the header; per point n: w = Cxx^-1 x, out_j = v_j R_j w.  With gO_j the incoming gradient,
+//   q = sum_j v_j R_j gO_j,  p = Cxx^-1 q,  u_j = gO_j - p,
+//   d/dv_j = Re(u_j^H R_j w),   d/dR_j = sum_n v_j u_j w^H  (only its Hermitian part K_j matters),
+//   R_j = A_j / D_j:  H_j = K_j / D_j - Re tr(K_j/2 R_j) / D_j * I,
+//   d/dy0[n,:,j] = (d/dv_j * y0 + H_j y0) / ma^2.
+// Pass 1 accumulates K_j per (row, window) (same fixed-order reduction as the forward statistics), pass 2
+// forms H_j, pass 3 rewrites the gradient arena in place.
+struct WPoint {
+    float v[4], gv[4];
+    float2 u[4][2];
+    float2 w0, w1;
+};
+
+__device__ inline void wiener_bwd_point(const float* __restrict__ st, float2 x0, float2 x1, const float2 (&y)[4][2],
+                                        const float2 (&g)[4][2], WPoint& P) {
+    const float inv_ma2 = st[16];
+    const float reg = sqrtf(FLT_EPSILON);
+    float c00 = reg, c11 = reg;
+    float2 c01 = make_float2(0.f, 0.f);
+    float R00[4], R11[4];
+    float2 R01[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        P.v[j] = 0.5f * ((y[j][0].x * y[j][0].x + y[j][0].y * y[j][0].y) * inv_ma2 +
+                         (y[j][1].x * y[j][1].x + y[j][1].y * y[j][1].y) * inv_ma2);
+        R00[j] = st[4 * j]; R11[j] = st[4 * j + 1]; R01[j] = make_float2(st[4 * j + 2], st[4 * j + 3]);
+        c00 += P.v[j] * R00[j];
+        c11 += P.v[j] * R11[j];
+        c01.x += P.v[j] * R01[j].x;
+        c01.y += P.v[j] * R01[j].y;
+    }
+    const float idet = 1.f / (c00 * c11 - (c01.x * c01.x + c01.y * c01.y));
+    const float i00 = c11 * idet, i11 = c00 * idet;
+    const float2 i01 = make_float2(-c01.x * idet, -c01.y * idet);
+    auto solve = [&](float2 a0, float2 a1, float2& o0, float2& o1) {      // Cxx^-1 a
+        const float2 t = cmul(i01, a1), s = cmulc(a0, i01);               // i10 = conj(i01)
+        o0 = make_float2(i00 * a0.x + t.x, i00 * a0.y + t.y);
+        o1 = make_float2(s.x + i11 * a1.x, s.y + i11 * a1.y);
+    };
+    solve(x0, x1, P.w0, P.w1);
+    float2 q0 = make_float2(0.f, 0.f), q1 = q0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // R_j gO_j
+        const float2 a = cmul(R01[j], g[j][1]), b = cmulc(g[j][0], R01[j]);
+        q0.x += P.v[j] * (R00[j] * g[j][0].x + a.x); q0.y += P.v[j] * (R00[j] * g[j][0].y + a.y);
+        q1.x += P.v[j] * (b.x + R11[j] * g[j][1].x); q1.y += P.v[j] * (b.y + R11[j] * g[j][1].y);
+    }
+    float2 p0, p1;
+    solve(q0, q1, p0, p1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        P.u[j][0] = make_float2(g[j][0].x - p0.x, g[j][0].y - p0.y);
+        P.u[j][1] = make_float2(g[j][1].x - p1.x, g[j][1].y - p1.y);
+        const float2 a = cmul(R01[j], P.w1), b = cmulc(P.w0, R01[j]);
+        const float2 rw0 = make_float2(R00[j] * P.w0.x + a.x, R00[j] * P.w0.y + a.y);
+        const float2 rw1 = make_float2(b.x + R11[j] * P.w1.x, b.y + R11[j] * P.w1.y);
+        P.gv[j] = (P.u[j][0].x * rw0.x + P.u[j][0].y * rw0.y) + (P.u[j][1].x * rw1.x + P.u[j][1].y * rw1.y);
+    }
+}
+
+__device__ inline void wiener_load_point(const float2* __restrict__ X, const float2* __restrict__ Y0,
+                                         const float2* __restrict__ G, const WRow& r, int Bn, int S, int64_t n,
+                                         float2& x0, float2& x1, float2 (&y)[4][2], float2 (&g)[4][2], int64_t (&yi)[4]) {
+    const int64_t N = (int64_t)S * r.T;
+    x0 = X[cidx(r, 2 * Bn, S, r.b * 2, n)];
+    x1 = X[cidx(r, 2 * Bn, S, r.b * 2 + 1, n)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        yi[j] = cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2, n);
+        y[j][0] = Y0[yi[j]]; y[j][1] = Y0[yi[j] + (int64_t)r.F * N];
+        g[j][0] = G[yi[j]]; g[j][1] = G[yi[j] + (int64_t)r.F * N];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wiener_bwd_stats(const float2* __restrict__ X, const float2* __restrict__ Y0,
+                                                           const float2* __restrict__ G, const WRow* __restrict__ rows,
+                                                           const int* __restrict__ work, const float* __restrict__ stats,
+                                                           float* __restrict__ bstats, int Bn, int S, int win_len) {
+    const int row = work[2 * blockIdx.x], w = work[2 * blockIdx.x + 1];
+    const WRow r = rows[row];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n0 = (int64_t)w * win_len;
+    const int64_t n1 = n0 + win_len < N ? n0 + win_len : N;
+    const float* st = stats + r.stat + (int64_t)w * STAT;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+        float2 x0, x1, y[4][2], g[4][2];
+        int64_t yi[4];
+        wiener_load_point(X, Y0, G, r, Bn, S, n, x0, x1, y, g, yi);
+        WPoint P;
+        wiener_bwd_point(st, x0, x1, y, g, P);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {      // K = v (u w^H + w u^H)
+            const float2 a = cmulc(P.u[j][0], P.w1), b = cmulc(P.w0, P.u[j][1]);
+            acc[4 * j + 0] += 2.f * P.v[j] * (P.u[j][0].x * P.w0.x + P.u[j][0].y * P.w0.y);
+            acc[4 * j + 1] += 2.f * P.v[j] * (P.u[j][1].x * P.w1.x + P.u[j][1].y * P.w1.y);
+            acc[4 * j + 2] += P.v[j] * (a.x + b.x);
+            acc[4 * j + 3] += P.v[j] * (a.y + b.y);
+        }
+    }
+    __shared__ float red[4][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x;
+        bstats[r.stat + (int64_t)w * STAT + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
+// K_j -> H_j, one thread per (row, window)
+__global__ void k_wiener_bwd_finalize(const WRow* __restrict__ rows, const int* __restrict__ work, int nwork,
+                                      const float* __restrict__ stats, float* __restrict__ bstats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwork) return;
+    const WRow r = rows[work[2 * i]];
+    const int64_t o = r.stat + (int64_t)work[2 * i + 1] * STAT;
+    const float* st = stats + o;
+    float* bs = bstats + o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float den = st[20 + j];
+        const float k00 = bs[4 * j], k11 = bs[4 * j + 1], k01x = bs[4 * j + 2], k01y = bs[4 * j + 3];
+        const float s = (0.5f * (k00 * st[4 * j] + k11 * st[4 * j + 1]) + (k01x * st[4 * j + 2] + k01y * st[4 * j + 3])) * den;
+        bs[4 * j] = k00 * den - s;
+        bs[4 * j + 1] = k11 * den - s;
+        bs[4 * j + 2] = k01x * den;
+        bs[4 * j + 3] = k01y * den;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restrict__ X, const float2* __restrict__ Y0,
+                                                           float2* __restrict__ G, const WRow* __restrict__ rows,
+                                                           const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                           int Bn, int S, int win_len) {
+    const WRow r = rows[blockIdx.y];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t o = r.stat + (n / win_len) * STAT;
+    const float* st = stats + o;
+    const float* bs = bstats + o;
+    float2 x0, x1, y[4][2], g[4][2];
+    int64_t yi[4];
+    wiener_load_point(X, Y0, G, r, Bn, S, n, x0, x1, y, g, yi);
+    WPoint P;
+    wiener_bwd_point(st, x0, x1, y, g, P);
+    const float inv_ma2 = st[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float h00 = bs[4 * j], h11 = bs[4 * j + 1];
+        const float2 h01 = make_float2(bs[4 * j + 2], bs[4 * j + 3]);
+        const float2 a = cmul(h01, y[j][1]), b = cmulc(y[j][0], h01);
+        G[yi[j]] = make_float2((P.gv[j] * y[j][0].x + h00 * y[j][0].x + a.x) * inv_ma2,
+                               (P.gv[j] * y[j][0].y + h00 * y[j][0].y + a.y) * inv_ma2);
+        G[yi[j] + (int64_t)r.F * N] = make_float2((P.gv[j] * y[j][1].x + b.x + h11 * y[j][1].x) * inv_ma2,
+                                                  (P.gv[j] * y[j][1].y + b.y + h11 * y[j][1].y) * inv_ma2);
     }
 }
 
@@ -267,6 +437,28 @@ static int check_table(const char* who, int nblocks, const int32_t* F, const int
         rows += (int64_t)Bn * F[b];
     }
     XSQ_REQUIRE(rows <= 65535, "%s: %lld rows exceed one launch", who, (long long)rows);
+    return XSQ_OK;
+}
+
+// backward of xsq_wiener_em: `stats` is the workspace the forward call left behind, G holds dL/d(out) on entry
+// and dL/d(y0) on return, Y0 is the pre-filter estimate.  bstats: another workspace of the same size.
+int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, float* G,
+                       int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream) {
+    if (batch_group <= 0) batch_group = Bn;
+    WTable t;
+    int rc;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, batch_group, &t))) return rc;
+    { XSQ_PROF("wiener_bwd_stats", stream);
+    hipLaunchKernelGGL(k_wiener_bwd_stats, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, (const float2*)Y0,
+                       (const float2*)G, t.d_rows, t.d_work, (const float*)stats, (float*)bstats, Bn, S, win_len); }
+    { XSQ_PROF("wiener_bwd_finalize", stream);
+    hipLaunchKernelGGL(k_wiener_bwd_finalize, dim3((t.nwork + 255) / 256), dim3(256), 0, stream, t.d_rows, t.d_work, t.nwork,
+                       (const float*)stats, (float*)bstats); }
+    { XSQ_PROF("wiener_bwd_apply", stream);
+    hipLaunchKernelGGL(k_wiener_bwd_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
+                       (const float2*)X, (const float2*)Y0, (float2*)G, t.d_rows, (const float*)stats, (const float*)bstats,
+                       Bn, S, win_len); }
+    XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }
 
