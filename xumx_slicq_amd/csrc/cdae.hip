@@ -117,7 +117,8 @@ struct CdaeL1Op {
         g.Fo = b.F1; g.To = a.T1; g.Fi = b.F; g.Ti = a.S * b.T;
         g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = 2 * b.kf * b.T; g.ldb = b.ld1;
         g.B = a.pool + b.w1[tgt]; g.shift = a.pool + b.s1[tgt];
-        g.in = a.xin + (int64_t)a.Bn * 2 * a.S * b.cum;
+        g.in = a.xin8 ? a.xin8 + (int64_t)a.Bn * 8 * a.S * b.cum + (int64_t)tgt * a.Bn * 2 * b.F * g.Ti
+                      : a.xin + (int64_t)a.Bn * 2 * a.S * b.cum;
         g.out = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
         return g;
     }
@@ -127,7 +128,7 @@ struct CdaeL1Op {
         int b, f, t;
         split_row(m, g.Fo, g.To, b, f, t);
         r.f = f;
-        r.t = t * g.hop - (a.causal ? g.T - 1 : 0);          // first input sample of the window
+        r.t = t * g.hop - ((a.causal && !a.xin8) ? g.T - 1 : 0);   // first input sample of the window
         r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
         return r;
     }
@@ -142,11 +143,11 @@ struct CdaeL1Op {
             const float2 hi = *reinterpret_cast<const float2*>(p + 2);
             return make_float4(lo.x, lo.y, hi.x, hi.y);
         }
-        const int t0 = r.t + dt;                               // causal: zero left padding of W-1 samples
-        if (t0 >= 0) v.x = p[0];
-        if (t0 + 1 >= 0) v.y = p[1];
-        if (t0 + 2 >= 0) v.z = p[2];
-        if (t0 + 3 >= 0) v.w = p[3];
+        const int t0 = r.t + dt;     // causal: zero left padding of W-1 samples (forward) / cropped right edge (xin8)
+        if (t0 >= 0 && t0 < g.Ti) v.x = p[0];
+        if (t0 + 1 >= 0 && t0 + 1 < g.Ti) v.y = p[1];
+        if (t0 + 2 >= 0 && t0 + 2 < g.Ti) v.z = p[2];
+        if (t0 + 3 >= 0 && t0 + 3 < g.Ti) v.w = p[3];
         return v;
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
@@ -241,7 +242,7 @@ struct CdaeL4Op {
         const int tgt = gid & 3;
         Group g;
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
-        g.Fo = b.F; g.To = 2 * a.S; g.Fi = b.F1; g.Ti = a.T1;
+        g.Fo = b.F; g.To = a.gx8 ? a.T1 + 1 : 2 * a.S; g.Fi = b.F1; g.Ti = a.T1;
         g.M = a.Bn * g.Fo * g.To; g.N = b.T; g.K = b.kf * 2 * CS; g.ldb = b.ld4;
         g.B = a.pool + b.w4[tgt]; g.shift = a.pool + b.b4[tgt];
         g.in = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
@@ -272,6 +273,23 @@ struct CdaeL4Op {
         const int n1 = n + 32;
         const int ca = n >= g.hop, cb = n1 >= g.hop;
         const int dta = n - ca * g.hop, dtb = n1 - cb * g.hop;
+        if (a.gx8) {        // data gradient of layer 1: raw store, (target, b, c, f, u*hop + dt), row length To*hop
+            const int64_t STp = (int64_t)g.To * g.hop, FSTp = (int64_t)g.F * STp;
+            float* o = a.gx8 + 4 * (int64_t)a.Bn * g.To * g.cum + (int64_t)g.tgt * a.Bn * 2 * FSTp;
+            int b, f, u;
+            split_row(row0, g.Fo, g.To, b, f, u);
+            int prev = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                u += acc_row(r) - prev; prev = acc_row(r);
+                while (u >= g.To) { u -= g.To; if (++f == g.Fo) { f = 0; ++b; } }
+                if (row0 + acc_row(r) >= g.M) break;
+                float* d = o + (int64_t)(b * 2) * FSTp + (int64_t)f * STp + (int64_t)u * g.hop;
+                if (v0) d[ca * FSTp + dta] = a0[r];
+                if (v1) d[cb * FSTp + dtb] = a1[r];
+            }
+            return;
+        }
         const float ba = g.shift[ca], bb = g.shift[cb];
         const int64_t ST = (int64_t)a.S * g.T;
         const int64_t FST = (int64_t)g.F * ST;
@@ -325,7 +343,7 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
     auto kof = [&](int b) {
         const CdaeBlockDev& d = Mo->blocks[b];
-        return layer == 1 ? 2 * d.kf * d.T : (layer == 4 ? d.kf * 2 * CS : d.kf * 4 * CS);
+        return layer == 1 ? 2 * d.kf * d.T : (layer >= 4 ? d.kf * 2 * CS : d.kf * 4 * CS);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return kof(x) > kof(y); });
     for (int b : order) {
@@ -335,9 +353,10 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             case 1: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
             case 2: M = (int64_t)Bn * d.F2 * T2; N = CS; break;
             case 3: M = (int64_t)Bn * d.F1 * T1; N = CS; break;
-            default: M = (int64_t)Bn * d.F * 2 * S; N = d.T; break;
+            case 4: M = (int64_t)Bn * d.F * 2 * S; N = d.T; break;
+            default: M = (int64_t)Bn * d.F * (T1 + 1); N = d.T; break;     // 6: layer-4 operator as layer-1 data gradient
         }
-        if (layer == 1 || layer == 4) {
+        if (layer == 1 || layer == 4 || layer == 6) {
             // the four targets read the same input (L1: whitened magnitude) / the same mix X (L4 epilogue):
             // keep their tiles of one (row, column) patch adjacent so the re-reads hit the XCD's L2
             for (int64_t m0 = 0; m0 < M; m0 += 128)
@@ -542,18 +561,19 @@ int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const
     return XSQ_OK;
 }
 
-int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream) {
+int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name) {
     TileTable tt;
+    if (layer == 4 && a.gx8) layer = 6;
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt);
     if (rc) return rc;
     switch (layer) {
-        case 1: { XSQ_PROF("cdae_l1_gemm", stream);
+        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream);
             hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL1Op{a}, tt.d_tiles, tt.ntiles); } break;
-        case 2: { XSQ_PROF("cdae_l2_gemm", stream);
+        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream);
             hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL2Op{a}, tt.d_tiles, tt.ntiles); } break;
-        case 3: { XSQ_PROF("cdae_l3_gemm", stream);
+        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream);
             hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL3Op{a}, tt.d_tiles, tt.ntiles); } break;
-        default: { XSQ_PROF("cdae_l4_gemm", stream);
+        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
             hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL4Op{a}, tt.d_tiles, tt.ntiles); } break;
     }
     return XSQ_OK;
@@ -576,7 +596,7 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
     cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream);
-    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0};
+    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0, nullptr, nullptr};
     for (int layer = 1; layer <= 4; ++layer) {
         const int rc = cdae_launch_layer(Mo, layer, a, stream);
         if (rc) return rc;

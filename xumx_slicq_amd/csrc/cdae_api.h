@@ -57,11 +57,16 @@ struct CdaeArgs {
     float* masks;         // optional real arena (8B channels), nullptr to skip
     int Bn, S, T1, T2, causal;
     int raw;              // 1: layers 1-3 store the raw convolution (training: BatchNorm on batch statistics follows)
+    // training only (csrc/train.hip); nullptr on the inference path
+    const float* xin8;    // layer-1 operator as the DATA GRADIENT of layer 4: input = real arena with 8B channels
+                          // (target-specific), no left padding, right edge checked; weights = w4 in w1's layout
+    float* gx8;           // layer-4 operator as the DATA GRADIENT of layer 1: raw store of (target, b, c, f, u*hop+dt)
+                          // with u < T1+1 (padded coordinates s = tau + left pad); weights = w1 in w4's layout
 };
 
 
 // one grouped launch of CDAE layer 1..4 over all blocks x targets (tile table cached per (layer, B, S))
-int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream);
+int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name = nullptr);
 // |X| -> whitened magnitude with explicit mean / scale tables (sum_b F_b floats each)
 int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
                           int Bn, int S, hipStream_t stream);

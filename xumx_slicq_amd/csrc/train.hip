@@ -65,38 +65,63 @@ __global__ void k_gather(const float* __restrict__ src, const int* __restrict__ 
 // stats layout per (group, layer): mean[64] | invstd[64] | sum_g[64] | sum_gz[64]
 __device__ __forceinline__ float* bn_slot(float* stats, int group, int layer) { return stats + ((int64_t)group * 3 + layer) * 256; }
 
-// one workgroup per group: batch mean / biased variance per channel, running-stat update (momentum 0.1)
-__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ z, const TrainGroup* __restrict__ groups,
-                                                   TrainDims d, int layer, float* __restrict__ stats,
-                                                   float* __restrict__ pool, int update_running) {
-    const TrainGroup g = groups[blockIdx.x];
+// Reductions over the rows of a group run in two deterministic stages: BN_NCH row chunks per group write double
+// partial sums (fixed-order tree inside the workgroup), one small workgroup per group adds them in chunk order.
+static const int BN_NCH = 32;
+__device__ __forceinline__ void chunk_rows(int64_t M, int ch, int64_t& r0, int64_t& r1) {
+    const int64_t R = ((M + BN_NCH - 1) / BN_NCH + 3) / 4 * 4;
+    r0 = (int64_t)ch * R;
+    r1 = r0 + R < M ? r0 + R : M;
+}
+__device__ __forceinline__ double* bn_part(double* part, int group, int ch) { return part + ((int64_t)group * BN_NCH + ch) * 128; }
+
+// stage 1, grid (BN_NCH, groups): per channel sum and sum of squares over the chunk's rows
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ z, const TrainGroup* __restrict__ groups,
+                                                           TrainDims d, int layer, double* __restrict__ part) {
+    const TrainGroup g = groups[blockIdx.y];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    int64_t r0, r1;
+    chunk_rows(M, blockIdx.x, r0, r1);
     const float* zz = z + (layer == 1 ? act2_off(g, d) : act1_off(g, d));
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int64_t m = rs; m < M; m += 4) { const double v = zz[m * CS + c]; s1 += v; s2 += v * v; }
-    __shared__ double r1[256], r2[256];
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+        for (int64_t m = r0 + rs; m < r1; m += 4) { const double v = zz[m * CS + c]; s1 += v; s2 += v * v; }
+    __shared__ double q1[256], q2[256];
+    q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
     __syncthreads();
-    if (rs == 0 && c < C) {
-        const double a = (r1[c] + r1[c + 64]) + (r1[c + 128] + r1[c + 192]);
-        const double b = (r2[c] + r2[c + 64]) + (r2[c + 128] + r2[c + 192]);
-        const double mean = a / (double)M;
-        double var = b / (double)M - mean * mean;
-        if (var < 0.0) var = 0.0;
-        float* st = bn_slot(stats, blockIdx.x, layer);
-        st[c] = (float)mean;
-        st[64 + c] = (float)(1.0 / sqrt(var + (double)BN_EPS_F));
-        if (update_running) {
-            const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
-            float* rm = pool + pb + 2 * C;
-            float* rv = pool + pb + 3 * C;
-            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            rm[c] = (float)(0.9 * (double)rm[c] + 0.1 * mean);
-            rv[c] = (float)(0.9 * (double)rv[c] + 0.1 * unbiased);
-        }
+    if (rs == 0) {
+        double* o = bn_part(part, blockIdx.y, blockIdx.x);
+        o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
+        o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
+    }
+}
+
+// stage 2, one 64-thread workgroup per group: batch mean / biased variance, running-stat update (momentum 0.1)
+__global__ __launch_bounds__(64) void k_bn_stats_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
+                                                        TrainDims d, int layer, float* __restrict__ stats,
+                                                        float* __restrict__ pool, int update_running) {
+    const TrainGroup g = groups[blockIdx.x];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const int C = layer == 1 ? g.C2 : g.C1;
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < BN_NCH; ++ch) { const double* o = part + ((int64_t)blockIdx.x * BN_NCH + ch) * 128; a += o[c]; b += o[64 + c]; }
+    const double mean = a / (double)M;
+    double var = b / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* st = bn_slot(stats, blockIdx.x, layer);
+    st[c] = (float)mean;
+    st[64 + c] = (float)(1.0 / sqrt(var + (double)BN_EPS_F));
+    if (update_running) {
+        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+        float* rm = pool + pb + 2 * C;
+        float* rv = pool + pb + 3 * C;
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rm[c] = (float)(0.9 * (double)rm[c] + 0.1 * mean);
+        rv[c] = (float)(0.9 * (double)rv[c] + 0.1 * unbiased);
     }
 }
 
@@ -120,40 +145,55 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
     a[off + i] = v;
 }
 
-// backward, step 1: per channel sum(g_bn) and sum(g_bn * zhat), g_bn = g_a * [a > 0]; writes the affine
-// gradients into the gradient pool.  One workgroup per group.
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ z, const float* __restrict__ a,
-                                                        const float* __restrict__ ga, const TrainGroup* __restrict__ groups,
-                                                        TrainDims d, int layer, float* __restrict__ stats,
-                                                        float* __restrict__ gpool) {
-    const TrainGroup g = groups[blockIdx.x];
+// backward, step 1 (two stages like the statistics): per channel sum(g_bn) and sum(g_bn * zhat), g_bn = g_a * [a > 0]
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ z, const float* __restrict__ a,
+                                                         const float* __restrict__ ga, const TrainGroup* __restrict__ groups,
+                                                         TrainDims d, int layer, const float* __restrict__ stats,
+                                                         double* __restrict__ part) {
+    const TrainGroup g = groups[blockIdx.y];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    int64_t r0, r1;
+    chunk_rows(M, blockIdx.x, r0, r1);
     const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
-    float* st = bn_slot(stats, blockIdx.x, layer);
+    const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         const float mean = st[c], inv = st[64 + c];
-        for (int64_t m = rs; m < M; m += 4) {
+        for (int64_t m = r0 + rs; m < r1; m += 4) {
             const int64_t i = off + m * CS + c;
             const float gb = a[i] > 0.f ? ga[i] : 0.f;
             s1 += gb;
             s2 += (double)gb * (double)((z[i] - mean) * inv);
         }
     }
-    __shared__ double r1[256], r2[256];
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __shared__ double q1[256], q2[256];
+    q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
     __syncthreads();
-    if (rs == 0 && c < C) {
-        const double sg = (r1[c] + r1[c + 64]) + (r1[c + 128] + r1[c + 192]);
-        const double sgz = (r2[c] + r2[c + 64]) + (r2[c + 128] + r2[c + 192]);
-        st[128 + c] = (float)(sg / (double)M);
-        st[192 + c] = (float)(sgz / (double)M);
-        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
-        gpool[pb + c] = (float)sgz;        // d gamma
-        gpool[pb + C + c] = (float)sg;     // d beta
+    if (rs == 0) {
+        double* o = bn_part(part, blockIdx.y, blockIdx.x);
+        o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
+        o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
     }
+}
+
+__global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
+                                                      TrainDims d, int layer, float* __restrict__ stats,
+                                                      float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.x];
+    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+    const int C = layer == 1 ? g.C2 : g.C1;
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgz = 0.0;
+    for (int ch = 0; ch < BN_NCH; ++ch) { const double* o = part + ((int64_t)blockIdx.x * BN_NCH + ch) * 128; sg += o[c]; sgz += o[64 + c]; }
+    float* st = bn_slot(stats, blockIdx.x, layer);
+    st[128 + c] = (float)(sg / (double)M);
+    st[192 + c] = (float)(sgz / (double)M);
+    const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+    gpool[pb + c] = (float)sgz;        // d gamma
+    gpool[pb + C + c] = (float)sg;     // d beta
 }
 
 // backward, step 2 (in place on ga): g_z = gamma * invstd * (g_bn - mean(g_bn) - zhat * mean(g_bn * zhat))
@@ -269,32 +309,6 @@ __global__ __launch_bounds__(256) void k_l4_wgrad(const float* __restrict__ a3, 
     gpool[g.p_w4 + e] = acc;
 }
 
-// data: thread per (row (b,f3,t3), c3):  sum_{c,df,dt} w4[c3,c,df,dt] * gp4[b,c,f3+df,t3*hop+dt]
-__global__ __launch_bounds__(256) void k_l4_dgrad(const float* __restrict__ gp4, const float* __restrict__ pool,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga3) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * g.F1 * d.T1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * CS) return;
-    const int c3 = (int)(i % CS);
-    const int64_t m = i / CS;
-    float acc = 0.f;
-    if (c3 < g.C1) {
-        const int t3 = (int)(m % d.T1), f3 = (int)((m / d.T1) % g.F1), b = (int)(m / ((int64_t)d.T1 * g.F1));
-        const int64_t ST = (int64_t)d.S * g.T;
-        const float* w = pool + g.p_w4 + (int64_t)c3 * 2 * g.kf * g.T;
-        for (int c = 0; c < 2; ++c)
-            for (int df = 0; df < g.kf; ++df) {
-                const float* gp = gp4 + r8_idx(g, d, b, c, f3 + df, (int64_t)t3 * g.hop);
-                const float* ww = w + (int64_t)(c * g.kf + df) * g.T;
-                const int64_t lim = ST - (int64_t)t3 * g.hop;          // causal model: the crop cuts the last window
-                const int n = lim < g.T ? (int)lim : g.T;
-                for (int dt = 0; dt < n; ++dt) acc += ww[dt] * gp[dt];
-            }
-    }
-    ga3[act1_off(g, d) + i] = acc;
-}
-
 // ---- layer 3 backward (ConvTranspose2d 51 -> 50, (kf, 4)) -----------------------------------------------
 // z3[b,f3,t3,c3] = sum w3[c2,c3,df,dt] a2[b,f3-df,t3-dt,c2]
 __global__ __launch_bounds__(256) void k_l3_wgrad(const float* __restrict__ a2, const float* __restrict__ gz3,
@@ -315,29 +329,6 @@ __global__ __launch_bounds__(256) void k_l3_wgrad(const float* __restrict__ a2, 
     gpool[g.p_w3 + e] = acc;
 }
 
-// ga2[b,f2,t2,c2] = sum_{c3,df,dt} w3[c2,c3,df,dt] gz3[b,f2+df,t2+dt,c3]
-__global__ __launch_bounds__(256) void k_l3_dgrad(const float* __restrict__ gz3, const float* __restrict__ pool,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga2) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * g.F2 * d.T2;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * CS) return;
-    const int c2 = (int)(i % CS);
-    const int64_t m = i / CS;
-    float acc = 0.f;
-    if (c2 < g.C2) {
-        const int t2 = (int)(m % d.T2), f2 = (int)((m / d.T2) % g.F2), b = (int)(m / ((int64_t)d.T2 * g.F2));
-        const float* G = gz3 + act1_off(g, d);
-        const float* w = pool + g.p_w3 + (int64_t)c2 * g.C1 * g.kf * 4;
-        for (int df = 0; df < g.kf; ++df)
-            for (int dt = 0; dt < 4; ++dt) {
-                const float* gr = G + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + t2 + dt) * CS;
-                for (int c3 = 0; c3 < g.C1; ++c3) acc += w[(c3 * g.kf + df) * 4 + dt] * gr[c3];
-            }
-    }
-    ga2[act2_off(g, d) + i] = acc;
-}
-
 // ---- layer 2 backward (Conv2d 50 -> 51, (kf, 4)) ----------------------------------------------------------
 // z2[b,f2,t2,c2] = sum w2[c2,c1,df,dt] a1[b,f2+df,t2+dt,c1]
 __global__ __launch_bounds__(256) void k_l2_wgrad(const float* __restrict__ a1, const float* __restrict__ gz2,
@@ -356,34 +347,6 @@ __global__ __launch_bounds__(256) void k_l2_wgrad(const float* __restrict__ a1, 
             for (int t2 = 0; t2 < d.T2; ++t2) acc += gr[(int64_t)t2 * CS] * ar[(int64_t)t2 * CS];
         }
     gpool[g.p_w2 + e] = acc;
-}
-
-// ga1[b,f1,t1,c1] = sum_{c2,df,dt} w2[c2,c1,df,dt] gz2[b,f1-df,t1-dt,c2]   (zero outside)
-__global__ __launch_bounds__(256) void k_l2_dgrad(const float* __restrict__ gz2, const float* __restrict__ pool,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ ga1) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * g.F1 * d.T1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * CS) return;
-    const int c1 = (int)(i % CS);
-    const int64_t m = i / CS;
-    float acc = 0.f;
-    if (c1 < g.C1) {
-        const int t1 = (int)(m % d.T1), f1 = (int)((m / d.T1) % g.F1), b = (int)(m / ((int64_t)d.T1 * g.F1));
-        const float* G = gz2 + act2_off(g, d);
-        const float* w = pool + g.p_w2;
-        for (int df = 0; df < g.kf; ++df) {
-            const int f2 = f1 - df;
-            if (f2 < 0 || f2 >= g.F2) continue;
-            for (int dt = 0; dt < 4; ++dt) {
-                const int t2 = t1 - dt;
-                if (t2 < 0 || t2 >= d.T2) continue;
-                const float* gr = G + ((int64_t)(b * g.F2 + f2) * d.T2 + t2) * CS;
-                for (int c2 = 0; c2 < g.C2; ++c2) acc += w[((c2 * g.C1 + c1) * g.kf + df) * 4 + dt] * gr[c2];
-            }
-        }
-    }
-    ga1[act1_off(g, d) + i] = acc;
 }
 
 // ---- layer 1 backward (Conv2d 2 -> 50, (kf, W), stride hop; causal: left pad W-1) ---------------------------
@@ -408,47 +371,31 @@ __global__ __launch_bounds__(256) void k_l1_wgrad(const float* __restrict__ xin,
     gpool[g.p_w1 + e] = acc;
 }
 
-// input whitening: xin = (|X| + mean_f) * scale_f.  One workgroup per (block, f): g_xin on the fly (sum over the 4
-// targets of the layer-1 data gradient), reduced to d mean_f = sum g_xin * scale_f, d scale_f = sum g_xin * xin / scale_f.
-// `groups4` points at the block's first group (target 0); the 4 targets are consecutive.
-__global__ __launch_bounds__(256) void k_l1_input_grad(const float* __restrict__ xin, const float* __restrict__ gz1,
-                                                        const float* __restrict__ pool, const TrainGroup* __restrict__ groups,
-                                                        const int2* __restrict__ rows, TrainDims d, float* __restrict__ gpool) {
+// input whitening: xin = (|X| + mean_f) * scale_f.  gx8 holds the layer-1 data gradient per target in padded
+// coordinates s = tau + pad (layer-4 operator, see cdae_api.h).  One workgroup per (block, f):
+//   d mean_f = scale_f * sum g_xin,   d scale_f = sum g_xin * xin / scale_f      (sums over target, b, channel, tau)
+__global__ __launch_bounds__(256) void k_input_grad_reduce(const float* __restrict__ xin, const float* __restrict__ gx8,
+                                                            const float* __restrict__ pool, const TrainGroup* __restrict__ groups,
+                                                            const int2* __restrict__ rows, TrainDims d, float* __restrict__ gpool) {
     const int2 r = rows[blockIdx.x];           // (first group of the block, f)
-    const TrainGroup g0 = groups[r.x];
+    const TrainGroup g = groups[r.x];
     const int f = r.y;
-    const int64_t ST = (int64_t)d.S * g0.T;
-    const int pad = d.causal ? g0.T - 1 : 0;
-    const float sc = pool[g0.p_scale + f];
+    const int To = d.T1 + 1;
+    const int64_t ST = (int64_t)d.S * g.T, STp = (int64_t)To * g.hop;
+    const int pad = d.causal ? g.T - 1 : 0;
+    const int64_t s_end = pad + ST < STp ? pad + ST : STp;
+    const float sc = pool[g.p_scale + f];
+    const float* gb = gx8 + 4 * (int64_t)d.Bn * To * g.cum;
     double sm = 0.0, ss = 0.0;
-    for (int64_t q = threadIdx.x; q < (int64_t)d.Bn * 2 * ST; q += 256) {
-        const int64_t tau = q % ST;
-        const int ci = (int)((q / ST) % 2), b = (int)(q / (2 * ST));
-        // windows t1 that contain tau: tau + pad - t1*hop in [0, W)
-        const int64_t tp = tau + pad;
-        int t_hi = (int)(tp / g0.hop);
-        if (t_hi > d.T1 - 1) t_hi = d.T1 - 1;
-        int t_lo = (int)((tp - g0.T + g0.hop) / g0.hop);       // ceil((tp - W + 1) / hop)
-        if (tp - g0.T + 1 <= 0) t_lo = 0;
-        float gx = 0.f;
-        for (int tg = 0; tg < 4; ++tg) {
-            const TrainGroup g = groups[r.x + tg];
-            const float* G = gz1 + act1_off(g, d);
-            const float* w = pool + g.p_w1;
-            for (int df = 0; df < g.kf; ++df) {
-                const int f1 = f - df;
-                if (f1 < 0 || f1 >= g.F1) continue;
-                for (int t1 = t_lo; t1 <= t_hi; ++t1) {
-                    const int dt = (int)(tp - (int64_t)t1 * g.hop);
-                    if (dt < 0 || dt >= g.T) continue;
-                    const float* gr = G + ((int64_t)(b * g.F1 + f1) * d.T1 + t1) * CS;
-                    for (int co = 0; co < g.C1; ++co) gx += w[((co * 2 + ci) * g.kf + df) * g.T + dt] * gr[co];
-                }
-            }
+    for (int q = 0; q < 4 * d.Bn * 2; ++q) {              // q = (tgt * Bn + b) * 2 + c
+        const int bc = q % (d.Bn * 2);
+        const float* gr = gb + ((int64_t)q * g.F + f) * STp;
+        const float* xr = xin + r2_idx(g, d, bc >> 1, bc & 1, f, 0) - pad;
+        for (int64_t s = pad + threadIdx.x; s < s_end; s += 256) {
+            const float gx = gr[s];
+            sm += gx;
+            ss += (double)gx * (double)xr[s];
         }
-        const float xv = xin[r2_idx(g0, d, b, ci, f, tau)];
-        sm += (double)gx * sc;
-        ss += (double)gx * (double)(xv / sc);
     }
     __shared__ double red[2][256];
     red[0][threadIdx.x] = sm; red[1][threadIdx.x] = ss;
@@ -457,7 +404,7 @@ __global__ __launch_bounds__(256) void k_l1_input_grad(const float* __restrict__
         if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { gpool[g0.p_mean + f] = (float)red[0][0]; gpool[g0.p_scale + f] = (float)red[1][0]; }
+    if (threadIdx.x == 0) { gpool[g.p_mean + f] = (float)(red[0][0] * sc); gpool[g.p_scale + f] = (float)(red[1][0] / sc); }
 }
 
 // ---- AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments) ----------------------
@@ -489,6 +436,8 @@ struct xsq_train {
     float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr;
     unsigned char* d_trainable = nullptr;
     int *d_map_pool = nullptr, *d_map_mean = nullptr, *d_map_scale = nullptr;
+    int* d_map_bwd = nullptr;               // canonical pool -> weights of the data-gradient operators (same slots as the forward pool)
+    float* d_pool_bwd = nullptr;
     int64_t step = 0;
     std::vector<int32_t> Fv, Tv;
 };
@@ -506,6 +455,7 @@ int xsq_train_destroy(xsq_train* T) {
     (void)hipFree(T->d_groups); (void)hipFree(T->d_geo); (void)hipFree(T->d_rows); (void)hipFree(T->d_params);
     (void)hipFree(T->d_grads); (void)hipFree(T->d_m); (void)hipFree(T->d_v); (void)hipFree(T->d_trainable);
     (void)hipFree(T->d_map_pool); (void)hipFree(T->d_map_mean); (void)hipFree(T->d_map_scale);
+    (void)hipFree(T->d_map_bwd); (void)hipFree(T->d_pool_bwd);
     delete T;
     return XSQ_OK;
 }
@@ -586,6 +536,39 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
             map[cb.b4[t] + 1] = (int)(g.p_b4 + 1);
         }
     }
+    // data-gradient operators reuse the forward GEMM operators on the gradient arenas (cdae_api.h):
+    //   slot w1 <- w4 (layer-1 operator = d/d a3 of layer 4)      slot w2 <- w3 (layer-2 operator = d/d a2 of layer 3)
+    //   slot w3 <- w2 (layer-3 operator = d/d a1 of layer 2)      slot w4 <- w1 (layer-4 operator = d/d xin of layer 1)
+    std::vector<int> mapb((size_t)extent, -1);
+    for (int b = 0; b < nblocks; ++b) {
+        const CdaeBlockDev& cb = Mo->blocks[b];
+        const int kf = cb.kf, W = cb.T, hop = cb.hop;
+        const int K1 = 2 * kf * W, K2 = kf * 4 * CS;
+        for (int t = 0; t < NT; ++t) {
+            const TrainGroup& g = Tr->groups[b * 4 + t];
+            for (int co = 0; co < H1; ++co)
+                for (int k = 0; k < K1; ++k) mapb[cb.w1[t] + (int64_t)co * cb.ld1 + k] = (int)(g.p_w4 + (int64_t)co * K1 + k);
+            for (int c2 = 0; c2 < H2; ++c2)
+                for (int c3 = 0; c3 < H1; ++c3)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            mapb[cb.w2[t] + (int64_t)c2 * K2 + (df * 4 + dt) * CS + c3] =
+                                (int)(g.p_w3 + (((int64_t)c2 * H1 + c3) * kf + df) * 4 + dt);
+            for (int c1 = 0; c1 < H1; ++c1)
+                for (int c2 = 0; c2 < H2; ++c2)
+                    for (int df = 0; df < kf; ++df)
+                        for (int dt = 0; dt < 4; ++dt)
+                            mapb[cb.w3[t] + (int64_t)c1 * K2 + (df * 4 + (3 - dt)) * CS + c2] =
+                                (int)(g.p_w2 + (((int64_t)c2 * H1 + c1) * kf + df) * 4 + dt);
+            for (int co = 0; co < H1; ++co)
+                for (int c = 0; c < 2; ++c)
+                    for (int df = 0; df < kf; ++df)
+                        for (int tap = 0; tap < 2; ++tap)
+                            for (int dt = 0; dt < hop; ++dt)
+                                mapb[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + tap) * CS + co] =
+                                    (int)(g.p_w1 + (((int64_t)co * 2 + c) * kf + df) * W + dt + tap * hop);
+        }
+    }
 #define UPV(dst, vec, TY)                                                                         \
     do {                                                                                          \
         XSQ_HIP(hipMalloc(&(dst), (vec).size() * sizeof(TY)));                                    \
@@ -598,6 +581,8 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
     UPV(Tr->d_map_pool, map, int);
     UPV(Tr->d_map_mean, map_mean, int);
     UPV(Tr->d_map_scale, map_scale, int);
+    UPV(Tr->d_map_bwd, mapb, int);
+    XSQ_HIP(hipMalloc(&Tr->d_pool_bwd, (size_t)extent * 4));
 #undef UPV
     XSQ_HIP(hipMalloc(&Tr->d_params, (size_t)nparams * 4));
     XSQ_HIP(hipMemcpy(Tr->d_params, params, (size_t)nparams * 4, hipMemcpyHostToDevice));
@@ -635,7 +620,7 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
     const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
     size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
-    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4);
+    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt((size_t)Tr->ngroups * BN_NCH * 128 * 8);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
     if (wiener) b += 2 * alt(xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000)) + 4096;
     return b;
@@ -667,6 +652,7 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     void* wst = wiener ? take(wst_bytes) : nullptr;
     void* wbst = wiener ? take(wst_bytes) : nullptr;
     float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
+    double* part = (double*)take((size_t)Tr->ngroups * BN_NCH * 128 * 8);
     float *mean = (float*)take((size_t)Tr->sumF * 4), *scale = (float*)take((size_t)Tr->sumF * 4);
     double* d_loss = (double*)take((size_t)Tr->nblocks * 16);
     void* loss_ws = w;
@@ -674,9 +660,10 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
 
     auto grid1 = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     // ---- parameters -> GEMM layouts -------------------------------------------------------------
-    hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_pool, Mo->d_pool, Tr->pool_floats);
-    hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_mean, mean, Tr->sumF);
-    hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_scale, scale, Tr->sumF);
+    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_pool, Mo->d_pool, Tr->pool_floats); }
+    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_bwd, Tr->d_pool_bwd, Tr->pool_floats); }
+    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_mean, mean, Tr->sumF); }
+    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_scale, scale, Tr->sumF); }
     // ---- forward ----------------------------------------------------------------------------------
     int rc;
     cdae_launch_magnitude(Mo, X, xin, mean, scale, Bn, S, stream);
@@ -689,18 +676,21 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
         maxW23 = std::max<int64_t>(maxW23, (int64_t)H2 * H1 * g.kf * 4);
     }
     const unsigned G = (unsigned)Tr->ngroups;
-    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1};
+    CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     if ((rc = cdae_launch_layer(Mo, 1, a, stream))) return rc;                       // z1
-    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z1, Tr->d_groups, d, 0, stats, Tr->d_params, apply_update);
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, Tr->d_groups, d, 0, stats, Tr->d_params);
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z1, Tr->d_groups, d, 0, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 0, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, Tr->d_groups, d, 0, stats, Tr->d_params); }
     a.act1 = a1; a.act2 = z2;
     if ((rc = cdae_launch_layer(Mo, 2, a, stream))) return rc;                       // z2 from a1
-    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z2, Tr->d_groups, d, 1, stats, Tr->d_params, apply_update);
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, Tr->d_groups, d, 1, stats, Tr->d_params);
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z2, Tr->d_groups, d, 1, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 1, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, Tr->d_groups, d, 1, stats, Tr->d_params); }
     a.act2 = a2; a.act3 = z3;
     if ((rc = cdae_launch_layer(Mo, 3, a, stream))) return rc;                       // z3 from a2
-    hipLaunchKernelGGL(k_bn_stats, dim3(G), dim3(256), 0, stream, z3, Tr->d_groups, d, 2, stats, Tr->d_params, apply_update);
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, Tr->d_groups, d, 2, stats, Tr->d_params);
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z3, Tr->d_groups, d, 2, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 2, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, Tr->d_groups, d, 2, stats, Tr->d_params); }
     a.act3 = a3;
     if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks, Y = mask * X
     if (wiener) {       // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69)
@@ -711,33 +701,43 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     if ((rc = xsq_loss_forward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, loss_ws, loss_ws_bytes, stream))) return rc;
     int64_t maxC = 0;
     for (int b = 0; b < Tr->nblocks; ++b) maxC = std::max<int64_t>(maxC, (int64_t)Bn * 2 * Tr->Fv[b] * S * Tr->Tv[b] * 2);
-    hipLaunchKernelGGL(k_loss_bwd, dim3(grid1(maxC).x, (unsigned)Tr->nblocks), dim3(256), 0, stream, Y, Yt, masks, gY, gM, Tr->d_geo, Tr->nblocks, Bn, S);
+    { XSQ_PROF("train_loss_bwd", stream); hipLaunchKernelGGL(k_loss_bwd, dim3(grid1(maxC).x, (unsigned)Tr->nblocks), dim3(256), 0, stream, Y, Yt, masks, gY, gM, Tr->d_geo, Tr->nblocks, Bn, S); }
     if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, Y0, gY, Bn, S, 5000, Bn, wst, wbst, stream)))
         return rc;
-    hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d);
+    { XSQ_PROF("train_mask_bwd", stream); hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d); }
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;
-    hipLaunchKernelGGL(k_l4_bias_grad, dim3(G), dim3(256), 0, stream, gM, Tr->d_groups, d, gp);
-    hipLaunchKernelGGL(k_l4_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, a3, gM, Tr->d_groups, d, gp);
-    hipLaunchKernelGGL(k_l4_dgrad, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, gM, Tr->d_params, Tr->d_groups, d, g3);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, gp);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, Tr->d_params);
-    hipLaunchKernelGGL(k_l3_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a2, g3, Tr->d_groups, d, gp);
-    hipLaunchKernelGGL(k_l3_dgrad, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, g3, Tr->d_params, Tr->d_groups, d, g2);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, gp);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, Tr->d_params);
-    hipLaunchKernelGGL(k_l2_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a1, g2, Tr->d_groups, d, gp);
-    hipLaunchKernelGGL(k_l2_dgrad, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, g2, Tr->d_params, Tr->d_groups, d, g1);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, gp);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, Tr->d_params);
-    hipLaunchKernelGGL(k_l1_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, xin, g1, Tr->d_groups, d, gp);
-    hipLaunchKernelGGL(k_l1_input_grad, dim3((unsigned)Tr->sumF), dim3(256), 0, stream, xin, g1, Tr->d_params, Tr->d_groups, Tr->d_rows, d, gp);
+    { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_grad, dim3(G), dim3(256), 0, stream, gM, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l4_wgrad", stream); hipLaunchKernelGGL(k_l4_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, a3, gM, Tr->d_groups, d, gp); }
+    CdaeArgs bw{Mo->d_blocks, Tr->d_pool_bwd, xin, g1, g2, g3, X, Y, nullptr, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
+    bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
+    if ((rc = cdae_launch_layer(Mo, 1, bw, stream, "train_l4_dgrad_gemm"))) return rc;
+    bw.xin8 = nullptr;
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 2, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, Tr->d_params); }
+    { XSQ_PROF("train_l3_wgrad", stream); hipLaunchKernelGGL(k_l3_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a2, g3, Tr->d_groups, d, gp); }
+    bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
+    if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 1, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, Tr->d_params); }
+    { XSQ_PROF("train_l2_wgrad", stream); hipLaunchKernelGGL(k_l2_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a1, g2, Tr->d_groups, d, gp); }
+    bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
+    if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 0, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, Tr->d_params); }
+    { XSQ_PROF("train_l1_wgrad", stream); hipLaunchKernelGGL(k_l1_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, xin, g1, Tr->d_groups, d, gp); }
+    bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);
+    if ((rc = cdae_launch_layer(Mo, 4, bw, stream, "train_l1_dgrad_gemm"))) return rc;   // gY is free by now
+    { XSQ_PROF("train_input_grad_reduce", stream); hipLaunchKernelGGL(k_input_grad_reduce, dim3((unsigned)Tr->sumF), dim3(256), 0, stream, xin, gY, Tr->d_params, Tr->d_groups, Tr->d_rows, d, gp); }
     // ---- update ---------------------------------------------------------------------------------------
     if (apply_update) {
         Tr->step += 1;
         const float b1 = 0.9f, b2 = 0.999f;
-        hipLaunchKernelGGL(k_adamw, grid1(Tr->nparams), dim3(256), 0, stream, Tr->d_params, gp, Tr->d_m, Tr->d_v, Tr->d_trainable,
-                           Tr->nparams, lr, wd, b1, b2, 1e-8f, 1.f - powf(b1, (float)Tr->step), 1.f - powf(b2, (float)Tr->step));
+        { XSQ_PROF("train_adamw", stream); hipLaunchKernelGGL(k_adamw, grid1(Tr->nparams), dim3(256), 0, stream, Tr->d_params, gp, Tr->d_m, Tr->d_v, Tr->d_trainable,
+                           Tr->nparams, lr, wd, b1, b2, 1e-8f, 1.f - powf(b1, (float)Tr->step), 1.f - powf(b2, (float)Tr->step)); }
     }
     XSQ_HIP(hipGetLastError());
     // loss scalars (the reference calls loss.item() every step as well, training.py:110)
