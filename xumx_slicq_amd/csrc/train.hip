@@ -15,11 +15,14 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/xumx_slicq_hip.h"
 #include "cdae_api.h"
 #include "prof.h"
+#include "wgrad.h"
 
 namespace xsq {
 
@@ -286,89 +289,119 @@ __global__ __launch_bounds__(256) void k_l4_bias_grad(const float* __restrict__ 
     if (threadIdx.x < 2) gpool[g.p_b4 + threadIdx.x] = (float)red[threadIdx.x][0];
 }
 
-// weight: thread per element of w4 (in=50, out=2, kf, W):  sum_{b,f3,t3} a3[b,f3,t3,c3] * gp4[b,c,f3+df,t3*hop+dt]
-__global__ __launch_bounds__(256) void k_l4_wgrad(const float* __restrict__ a3, const float* __restrict__ gp4,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d,
-                                                   float* __restrict__ gpool) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= g.C1 * 2 * g.kf * g.T) return;
-    const int dt = e % g.T, df = (e / g.T) % g.kf, c = (e / (g.T * g.kf)) % 2, c3 = e / (g.T * g.kf * 2);
-    const float* A = a3 + act1_off(g, d);
-    const int64_t ST = (int64_t)d.S * g.T;
-    float acc = 0.f;
-    for (int b = 0; b < d.Bn; ++b)
-        for (int f3 = 0; f3 < g.F1; ++f3) {
-            const float* gp = gp4 + r8_idx(g, d, b, c, f3 + df, 0);
-            const float* ar = A + ((int64_t)(b * g.F1 + f3) * d.T1) * CS + c3;
-            for (int t3 = 0; t3 < d.T1; ++t3) {
-                const int64_t tau = (int64_t)t3 * g.hop + dt;
-                if (tau < ST) acc += ar[(int64_t)t3 * CS] * gp[tau];
-            }
+// ---- weight gradients (wgrad.h) -----------------------------------------------------------------------------
+// layers 2 / 3:  gw2[c2][c1,df,dt] = sum_k gz2[k][c2] * a1[(b, f2+df, t2+dt)][c1]
+//                gw3[c2][c3,df,dt] = sum_k a2[k][c2]  * gz3[(b, f2+df, t2+dt)][c3]          k = (b, f2, t2)
+// A = an act2-like array (rows k), B = 4 x 52 contiguous floats of an act1-like array per frequency tap df;
+// one column tile per df, column = dt*52 + c.
+struct WgL23Op {
+    static constexpr int NTL = 224;
+    struct Group { const float* A; const float* B; int F1, F2; };
+    struct Row { const float* p; };
+    struct Cols { int n; };
+    const float* Aarr; const float* Barr; const TrainGroup* groups; TrainDims d;
+    __device__ Group group(int gid) const {
+        const TrainGroup g = groups[gid];
+        return Group{Aarr + act2_off(g, d), Barr + act1_off(g, d), g.F1, g.F2};
+    }
+    __device__ const float* a_row(const Group& g, int k) const { return g.A + (int64_t)k * CS; }
+    __device__ Row row(const Group& g, int k, int df) const {
+        const int per = g.F2 * d.T2;
+        const int b = k / per, r = k - b * per;
+        const int f2 = r / d.T2, t2 = r - f2 * d.T2;
+        return Row{g.B + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + t2) * CS};
+    }
+    __device__ Cols cols(const Group&, int, int n) const { return Cols{n}; }
+    __device__ float4 load_b4(const Group&, const Row& r, const Cols& c) const {
+        return c.n < 4 * CS ? *reinterpret_cast<const float4*>(r.p + c.n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
+// layers 1 / 4:  gw1[co][ci,df,dt] = sum_k gz1[k][co] * xin[b, ci, f1+df, t1*hop + dt - pad]
+//                gw4[c3][c,df,dt]  = sum_k a3[k][c3]  * gp4[tgt, b, c, f1+df, t1*hop + dt]    k = (b, f1, t1)
+// A = an act1-like array, B = (ci, df) spans of W samples of a real arena (2B channels, or the target's
+// 2B channels of an 8B-channel arena); samples outside [0, S*T) are zero (causal padding / crop).
+struct WgL14Op {
+    static constexpr int NTL = 256;
+    struct Group { const float* A; const float* R; int F, F1, T, hop, kf, K1, pad; int64_t ST; };
+    struct Row { const float* p; int64_t tau0; };
+    struct Cols { int64_t off; int dt; int valid; };
+    const float* Aarr; const float* Rarr; const TrainGroup* groups; TrainDims d; int chan8, padleft;
+    __device__ Group group(int gid) const {
+        const TrainGroup g = groups[gid];
+        Group o;
+        o.ST = (int64_t)d.S * g.T;
+        o.A = Aarr + act1_off(g, d);
+        o.R = chan8 ? Rarr + (int64_t)d.Bn * 8 * d.S * g.cum + (int64_t)g.tgt * d.Bn * 2 * g.F * o.ST
+                    : Rarr + (int64_t)d.Bn * 2 * d.S * g.cum;
+        o.F = g.F; o.F1 = g.F1; o.T = g.T; o.hop = g.hop; o.kf = g.kf; o.K1 = 2 * g.kf * g.T;
+        o.pad = (padleft && d.causal) ? g.T - 1 : 0;
+        return o;
+    }
+    __device__ const float* a_row(const Group& g, int k) const { return g.A + (int64_t)k * CS; }
+    __device__ Row row(const Group& g, int k, int) const {
+        const int per = g.F1 * d.T1;
+        const int b = k / per, r = k - b * per;
+        const int f1 = r / d.T1, t1 = r - f1 * d.T1;
+        const int64_t tau0 = (int64_t)t1 * g.hop - g.pad;
+        return Row{g.R + ((int64_t)b * 2 * g.F + f1) * g.ST + tau0, tau0};
+    }
+    __device__ Cols cols(const Group& g, int ntile, int n) const {
+        const int ng = ntile * NTL + n;
+        Cols c; c.valid = ng < g.K1 && n < NTL; c.off = 0; c.dt = 0;
+        if (c.valid) {
+            const int seg = ng / g.T; c.dt = ng - seg * g.T;
+            const int ci = seg / g.kf, df = seg - ci * g.kf;
+            c.off = ((int64_t)ci * g.F + df) * g.ST + c.dt;
         }
-    gpool[g.p_w4 + e] = acc;
+        return c;
+    }
+    __device__ float4 load_b4(const Group& g, const Row& r, const Cols& c) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!c.valid) return v;
+        const float* p = r.p + c.off;
+        const int64_t t = r.tau0 + c.dt;
+        if (t >= 0 && t + 3 < g.ST) { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; return v; }
+        if (t >= 0 && t < g.ST) v.x = p[0];
+        if (t + 1 >= 0 && t + 1 < g.ST) v.y = p[1];
+        if (t + 2 >= 0 && t + 2 < g.ST) v.z = p[2];
+        if (t + 3 >= 0 && t + 3 < g.ST) v.w = p[3];
+        return v;
+    }
+};
+
+// chunk sums -> canonical gradient layout.  grid (ceil(64 * kf_max * 208 / 256), groups)
+__global__ __launch_bounds__(256) void k_wgrad_reduce23(const float* __restrict__ partial, const WgGroupInfo* __restrict__ info,
+                                                         const TrainGroup* __restrict__ groups, int layer, float* __restrict__ gpool) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int per = g.kf * 4 * CS;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t / per;
+    if (m >= g.C2) return;
+    const int r = t - m * per, df = r / (4 * CS), col = r - df * 4 * CS;
+    const int dt = col / CS, cx = col - dt * CS;
+    if (cx >= g.C1) return;
+    const WgGroupInfo gi = info[blockIdx.y];
+    const float* p = partial + ((int64_t)(gi.tile_base + df * gi.nch) * 64 + m) * WgL23Op::NTL + col;
+    float acc = 0.f;
+    for (int ch = 0; ch < gi.nch; ++ch) acc += p[(int64_t)ch * 64 * WgL23Op::NTL];
+    gpool[(layer == 2 ? g.p_w2 : g.p_w3) + (((int64_t)m * g.C1 + cx) * g.kf + df) * 4 + dt] = acc;
 }
 
-// ---- layer 3 backward (ConvTranspose2d 51 -> 50, (kf, 4)) -----------------------------------------------
-// z3[b,f3,t3,c3] = sum w3[c2,c3,df,dt] a2[b,f3-df,t3-dt,c2]
-__global__ __launch_bounds__(256) void k_l3_wgrad(const float* __restrict__ a2, const float* __restrict__ gz3,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
+// grid (ceil(50 * K1_max / 256), groups)
+__global__ __launch_bounds__(256) void k_wgrad_reduce14(const float* __restrict__ partial, const WgGroupInfo* __restrict__ info,
+                                                         const TrainGroup* __restrict__ groups, int layer, float* __restrict__ gpool) {
     const TrainGroup g = groups[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= g.C2 * g.C1 * g.kf * 4) return;
-    const int dt = e % 4, df = (e / 4) % g.kf, c3 = (e / (4 * g.kf)) % g.C1, c2 = e / (4 * g.kf * g.C1);
-    const float* A = a2 + act2_off(g, d);
-    const float* G = gz3 + act1_off(g, d);
+    const int K1 = 2 * g.kf * g.T;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.C1 * K1) return;
+    const int m = t / K1, n = t - m * K1;
+    const int ntile = n / WgL14Op::NTL, col = n - ntile * WgL14Op::NTL;
+    const WgGroupInfo gi = info[blockIdx.y];
+    const float* p = partial + ((int64_t)(gi.tile_base + ntile * gi.nch) * 64 + m) * WgL14Op::NTL + col;
     float acc = 0.f;
-    for (int b = 0; b < d.Bn; ++b)
-        for (int f2 = 0; f2 < g.F2; ++f2) {
-            const float* ar = A + ((int64_t)(b * g.F2 + f2) * d.T2) * CS + c2;
-            const float* gr = G + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + dt) * CS + c3;
-            for (int t2 = 0; t2 < d.T2; ++t2) acc += ar[(int64_t)t2 * CS] * gr[(int64_t)t2 * CS];
-        }
-    gpool[g.p_w3 + e] = acc;
-}
-
-// ---- layer 2 backward (Conv2d 50 -> 51, (kf, 4)) ----------------------------------------------------------
-// z2[b,f2,t2,c2] = sum w2[c2,c1,df,dt] a1[b,f2+df,t2+dt,c1]
-__global__ __launch_bounds__(256) void k_l2_wgrad(const float* __restrict__ a1, const float* __restrict__ gz2,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= g.C2 * g.C1 * g.kf * 4) return;
-    const int dt = e % 4, df = (e / 4) % g.kf, c1 = (e / (4 * g.kf)) % g.C1, c2 = e / (4 * g.kf * g.C1);
-    const float* A = a1 + act1_off(g, d);
-    const float* G = gz2 + act2_off(g, d);
-    float acc = 0.f;
-    for (int b = 0; b < d.Bn; ++b)
-        for (int f2 = 0; f2 < g.F2; ++f2) {
-            const float* gr = G + ((int64_t)(b * g.F2 + f2) * d.T2) * CS + c2;
-            const float* ar = A + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + dt) * CS + c1;
-            for (int t2 = 0; t2 < d.T2; ++t2) acc += gr[(int64_t)t2 * CS] * ar[(int64_t)t2 * CS];
-        }
-    gpool[g.p_w2 + e] = acc;
-}
-
-// ---- layer 1 backward (Conv2d 2 -> 50, (kf, W), stride hop; causal: left pad W-1) ---------------------------
-__global__ __launch_bounds__(256) void k_l1_wgrad(const float* __restrict__ xin, const float* __restrict__ gz1,
-                                                   const TrainGroup* __restrict__ groups, TrainDims d, float* __restrict__ gpool) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= g.C1 * 2 * g.kf * g.T) return;
-    const int dt = e % g.T, df = (e / g.T) % g.kf, ci = (e / (g.T * g.kf)) % 2, co = e / (g.T * g.kf * 2);
-    const float* G = gz1 + act1_off(g, d);
-    const int pad = d.causal ? g.T - 1 : 0;
-    float acc = 0.f;
-    for (int b = 0; b < d.Bn; ++b)
-        for (int f1 = 0; f1 < g.F1; ++f1) {
-            const float* xr = xin + r2_idx(g, d, b, ci, f1 + df, 0);
-            const float* gr = G + ((int64_t)(b * g.F1 + f1) * d.T1) * CS + co;
-            for (int t1 = 0; t1 < d.T1; ++t1) {
-                const int64_t tau = (int64_t)t1 * g.hop + dt - pad;
-                if (tau >= 0) acc += gr[(int64_t)t1 * CS] * xr[tau];
-            }
-        }
-    gpool[g.p_w1 + e] = acc;
+    for (int ch = 0; ch < gi.nch; ++ch) acc += p[(int64_t)ch * 64 * WgL14Op::NTL];
+    gpool[(layer == 1 ? g.p_w1 : g.p_w4) + t] = acc;
 }
 
 // input whitening: xin = (|X| + mean_f) * scale_f.  gx8 holds the layer-1 data gradient per target in padded
@@ -440,9 +473,58 @@ struct xsq_train {
     float* d_pool_bwd = nullptr;
     int64_t step = 0;
     std::vector<int32_t> Fv, Tv;
+    struct WgTables { xsq::WgTile *d_t23 = nullptr, *d_t14 = nullptr; xsq::WgGroupInfo *d_i23 = nullptr, *d_i14 = nullptr; int n23 = 0, n14 = 0; };
+    std::mutex mu;
+    std::map<std::pair<int, int>, WgTables> wg;     // (B, S) -> weight-gradient tile tables
 };
 
 using namespace xsq;
+
+static const int WG_KC = 512;      // rows of one weight-gradient chunk
+
+// tiles of the two weight-gradient launches: (group, column tile, row chunk); chunks of one (group, column tile) consecutive
+static void wg_build(const xsq_train* Tr, int Bn, int S, std::vector<WgTile>* t23, std::vector<WgGroupInfo>* i23,
+                     std::vector<WgTile>* t14, std::vector<WgGroupInfo>* i14) {
+    const int T1 = Tr->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    for (int gi = 0; gi < Tr->ngroups; ++gi) {
+        const TrainGroup& g = Tr->groups[gi];
+        const int M2 = Bn * g.F2 * T2, M1 = Bn * g.F1 * T1;
+        const int nch2 = (M2 + WG_KC - 1) / WG_KC, nch1 = (M1 + WG_KC - 1) / WG_KC;
+        i23->push_back(WgGroupInfo{(int)t23->size(), nch2});
+        for (int nt = 0; nt < g.kf; ++nt)
+            for (int ch = 0; ch < nch2; ++ch) t23->push_back(WgTile{gi, nt, ch * WG_KC, std::min(M2, (ch + 1) * WG_KC)});
+        i14->push_back(WgGroupInfo{(int)t14->size(), nch1});
+        const int ntiles = (2 * g.kf * g.T + WgL14Op::NTL - 1) / WgL14Op::NTL;
+        for (int nt = 0; nt < ntiles; ++nt)
+            for (int ch = 0; ch < nch1; ++ch) t14->push_back(WgTile{gi, nt, ch * WG_KC, std::min(M1, (ch + 1) * WG_KC)});
+    }
+}
+
+static size_t wg_partial_floats(const xsq_train* Tr, int Bn, int S) {
+    std::vector<WgTile> a, b; std::vector<WgGroupInfo> ia, ib;
+    wg_build(Tr, Bn, S, &a, &ia, &b, &ib);
+    return std::max(a.size() * 64 * WgL23Op::NTL, b.size() * 64 * WgL14Op::NTL);
+}
+
+static int wg_tables(xsq_train* Tr, int Bn, int S, xsq_train::WgTables* out) {
+    std::lock_guard<std::mutex> lk(Tr->mu);
+    auto it = Tr->wg.find({Bn, S});
+    if (it != Tr->wg.end()) { *out = it->second; return XSQ_OK; }
+    std::vector<WgTile> a, b; std::vector<WgGroupInfo> ia, ib;
+    wg_build(Tr, Bn, S, &a, &ia, &b, &ib);
+    xsq_train::WgTables w;
+    w.n23 = (int)a.size(); w.n14 = (int)b.size();
+#define UPW(dst, vec, TY)                                                                         \
+    do {                                                                                          \
+        XSQ_HIP(hipMalloc(&(dst), (vec).size() * sizeof(TY)));                                    \
+        XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(TY), hipMemcpyHostToDevice)); \
+    } while (0)
+    UPW(w.d_t23, a, WgTile); UPW(w.d_i23, ia, WgGroupInfo); UPW(w.d_t14, b, WgTile); UPW(w.d_i14, ib, WgGroupInfo);
+#undef UPW
+    Tr->wg[{Bn, S}] = w;
+    *out = w;
+    return XSQ_OK;
+}
 
 static inline size_t alt(size_t x) { return (x + 255) / 256 * 256; }
 static int kf_of_t(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }
@@ -456,6 +538,7 @@ int xsq_train_destroy(xsq_train* T) {
     (void)hipFree(T->d_grads); (void)hipFree(T->d_m); (void)hipFree(T->d_v); (void)hipFree(T->d_trainable);
     (void)hipFree(T->d_map_pool); (void)hipFree(T->d_map_mean); (void)hipFree(T->d_map_scale);
     (void)hipFree(T->d_map_bwd); (void)hipFree(T->d_pool_bwd);
+    for (auto& kv : T->wg) { (void)hipFree(kv.second.d_t23); (void)hipFree(kv.second.d_t14); (void)hipFree(kv.second.d_i23); (void)hipFree(kv.second.d_i14); }
     delete T;
     return XSQ_OK;
 }
@@ -620,7 +703,8 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
     const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
     size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
-    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt((size_t)Tr->ngroups * BN_NCH * 128 * 8);
+    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt((size_t)Tr->ngroups * BN_NCH * 128 * 8)
+         + alt(wg_partial_floats(Tr, Bn, S) * 4);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
     if (wiener) b += 2 * alt(xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000)) + 4096;
     return b;
@@ -653,6 +737,9 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     void* wbst = wiener ? take(wst_bytes) : nullptr;
     float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
     double* part = (double*)take((size_t)Tr->ngroups * BN_NCH * 128 * 8);
+    xsq_train::WgTables wt;
+    if (int rcw = wg_tables(Tr, Bn, S, &wt)) return rcw;
+    float* wpart = (float*)take(std::max((size_t)wt.n23 * 64 * WgL23Op::NTL, (size_t)wt.n14 * 64 * WgL14Op::NTL) * 4);
     float *mean = (float*)take((size_t)Tr->sumF * 4), *scale = (float*)take((size_t)Tr->sumF * 4);
     double* d_loss = (double*)take((size_t)Tr->nblocks * 16);
     void* loss_ws = w;
@@ -667,13 +754,13 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     // ---- forward ----------------------------------------------------------------------------------
     int rc;
     cdae_launch_magnitude(Mo, X, xin, mean, scale, Bn, S, stream);
-    int64_t maxM1 = 0, maxM2 = 0, maxP = 0, maxW14 = 0, maxW23 = 0;
+    int64_t maxM1 = 0, maxM2 = 0, maxP = 0, maxW14 = 0, maxR23 = 0;
     for (const TrainGroup& g : Tr->groups) {
         maxM1 = std::max<int64_t>(maxM1, (int64_t)Bn * g.F1 * T1 * CS);
         maxM2 = std::max<int64_t>(maxM2, (int64_t)Bn * g.F2 * T2 * CS);
         maxP = std::max<int64_t>(maxP, (int64_t)Bn * 2 * g.F * S * g.T);
         maxW14 = std::max<int64_t>(maxW14, (int64_t)H1 * 2 * g.kf * g.T);
-        maxW23 = std::max<int64_t>(maxW23, (int64_t)H2 * H1 * g.kf * 4);
+        maxR23 = std::max<int64_t>(maxR23, (int64_t)H2 * g.kf * 4 * CS);
     }
     const unsigned G = (unsigned)Tr->ngroups;
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
@@ -708,7 +795,9 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;
     { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_grad, dim3(G), dim3(256), 0, stream, gM, Tr->d_groups, d, gp); }
-    { XSQ_PROF("train_l4_wgrad", stream); hipLaunchKernelGGL(k_l4_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, a3, gM, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l4_wgrad", stream);
+      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
     CdaeArgs bw{Mo->d_blocks, Tr->d_pool_bwd, xin, g1, g2, g3, X, Y, nullptr, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
     if ((rc = cdae_launch_layer(Mo, 1, bw, stream, "train_l4_dgrad_gemm"))) return rc;
@@ -716,19 +805,25 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 2, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, Tr->d_params); }
-    { XSQ_PROF("train_l3_wgrad", stream); hipLaunchKernelGGL(k_l3_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a2, g3, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l3_wgrad", stream);
+      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
     if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 1, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, Tr->d_params); }
-    { XSQ_PROF("train_l2_wgrad", stream); hipLaunchKernelGGL(k_l2_wgrad, dim3(grid1(maxW23).x, G), dim3(256), 0, stream, a1, g2, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l2_wgrad", stream);
+      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
     if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 0, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, Tr->d_params); }
-    { XSQ_PROF("train_l1_wgrad", stream); hipLaunchKernelGGL(k_l1_wgrad, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, xin, g1, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l1_wgrad", stream);
+      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
     bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);
     if ((rc = cdae_launch_layer(Mo, 4, bw, stream, "train_l1_dgrad_gemm"))) return rc;   // gY is free by now
     { XSQ_PROF("train_input_grad_reduce", stream); hipLaunchKernelGGL(k_input_grad_reduce, dim3((unsigned)Tr->sumF), dim3(256), 0, stream, xin, gY, Tr->d_params, Tr->d_groups, Tr->d_rows, d, gp); }
