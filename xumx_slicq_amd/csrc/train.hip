@@ -68,34 +68,29 @@ __global__ void k_gather(const float* __restrict__ src, const int* __restrict__ 
 // stats layout per (group, layer): mean[64] | invstd[64] | sum_g[64] | sum_gz[64]
 __device__ __forceinline__ float* bn_slot(float* stats, int group, int layer) { return stats + ((int64_t)group * 3 + layer) * 256; }
 
-// Reductions over the rows of a group run in two deterministic stages: BN_NCH row chunks per group write double
-// partial sums (fixed-order tree inside the workgroup), one small workgroup per group adds them in chunk order.
-static const int BN_NCH = 32;
-__device__ __forceinline__ void chunk_rows(int64_t M, int ch, int64_t& r0, int64_t& r1) {
-    const int64_t R = ((M + BN_NCH - 1) / BN_NCH + 3) / 4 * 4;
-    r0 = (int64_t)ch * R;
-    r1 = r0 + R < M ? r0 + R : M;
-}
-__device__ __forceinline__ double* bn_part(double* part, int group, int ch) { return part + ((int64_t)group * BN_NCH + ch) * 128; }
+// Reductions over the rows of a group run in two deterministic stages: row tiles of BN_ROWS rows write double partial
+// sums (fixed-order tree inside the workgroup), one small workgroup per group adds its tiles in order.
+static const int BN_ROWS = 256;
+struct BnTile { int group, r0, r1; };
+struct BnInfo { int base, n; };
 
-// stage 1, grid (BN_NCH, groups): per channel sum and sum of squares over the chunk's rows
+// stage 1, one workgroup per row tile: per channel sum and sum of squares
 __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ z, const TrainGroup* __restrict__ groups,
-                                                           TrainDims d, int layer, double* __restrict__ part) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
-    int64_t r0, r1;
-    chunk_rows(M, blockIdx.x, r0, r1);
+                                                           const BnTile* __restrict__ tiles, TrainDims d, int layer,
+                                                           double* __restrict__ part) {
+    const BnTile t = tiles[blockIdx.x];
+    const TrainGroup g = groups[t.group];
     const float* zz = z + (layer == 1 ? act2_off(g, d) : act1_off(g, d));
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int64_t m = r0 + rs; m < r1; m += 4) { const double v = zz[m * CS + c]; s1 += v; s2 += v * v; }
+        for (int m = t.r0 + rs; m < t.r1; m += 4) { const double v = zz[(int64_t)m * CS + c]; s1 += v; s2 += v * v; }
     __shared__ double q1[256], q2[256];
     q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
     __syncthreads();
     if (rs == 0) {
-        double* o = bn_part(part, blockIdx.y, blockIdx.x);
+        double* o = part + (int64_t)blockIdx.x * 128;
         o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
         o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
     }
@@ -103,15 +98,16 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
 
 // stage 2, one 64-thread workgroup per group: batch mean / biased variance, running-stat update (momentum 0.1)
 __global__ __launch_bounds__(64) void k_bn_stats_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
-                                                        TrainDims d, int layer, float* __restrict__ stats,
-                                                        float* __restrict__ pool, int update_running) {
+                                                        const BnInfo* __restrict__ info, TrainDims d, int layer,
+                                                        float* __restrict__ stats, float* __restrict__ pool, int update_running) {
     const TrainGroup g = groups[blockIdx.x];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x;
     if (c >= C) return;
+    const BnInfo bi = info[blockIdx.x];
     double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < BN_NCH; ++ch) { const double* o = part + ((int64_t)blockIdx.x * BN_NCH + ch) * 128; a += o[c]; b += o[64 + c]; }
+    for (int ch = 0; ch < bi.n; ++ch) { const double* o = part + (int64_t)(bi.base + ch) * 128; a += o[c]; b += o[64 + c]; }
     const double mean = a / (double)M;
     double var = b / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -128,44 +124,49 @@ __global__ __launch_bounds__(64) void k_bn_stats_final(const double* __restrict_
     }
 }
 
-// a = relu((z - mean) * invstd * gamma + beta); pad channels -> 0.  grid (ceil(M*52/256), groups)
-__global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ z, float* __restrict__ a,
-                                                        const TrainGroup* __restrict__ groups, TrainDims d, int layer,
+// The channels-last arrays are contiguous over all groups, so the elementwise passes run flat: one thread per float4
+// of a row (13 per row); frow maps the row's (group-major) frequency-row index to its group.
+//   a = relu((z - mean) * invstd * gamma + beta); pad channels -> 0
+__global__ __launch_bounds__(256) void k_bn_relu_apply(const float4* __restrict__ z, float4* __restrict__ a,
+                                                        const TrainGroup* __restrict__ groups, const int* __restrict__ frow,
+                                                        int rows_per_f, int64_t nquads, int layer,
                                                         const float* __restrict__ stats, const float* __restrict__ pool) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * CS) return;
-    const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
-    const int c = (int)(i % CS);
+    if (i >= nquads) return;
+    const int64_t R = i / 13;
+    const int q = (int)(i - R * 13);
+    const int gid = frow[R / rows_per_f];
+    const TrainGroup& g = groups[gid];
     const int C = layer == 1 ? g.C2 : g.C1;
-    float v = 0.f;
-    if (c < C) {
-        const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
-        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
-        v = fmaxf((z[off + i] - st[c]) * st[64 + c] * pool[pb + c] + pool[pb + C + c], 0.f);
+    const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+    const float* st = stats + ((int64_t)gid * 3 + layer) * 256;
+    const float4 v = z[i];
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k;
+        o[k] = c < C ? fmaxf((in[k] - st[c]) * st[64 + c] * pool[pb + c] + pool[pb + C + c], 0.f) : 0.f;
     }
-    a[off + i] = v;
+    a[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward, step 1 (two stages like the statistics): per channel sum(g_bn) and sum(g_bn * zhat), g_bn = g_a * [a > 0]
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ z, const float* __restrict__ a,
                                                          const float* __restrict__ ga, const TrainGroup* __restrict__ groups,
-                                                         TrainDims d, int layer, const float* __restrict__ stats,
-                                                         double* __restrict__ part) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
-    int64_t r0, r1;
-    chunk_rows(M, blockIdx.x, r0, r1);
+                                                         const BnTile* __restrict__ tiles, TrainDims d, int layer,
+                                                         const float* __restrict__ stats, double* __restrict__ part) {
+    const BnTile t = tiles[blockIdx.x];
+    const TrainGroup g = groups[t.group];
     const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
-    const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
+    const float* st = stats + ((int64_t)t.group * 3 + layer) * 256;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         const float mean = st[c], inv = st[64 + c];
-        for (int64_t m = r0 + rs; m < r1; m += 4) {
-            const int64_t i = off + m * CS + c;
+        for (int m = t.r0 + rs; m < t.r1; m += 4) {
+            const int64_t i = off + (int64_t)m * CS + c;
             const float gb = a[i] > 0.f ? ga[i] : 0.f;
             s1 += gb;
             s2 += (double)gb * (double)((z[i] - mean) * inv);
@@ -175,22 +176,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
     __syncthreads();
     if (rs == 0) {
-        double* o = bn_part(part, blockIdx.y, blockIdx.x);
+        double* o = part + (int64_t)blockIdx.x * 128;
         o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
         o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
     }
 }
 
 __global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
-                                                      TrainDims d, int layer, float* __restrict__ stats,
-                                                      float* __restrict__ gpool) {
+                                                      const BnInfo* __restrict__ info, TrainDims d, int layer,
+                                                      float* __restrict__ stats, float* __restrict__ gpool) {
     const TrainGroup g = groups[blockIdx.x];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
     const int C = layer == 1 ? g.C2 : g.C1;
     const int c = threadIdx.x;
     if (c >= C) return;
+    const BnInfo bi = info[blockIdx.x];
     double sg = 0.0, sgz = 0.0;
-    for (int ch = 0; ch < BN_NCH; ++ch) { const double* o = part + ((int64_t)blockIdx.x * BN_NCH + ch) * 128; sg += o[c]; sgz += o[64 + c]; }
+    for (int ch = 0; ch < bi.n; ++ch) { const double* o = part + (int64_t)(bi.base + ch) * 128; sg += o[c]; sgz += o[64 + c]; }
     float* st = bn_slot(stats, blockIdx.x, layer);
     st[128 + c] = (float)(sg / (double)M);
     st[192 + c] = (float)(sgz / (double)M);
@@ -199,27 +201,34 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ 
     gpool[pb + C + c] = (float)sg;     // d beta
 }
 
-// backward, step 2 (in place on ga): g_z = gamma * invstd * (g_bn - mean(g_bn) - zhat * mean(g_bn * zhat))
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ z, const float* __restrict__ a,
-                                                       float* __restrict__ ga, const TrainGroup* __restrict__ groups,
-                                                       TrainDims d, int layer, const float* __restrict__ stats,
-                                                       const float* __restrict__ pool) {
-    const TrainGroup g = groups[blockIdx.y];
-    const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
+// backward, step 2 (flat, in place on ga): g_z = gamma * invstd * (g_bn - mean(g_bn) - zhat * mean(g_bn * zhat))
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float4* __restrict__ z, const float4* __restrict__ a,
+                                                       float4* __restrict__ ga, const TrainGroup* __restrict__ groups,
+                                                       const int* __restrict__ frow, int rows_per_f, int64_t nquads, int layer,
+                                                       const float* __restrict__ stats, const float* __restrict__ pool) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * CS) return;
-    const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
-    const int c = (int)(i % CS);
+    if (i >= nquads) return;
+    const int64_t R = i / 13;
+    const int q = (int)(i - R * 13);
+    const int gid = frow[R / rows_per_f];
+    const TrainGroup& g = groups[gid];
     const int C = layer == 1 ? g.C2 : g.C1;
-    float v = 0.f;
-    if (c < C) {
-        const float* st = stats + ((int64_t)blockIdx.y * 3 + layer) * 256;
-        const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
-        const float zh = (z[off + i] - st[c]) * st[64 + c];
-        const float gb = a[off + i] > 0.f ? ga[off + i] : 0.f;
-        v = pool[pb + c] * st[64 + c] * (gb - st[128 + c] - zh * st[192 + c]);
+    const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
+    const float* st = stats + ((int64_t)gid * 3 + layer) * 256;
+    const float4 zv = z[i], av = a[i], gv = ga[i];
+    const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, ai[4] = {av.x, av.y, av.z, av.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k;
+        o[k] = 0.f;
+        if (c < C) {
+            const float zh = (zi[k] - st[c]) * st[64 + c];
+            const float gb = ai[k] > 0.f ? gi[k] : 0.f;
+            o[k] = pool[pb + c] * st[64 + c] * (gb - st[128 + c] - zh * st[192 + c]);
+        }
     }
-    ga[off + i] = v;
+    ga[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ---- loss gradients ---------------------------------------------------------------------------------
@@ -268,25 +277,31 @@ __global__ __launch_bounds__(256) void k_mask_bwd(const float2* __restrict__ X, 
 }
 
 // ---- layer 4 backward ---------------------------------------------------------------------------------
-// bias: one workgroup per group, both output channels
-__global__ __launch_bounds__(256) void k_l4_bias_grad(const float* __restrict__ gp4, const TrainGroup* __restrict__ groups,
-                                                       TrainDims d, float* __restrict__ gpool) {
-    const TrainGroup g = groups[blockIdx.x];
-    const int64_t ST = (int64_t)d.S * g.T, n = (int64_t)g.F * ST;
-    double s[2] = {0.0, 0.0};
-    for (int b = 0; b < d.Bn; ++b)
-        for (int c = 0; c < 2; ++c) {
-            const float* p = gp4 + r8_idx(g, d, b, c, 0, 0);
-            for (int64_t i = threadIdx.x; i < n; i += 256) s[c] += p[i];
-        }
-    __shared__ double red[2][256];
-    red[0][threadIdx.x] = s[0]; red[1][threadIdx.x] = s[1];
+// bias: stage 1, grid (2B, groups): one (b, c) plane per workgroup -> double partial; stage 2 adds the B planes of a channel
+__global__ __launch_bounds__(256) void k_l4_bias_partial(const float* __restrict__ gp4, const TrainGroup* __restrict__ groups,
+                                                          TrainDims d, double* __restrict__ part) {
+    const TrainGroup g = groups[blockIdx.y];
+    const int64_t n = (int64_t)g.F * d.S * g.T;
+    const float* p = gp4 + r8_idx(g, d, blockIdx.x >> 1, blockIdx.x & 1, 0, 0);
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += p[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
-        if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x < 2) gpool[g.p_b4 + threadIdx.x] = (float)red[threadIdx.x][0];
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * 2 * d.Bn + blockIdx.x] = red[0];
+}
+__global__ void k_l4_bias_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups, int ngroups, TrainDims d,
+                                float* __restrict__ gpool) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * ngroups) return;
+    const int gid = i >> 1, c = i & 1;
+    double s = 0.0;
+    for (int b = 0; b < d.Bn; ++b) s += part[(int64_t)gid * 2 * d.Bn + 2 * b + c];
+    gpool[groups[gid].p_b4 + c] = (float)s;
 }
 
 // ---- weight gradients (wgrad.h) -----------------------------------------------------------------------------
@@ -405,11 +420,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce14(const float* __restrict_
 }
 
 // input whitening: xin = (|X| + mean_f) * scale_f.  gx8 holds the layer-1 data gradient per target in padded
-// coordinates s = tau + pad (layer-4 operator, see cdae_api.h).  One workgroup per (block, f):
+// coordinates s = tau + pad (layer-4 operator, see cdae_api.h).
 //   d mean_f = scale_f * sum g_xin,   d scale_f = sum g_xin * xin / scale_f      (sums over target, b, channel, tau)
-__global__ __launch_bounds__(256) void k_input_grad_reduce(const float* __restrict__ xin, const float* __restrict__ gx8,
-                                                            const float* __restrict__ pool, const TrainGroup* __restrict__ groups,
-                                                            const int2* __restrict__ rows, TrainDims d, float* __restrict__ gpool) {
+// stage 1, grid (sum F, 4B): one (target, b) pair of planes per workgroup; stage 2 adds the 4B partials in order.
+__global__ __launch_bounds__(256) void k_input_grad_partial(const float* __restrict__ xin, const float* __restrict__ gx8,
+                                                             const TrainGroup* __restrict__ groups, const int2* __restrict__ rows,
+                                                             TrainDims d, double* __restrict__ part) {
     const int2 r = rows[blockIdx.x];           // (first group of the block, f)
     const TrainGroup g = groups[r.x];
     const int f = r.y;
@@ -417,13 +433,12 @@ __global__ __launch_bounds__(256) void k_input_grad_reduce(const float* __restri
     const int64_t ST = (int64_t)d.S * g.T, STp = (int64_t)To * g.hop;
     const int pad = d.causal ? g.T - 1 : 0;
     const int64_t s_end = pad + ST < STp ? pad + ST : STp;
-    const float sc = pool[g.p_scale + f];
     const float* gb = gx8 + 4 * (int64_t)d.Bn * To * g.cum;
+    const int b = blockIdx.y % d.Bn;
     double sm = 0.0, ss = 0.0;
-    for (int q = 0; q < 4 * d.Bn * 2; ++q) {              // q = (tgt * Bn + b) * 2 + c
-        const int bc = q % (d.Bn * 2);
-        const float* gr = gb + ((int64_t)q * g.F + f) * STp;
-        const float* xr = xin + r2_idx(g, d, bc >> 1, bc & 1, f, 0) - pad;
+    for (int c = 0; c < 2; ++c) {
+        const float* gr = gb + ((int64_t)(blockIdx.y * 2 + c) * g.F + f) * STp;       // blockIdx.y = tgt * Bn + b
+        const float* xr = xin + r2_idx(g, d, b, c, f, 0) - pad;
         for (int64_t s = pad + threadIdx.x; s < s_end; s += 256) {
             const float gx = gr[s];
             sm += gx;
@@ -437,7 +452,23 @@ __global__ __launch_bounds__(256) void k_input_grad_reduce(const float* __restri
         if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { gpool[g.p_mean + f] = (float)(red[0][0] * sc); gpool[g.p_scale + f] = (float)(red[1][0] / sc); }
+    if (threadIdx.x == 0) {
+        double* o = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 2;
+        o[0] = red[0][0]; o[1] = red[1][0];
+    }
+}
+__global__ void k_input_grad_final(const double* __restrict__ part, const float* __restrict__ pool,
+                                   const TrainGroup* __restrict__ groups, const int2* __restrict__ rows, int nrows, int nplanes,
+                                   float* __restrict__ gpool) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int2 r = rows[i];
+    const TrainGroup& g = groups[r.x];
+    double sm = 0.0, ss = 0.0;
+    for (int k = 0; k < nplanes; ++k) { sm += part[((int64_t)i * nplanes + k) * 2]; ss += part[((int64_t)i * nplanes + k) * 2 + 1]; }
+    const float sc = pool[g.p_scale + r.y];
+    gpool[g.p_mean + r.y] = (float)(sm * sc);
+    gpool[g.p_scale + r.y] = (float)(ss / sc);
 }
 
 // ---- AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments) ----------------------
@@ -473,7 +504,11 @@ struct xsq_train {
     float* d_pool_bwd = nullptr;
     int64_t step = 0;
     std::vector<int32_t> Fv, Tv;
-    struct WgTables { xsq::WgTile *d_t23 = nullptr, *d_t14 = nullptr; xsq::WgGroupInfo *d_i23 = nullptr, *d_i14 = nullptr; int n23 = 0, n14 = 0; };
+    struct WgTables {
+        xsq::WgTile *d_t23 = nullptr, *d_t14 = nullptr; xsq::WgGroupInfo *d_i23 = nullptr, *d_i14 = nullptr; int n23 = 0, n14 = 0;
+        xsq::BnTile *d_bt1 = nullptr, *d_bt2 = nullptr; xsq::BnInfo *d_bi1 = nullptr, *d_bi2 = nullptr; int nbt1 = 0, nbt2 = 0;   // act1-like / act2-like row tiles
+    };
+    int *d_frow1 = nullptr, *d_frow2 = nullptr;    // frequency-row index of the act1-like / act2-like arrays -> group
     std::mutex mu;
     std::map<std::pair<int, int>, WgTables> wg;     // (B, S) -> weight-gradient tile tables
 };
@@ -500,6 +535,24 @@ static void wg_build(const xsq_train* Tr, int Bn, int S, std::vector<WgTile>* t2
     }
 }
 
+static void bn_build(const xsq_train* Tr, int Bn, int S, int kind, std::vector<BnTile>* t, std::vector<BnInfo>* info) {
+    const int T1 = Tr->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    for (int gi = 0; gi < Tr->ngroups; ++gi) {
+        const TrainGroup& g = Tr->groups[gi];
+        const int M = kind == 0 ? Bn * g.F1 * T1 : Bn * g.F2 * T2;
+        const int n = (M + BN_ROWS - 1) / BN_ROWS;
+        info->push_back(BnInfo{(int)t->size(), n});
+        for (int k = 0; k < n; ++k) t->push_back(BnTile{gi, k * BN_ROWS, std::min(M, (k + 1) * BN_ROWS)});
+    }
+}
+
+// doubles of the reduction scratch: BatchNorm row tiles, bias planes, whitening planes
+static size_t part_doubles(const xsq_train* Tr, int Bn, int S) {
+    std::vector<BnTile> a, b; std::vector<BnInfo> ia, ib;
+    bn_build(Tr, Bn, S, 0, &a, &ia); bn_build(Tr, Bn, S, 1, &b, &ib);
+    return std::max({a.size() * 128, b.size() * 128, (size_t)Tr->ngroups * 2 * Bn, (size_t)Tr->sumF * 4 * Bn * 2});
+}
+
 static size_t wg_partial_floats(const xsq_train* Tr, int Bn, int S) {
     std::vector<WgTile> a, b; std::vector<WgGroupInfo> ia, ib;
     wg_build(Tr, Bn, S, &a, &ia, &b, &ib);
@@ -520,6 +573,10 @@ static int wg_tables(xsq_train* Tr, int Bn, int S, xsq_train::WgTables* out) {
         XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(TY), hipMemcpyHostToDevice)); \
     } while (0)
     UPW(w.d_t23, a, WgTile); UPW(w.d_i23, ia, WgGroupInfo); UPW(w.d_t14, b, WgTile); UPW(w.d_i14, ib, WgGroupInfo);
+    std::vector<BnTile> b1, b2; std::vector<BnInfo> j1, j2;
+    bn_build(Tr, Bn, S, 0, &b1, &j1); bn_build(Tr, Bn, S, 1, &b2, &j2);
+    w.nbt1 = (int)b1.size(); w.nbt2 = (int)b2.size();
+    UPW(w.d_bt1, b1, BnTile); UPW(w.d_bi1, j1, BnInfo); UPW(w.d_bt2, b2, BnTile); UPW(w.d_bi2, j2, BnInfo);
 #undef UPW
     Tr->wg[{Bn, S}] = w;
     *out = w;
@@ -538,7 +595,9 @@ int xsq_train_destroy(xsq_train* T) {
     (void)hipFree(T->d_grads); (void)hipFree(T->d_m); (void)hipFree(T->d_v); (void)hipFree(T->d_trainable);
     (void)hipFree(T->d_map_pool); (void)hipFree(T->d_map_mean); (void)hipFree(T->d_map_scale);
     (void)hipFree(T->d_map_bwd); (void)hipFree(T->d_pool_bwd);
-    for (auto& kv : T->wg) { (void)hipFree(kv.second.d_t23); (void)hipFree(kv.second.d_t14); (void)hipFree(kv.second.d_i23); (void)hipFree(kv.second.d_i14); }
+    for (auto& kv : T->wg) { (void)hipFree(kv.second.d_t23); (void)hipFree(kv.second.d_t14); (void)hipFree(kv.second.d_i23); (void)hipFree(kv.second.d_i14);
+        (void)hipFree(kv.second.d_bt1); (void)hipFree(kv.second.d_bt2); (void)hipFree(kv.second.d_bi1); (void)hipFree(kv.second.d_bi2); }
+    (void)hipFree(T->d_frow1); (void)hipFree(T->d_frow2);
     delete T;
     return XSQ_OK;
 }
@@ -665,6 +724,14 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
     UPV(Tr->d_map_mean, map_mean, int);
     UPV(Tr->d_map_scale, map_scale, int);
     UPV(Tr->d_map_bwd, mapb, int);
+    std::vector<int> frow1((size_t)4 * Mo->sumF1), frow2((size_t)4 * Mo->sumF2);
+    for (int gi = 0; gi < Tr->ngroups; ++gi) {
+        const TrainGroup& g = Tr->groups[gi];
+        for (int f = 0; f < g.F1; ++f) frow1[4 * g.cumF1 + g.tgt * g.F1 + f] = gi;
+        for (int f = 0; f < g.F2; ++f) frow2[4 * g.cumF2 + g.tgt * g.F2 + f] = gi;
+    }
+    UPV(Tr->d_frow1, frow1, int);
+    UPV(Tr->d_frow2, frow2, int);
     XSQ_HIP(hipMalloc(&Tr->d_pool_bwd, (size_t)extent * 4));
 #undef UPV
     XSQ_HIP(hipMalloc(&Tr->d_params, (size_t)nparams * 4));
@@ -703,7 +770,7 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
     const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
     size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
-    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt((size_t)Tr->ngroups * BN_NCH * 128 * 8)
+    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt(part_doubles(Tr, Bn, S) * 8)
          + alt(wg_partial_floats(Tr, Bn, S) * 4);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
     if (wiener) b += 2 * alt(xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000)) + 4096;
@@ -736,7 +803,7 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     void* wst = wiener ? take(wst_bytes) : nullptr;
     void* wbst = wiener ? take(wst_bytes) : nullptr;
     float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
-    double* part = (double*)take((size_t)Tr->ngroups * BN_NCH * 128 * 8);
+    double* part = (double*)take(part_doubles(Tr, Bn, S) * 8);
     xsq_train::WgTables wt;
     if (int rcw = wg_tables(Tr, Bn, S, &wt)) return rcw;
     float* wpart = (float*)take(std::max((size_t)wt.n23 * 64 * WgL23Op::NTL, (size_t)wt.n14 * 64 * WgL14Op::NTL) * 4);
@@ -763,21 +830,22 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
         maxR23 = std::max<int64_t>(maxR23, (int64_t)H2 * g.kf * 4 * CS);
     }
     const unsigned G = (unsigned)Tr->ngroups;
+    const int64_t nq1 = (int64_t)na1 / 4, nq2 = (int64_t)na2 / 4;      // float4s of the act1-like / act2-like arrays
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     if ((rc = cdae_launch_layer(Mo, 1, a, stream))) return rc;                       // z1
-    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z1, Tr->d_groups, d, 0, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 0, stats, Tr->d_params, apply_update); }
-    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, Tr->d_groups, d, 0, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, Tr->d_groups, wt.d_bt1, d, 0, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (float4*)a1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     a.act1 = a1; a.act2 = z2;
     if ((rc = cdae_launch_layer(Mo, 2, a, stream))) return rc;                       // z2 from a1
-    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z2, Tr->d_groups, d, 1, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 1, stats, Tr->d_params, apply_update); }
-    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, Tr->d_groups, d, 1, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, Tr->d_groups, wt.d_bt2, d, 1, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (float4*)a2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     a.act2 = a2; a.act3 = z3;
     if ((rc = cdae_launch_layer(Mo, 3, a, stream))) return rc;                       // z3 from a2
-    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z3, Tr->d_groups, d, 2, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 2, stats, Tr->d_params, apply_update); }
-    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, Tr->d_groups, d, 2, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, Tr->d_groups, wt.d_bt1, d, 2, part);
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, Tr->d_params, apply_update); }
+    { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (float4*)a3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     a.act3 = a3;
     if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks, Y = mask * X
     if (wiener) {       // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69)
@@ -794,7 +862,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_mask_bwd", stream); hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d); }
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;
-    { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_grad, dim3(G), dim3(256), 0, stream, gM, Tr->d_groups, d, gp); }
+    { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_partial, dim3(2 * Bn, G), dim3(256), 0, stream, gM, Tr->d_groups, d, part);
+      hipLaunchKernelGGL(k_l4_bias_final, grid1(2 * Tr->ngroups), dim3(256), 0, stream, part, Tr->d_groups, Tr->ngroups, d, gp); }
     { XSQ_PROF("train_l4_wgrad", stream);
       hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
@@ -802,31 +871,32 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
     if ((rc = cdae_launch_layer(Mo, 1, bw, stream, "train_l4_dgrad_gemm"))) return rc;
     bw.xin8 = nullptr;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 2, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, d, 2, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, wt.d_bt1, d, 2, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (const float4*)a3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     { XSQ_PROF("train_l3_wgrad", stream);
       hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
     if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 1, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM2).x, G), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, d, 1, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, wt.d_bt2, d, 1, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (const float4*)a2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     { XSQ_PROF("train_l2_wgrad", stream);
       hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
     if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(BN_NCH, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, d, 0, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid1(maxM1).x, G), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, d, 0, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, wt.d_bt1, d, 0, stats, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (const float4*)a1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     { XSQ_PROF("train_l1_wgrad", stream);
       hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
     bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);
     if ((rc = cdae_launch_layer(Mo, 4, bw, stream, "train_l1_dgrad_gemm"))) return rc;   // gY is free by now
-    { XSQ_PROF("train_input_grad_reduce", stream); hipLaunchKernelGGL(k_input_grad_reduce, dim3((unsigned)Tr->sumF), dim3(256), 0, stream, xin, gY, Tr->d_params, Tr->d_groups, Tr->d_rows, d, gp); }
+    { XSQ_PROF("train_input_grad_reduce", stream); hipLaunchKernelGGL(k_input_grad_partial, dim3((unsigned)Tr->sumF, 4 * Bn), dim3(256), 0, stream, xin, gY, Tr->d_groups, Tr->d_rows, d, part);
+      hipLaunchKernelGGL(k_input_grad_final, grid1(Tr->sumF), dim3(256), 0, stream, part, Tr->d_params, Tr->d_groups, Tr->d_rows, (int)Tr->sumF, 4 * Bn, gp); }
     // ---- update ---------------------------------------------------------------------------------------
     if (apply_update) {
         Tr->step += 1;
