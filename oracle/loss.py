@@ -59,4 +59,4 @@ def training_gradients(plan, sd, x, y_targets, causal: bool, wiener: bool):
     loss = mse + msk
     loss.backward()
     grads = {k: v.grad for k, v in params.items() if isinstance(v, torch.Tensor) and v.requires_grad}
-    return float(loss), float(mse), float(msk), grads
+    return float(loss.detach()), float(mse.detach()), float(msk.detach()), grads
