@@ -267,7 +267,7 @@ struct CdaeL4Op {
         return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + tap) * CS + c3);
     }
     // mask = sigmoid(acc + bias[c]);  Y[target] = mask * X.  Column n = c*hop + dt with n < 2*hop, so
-    // c is a compare; the row split (b, f, u) costs one division pair per lane and is then carried.
+    // c is a compare.
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
         const bool v0 = n < g.N, v1 = wide && n + 32 < g.N;
         const int n1 = n + 32;
@@ -291,34 +291,78 @@ struct CdaeL4Op {
             return;
         }
         const float ba = g.shift[ca], bb = g.shift[cb];
-        const int64_t ST = (int64_t)a.S * g.T;
-        const int64_t FST = (int64_t)g.F * ST;
-        const int64_t xbase = (int64_t)a.Bn * 2 * a.S * g.cum;
-        const int64_t ybase = (int64_t)a.Bn * 8 * a.S * g.cum;
-        int b, f, u;
-        split_row(row0, g.Fo, g.To, b, f, u);
-        const float2* X2 = reinterpret_cast<const float2*>(a.X);
-        float2* Y2 = reinterpret_cast<float2*>(a.Y);
-        int prev = 0;
+        // Rows m = (b, f, u) of one batch item are CONTIGUOUS in time: tau = f*S*T + u*hop = (m - b*F*To)*hop
+        // (To*hop = S*T), so element (b, c, f, tau) of the mix arena and of the target's sub-arena sits at
+        // m*hop + (b + c)*F*S*T: one multiply per row instead of a (b, f, u) split and 64-bit products.
+        const int FST = g.F * a.S * g.T;                      // 2*Bn*FST < 2^31 is checked at launch
+        const int perb = g.Fo * g.To;
+        const float2* X2 = reinterpret_cast<const float2*>(a.X) + (int64_t)a.Bn * 2 * a.S * g.cum;
+        float2* Y2 = reinterpret_cast<float2*>(a.Y) + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST;
+        float* Mk = a.masks ? a.masks + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST : nullptr;
+        const int offa = ca * FST + dta, offb = cb * FST + dtb;
+        // Straight-line code matters here: with per-row / per-column branches the compiler has to place
+        // conservative s_waitcnt vmcnt(0) at every join, and each one also waits for the STORES issued just
+        // before it -- the epilogue then runs at one store round trip per row (measured: 0.67 ms of the
+        // layer's 1.31 ms).  Fast path (every row of the slab valid, at most one batch boundary inside it):
+        // per column block one divergent region holding 16 loads, then 16 sigmoids and 16 stores, no joins.
+        const int slab0 = row0 & ~31;                          // tiles start at multiples of 128, slabs at multiples of 32
+        const int b0 = slab0 / perb;
+        const int next_b = (b0 + 1) * perb;
+        if (slab0 + 32 <= g.M && perb >= 32) {
+            const int obase = row0 * g.hop + b0 * FST, ocut = next_b - row0;     // row r: obase + acc_row(r)*hop (+ FST past the batch boundary)
+            auto off = [&](int r) { return obase + acc_row(r) * g.hop + (acc_row(r) >= ocut ? FST : 0); };
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 4) {
+                if (v0) {
+                    float2 x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = X2[off(r0 + q) + offa];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r0 + q] + ba)));
+                        Y2[off(r0 + q) + offa] = make_float2(mk * x[q].x, mk * x[q].y);
+                    }
+                }
+                if (v1) {
+                    float2 x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = X2[off(r0 + q) + offb];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r0 + q] + bb)));
+                        Y2[off(r0 + q) + offb] = make_float2(mk * x[q].x, mk * x[q].y);
+                    }
+                }
+            }
+            if (Mk) {        // training: the masks as well (second pass, sigmoid recomputed)
+                if (v0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Mk[off(r) + offa] = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
+                }
+                if (v1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Mk[off(r) + offb] = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
+                }
+            }
+            return;
+        }
+        // generic path: ragged last slab, or batch items shorter than a slab
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            u += acc_row(r) - prev; prev = acc_row(r);
-            while (u >= g.To) { u -= g.To; if (++f == g.Fo) { f = 0; ++b; } }
-            if (row0 + acc_row(r) >= g.M) break;
-            const int64_t tau = (int64_t)f * ST + (int64_t)u * g.hop;
-            const int64_t xr = xbase + (int64_t)(b * 2) * FST + tau;
-            const int64_t yr = ybase + (int64_t)((g.tgt * a.Bn + b) * 2) * FST + tau;
+            const int m = row0 + acc_row(r);
+            if (m >= g.M) break;
+            const int o = m * g.hop + (m / perb) * FST;
             if (v0) {
-                const float m = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
-                const float2 x = X2[xr + ca * FST + dta];
-                Y2[yr + ca * FST + dta] = make_float2(m * x.x, m * x.y);
-                if (a.masks) a.masks[yr + ca * FST + dta] = m;
+                const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
+                const float2 x = X2[o + offa];
+                Y2[o + offa] = make_float2(mk * x.x, mk * x.y);
+                if (Mk) Mk[o + offa] = mk;
             }
             if (v1) {
-                const float m = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
-                const float2 x = X2[xr + cb * FST + dtb];
-                Y2[yr + cb * FST + dtb] = make_float2(m * x.x, m * x.y);
-                if (a.masks) a.masks[yr + cb * FST + dtb] = m;
+                const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
+                const float2 x = X2[o + offb];
+                Y2[o + offb] = make_float2(mk * x.x, mk * x.y);
+                if (Mk) Mk[o + offb] = mk;
             }
         }
     }
@@ -563,6 +607,10 @@ int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const
 
 int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name) {
     TileTable tt;
+    if (layer == 4 && !a.gx8)
+        for (const CdaeBlockDev& d : Mo->blocks)
+            XSQ_REQUIRE((int64_t)2 * a.Bn * d.F * a.S * d.T < ((int64_t)1 << 31),
+                        "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block; split the batch", a.Bn, a.S);
     if (layer == 4 && a.gx8) layer = 6;
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt);
     if (rc) return rc;

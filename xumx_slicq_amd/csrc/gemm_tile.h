@@ -21,7 +21,7 @@
 #include "common.h"
 
 // Diagnostic builds only (tools/ablate.sh): bit 0 skip MFMAs, bit 1 skip A global loads,
-// bit 2 skip B global loads, bit 3 skip LDS fragment reads.  0 in the product build.
+// bit 2 skip B global loads, bit 3 skip LDS fragment reads, bit 4 skip the epilogue.  0 in the product build.
 #ifndef XSQ_ABLATE
 #define XSQ_ABLATE 0
 #endif
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     const bool wide = t.narrow == 0;          // wave-uniform
     const typename Op::Group g = op.group(t.group);
-    const int K = g.K;
+    const int K = (XSQ_ABLATE & 32) ? 16 : g.K;      // bit 5: one K-step only (epilogue cost in isolation)
 
     // ---- staging assignment: one float4 (4 consecutive k) of one row per thread and slot ----
     const int s_row = tid >> 2;          // 0..63
@@ -172,6 +172,15 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     }
 
     // ---- epilogue: accumulator register r of this lane is row row0 + acc_row(r), columns n and n+32 ----
+    if (XSQ_ABLATE & 16) {      // diagnostic: no epilogue (keep the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc0[i][r] + acc1[i][r];
+        if (sacc == 1.2345e-30f) __builtin_trap();
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
         op.epilogue(g, t.m0 + (wave * MT + i) * 32 + 4 * lk, t.n0 + lrow, acc0[i], acc1[i], wide);
