@@ -102,6 +102,13 @@ int xsq_slicqt_inverse(xsq_plan* plan, const float* coef, int BC, int S, int64_t
 int xsq_slicqt_inverse_rows(xsq_plan* plan, const float* coef, int BC, int S, int64_t length,
                             float* y, const int64_t* row_offsets, void* workspace,
                             size_t workspace_bytes, void* stream);
+/*   The separator's mix-phase path without the intermediate estimate arena: the coefficients of
+ *   packed channel bc are masks[bc] * mix[bc % BCx], formed while the band DFT loads them
+ *   (phase.py:96-113 fused into nsigtf.py:85-95).  masks: REAL arena, BC channels (what
+ *   xsq_cdae_forward writes with Y = NULL); mix: complex arena, BCx channels.               */
+int xsq_slicqt_inverse_masked(xsq_plan* plan, const float* masks, const float* mix, int BC, int BCx,
+                              int S, int64_t length, float* y, const int64_t* row_offsets,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- CDAE model ----------------------------------------------------------------
  * Replaces Unmix.forward (model.py:69-82) -> _SlicedUnmixCDAE.forward (model.py:213-271)
@@ -122,7 +129,8 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
 int xsq_model_destroy(xsq_model* model);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)
- *   Y      out: mask * X, arena for 8*B channels laid out (4 targets, B, 2, ...)
+ *   Y      out: mask * X, arena for 8*B channels laid out (4 targets, B, 2, ...); NULL (with masks
+ *          given) writes the masks only -- the input xsq_slicqt_inverse_masked expects
  *   masks  out, optional (NULL to skip): sigmoid masks, REAL arena with the geometry of Y
  *          (one float per coefficient) -- Unmix.forward(return_masks=True)             */
 int xsq_cdae_forward(xsq_model* model, const float* X, int B, int S, float* Y, float* masks,

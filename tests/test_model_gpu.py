@@ -269,3 +269,20 @@ def test_hip_graph_replay_matches_eager(seps):
         finally:
             sep.chunk_size = 2621440
         assert torch.equal(ea, ga) and torch.equal(eb, gb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("realtime", [True, False])
+def test_fused_phasemix_decode_is_bitwise_equal(realtime):
+    """Separator's mix-phase path (CDAE writes masks only, xsq_slicqt_inverse_masked forms mask * X while it
+    loads) against decoding the materialised estimates (xsq_cdae_forward with Y + xsq_slicqt_inverse_rows)."""
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.synth import synth_audio
+    sep = seeded_separator(realtime=realtime, wiener=False, chunk_size=60000)
+    x = synth_audio(150000, seed=77, nb_samples=2).cuda()      # two stacked full chunks + a tail
+    sep.fuse_phasemix = True
+    a = sep(x).clone()
+    sep.fuse_phasemix = False
+    b = sep(x).clone()
+    assert torch.equal(a, b)
+    assert a.abs().max() > 1e-3

@@ -55,6 +55,7 @@ _SIGS = {
     "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_slicqt_inverse_masked": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "xsq_model_num_params": (C.c_int64, [C.c_int, _vp, _vp]),
     "xsq_model_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64]),
     "xsq_model_destroy": (C.c_int, [_vp]),

@@ -41,13 +41,19 @@ struct Band4Args {
     float* dst;             // FWD: coefficient arena              INV: Z (row-major phase-ordered, or arena)
     int BC, S, nbins, L;
     int row_len;            // INV: > 0 -> row-major phase-ordered output with rows of row_len complex
+    // INV, optional: the coefficients are mask * mix, formed on the way in (the separator's mix-phase path:
+    // the CDAE then writes only the real masks).  mask = real arena with BC channels; src = the mix arena
+    // with BCx channels, coefficient channel bc reads mix channel bc % BCx.
+    const float* mask;
+    int BCx;
 };
 
-constexpr int D4_BM = 64, D4_LD = 20;
+constexpr int D4_BM = 64, D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
 
 template <bool FWD>
-__global__ __launch_bounds__(256) void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4_BM + 64) * D4_LD];
+    __shared__ __attribute__((aligned(16))) float2 twl[3 * D4_MPAD];      // w^(r t1), r = 1..3, of this tile's band
     float* const As0 = lds;                               // [buf][r][row][20]
     float* const Bs0 = lds + 2 * 4 * D4_BM * D4_LD;       // [buf][col][20]
 
@@ -64,21 +70,50 @@ __global__ __launch_bounds__(256) void band_dft4_kernel(Band4Args a, const TileD
     const bool row_ok = row < M;
     const int bc = row / a.S, s = row - bc * a.S;
     const float* xrow = nullptr;
-    if (row_ok)
-        xrow = FWD ? a.src + (int64_t)row * 2 * a.nbins
-                   : a.src + 2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
+    const float* mrow = nullptr;
+    if (row_ok) {
+        if (FWD) xrow = a.src + (int64_t)row * 2 * a.nbins;
+        else if (!a.mask) xrow = a.src + 2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
+        else {
+            mrow = a.mask + (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
+            xrow = a.src + 2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + s) * Lg);
+        }
+    }
     const float* win = a.pool + bd.win_off;
     const int mpad = (m_ + 7) & ~7;
     const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
+    for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the prologue barrier below
     const float* bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
     const bool b_on = wide || s_row < 32;
 
     float2 gx[4][2];       // quarters a = 0..3, two consecutive t1
-    float2 gt[3][2];       // twiddles r = 1..3
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int g_t1 = 0;          // t1 of the staged pair (twiddles are read from LDS in store_set)
+    struct __attribute__((aligned(8))) F4 { float x, y, z, w; };     // two consecutive complex values, 8-byte aligned
+    struct __attribute__((aligned(4))) F2 { float x, y; };           // two consecutive masks
 
     auto load_set = [&](int k0) {      // k0 = first real k of the K-step (16 per step = 8 complex t1)
         const int t1 = (k0 >> 1) + 2 * s_kq;
+        g_t1 = t1;
+        if (!FWD) {       // synthesis: the pair (t1, t1 + 1) of every quarter is one 16-byte load (+ one 8-byte mask load)
+            const bool ok0 = row_ok && t1 < m_, ok1 = row_ok && t1 + 1 < m_;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                gx[q4][0] = gx[q4][1] = make_float2(0.f, 0.f);
+                const float* p = xrow + 2 * (t1 + q4 * m_);
+                if (ok1) { const F4 v = *reinterpret_cast<const F4*>(p); gx[q4][0] = make_float2(v.x, v.y); gx[q4][1] = make_float2(v.z, v.w); }
+                else if (ok0) gx[q4][0] = *reinterpret_cast<const float2*>(p);
+                if (mrow) {
+                    const float* pm = mrow + t1 + q4 * m_;
+                    float mk0 = 0.f, mk1 = 0.f;
+                    if (ok1) { const F2 v = *reinterpret_cast<const F2*>(pm); mk0 = v.x; mk1 = v.y; }
+                    else if (ok0) mk0 = pm[0];
+                    gx[q4][0].x *= mk0; gx[q4][0].y *= mk0; gx[q4][1].x *= mk1; gx[q4][1].y *= mk1;
+                }
+            }
+            if (b_on) gb = *reinterpret_cast<const float4*>(bp + k0);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int tt = t1 + e;
@@ -97,19 +132,23 @@ __global__ __launch_bounds__(256) void band_dft4_kernel(Band4Args a, const TileD
                         const float gq = win[q];
                         v = make_float2(u.x * gq, cj * u.y * gq);
                     } else {
-                        v = *reinterpret_cast<const float2*>(xrow + 2 * (tt + q4 * m_));
+                        v = *reinterpret_cast<const float2*>(xrow + 2 * (tt + q4 * m_));      // (not reached: synthesis returns above)
                     }
                 }
                 gx[q4][e] = v;
             }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) gt[r][e] = tt < m_ ? tw[r * mpad + tt] : make_float2(0.f, 0.f);
         }
         if (b_on) gb = *reinterpret_cast<const float4*>(bp + k0);
     };
     auto store_set = [&](int buf) {
         float* Aw = As0 + buf * 4 * D4_BM * D4_LD + s_row * D4_LD + 4 * s_kq;
         float4 y[4];
+        float2 gt[3][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {      // t1 even, mpad % 8 == 0: one 16-byte LDS read per residue (zeros of the padded table past m)
+            const float4 w = g_t1 + 1 < mpad ? *reinterpret_cast<const float4*>(&twl[r * mpad + g_t1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gt[r][0] = make_float2(w.x, w.y); gt[r][1] = make_float2(w.z, w.w);
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float2 x0 = gx[0][e], x1 = gx[1][e], x2 = gx[2][e], x3 = gx[3][e];
@@ -142,6 +181,7 @@ __global__ __launch_bounds__(256) void band_dft4_kernel(Band4Args a, const TileD
 
     const int lrow = lane & 31, lk = lane >> 5;
     load_set(0);
+    __syncthreads();             // twiddle table complete
     store_set(0);
     __syncthreads();
     int cur = 0;

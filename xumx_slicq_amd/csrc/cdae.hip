@@ -311,6 +311,17 @@ struct CdaeL4Op {
         if (slab0 + 32 <= g.M && perb >= 32) {
             const int obase = row0 * g.hop + b0 * FST, ocut = next_b - row0;     // row r: obase + acc_row(r)*hop (+ FST past the batch boundary)
             auto off = [&](int r) { return obase + acc_row(r) * g.hop + (acc_row(r) >= ocut ? FST : 0); };
+            if (!a.Y) {      // masks only (the inverse transform multiplies by the mix on its way in)
+                if (v0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Mk[off(r) + offa] = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
+                }
+                if (v1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Mk[off(r) + offb] = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
+                }
+                return;
+            }
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 4) {
                 if (v0) {
@@ -354,14 +365,12 @@ struct CdaeL4Op {
             const int o = m * g.hop + (m / perb) * FST;
             if (v0) {
                 const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)));
-                const float2 x = X2[o + offa];
-                Y2[o + offa] = make_float2(mk * x.x, mk * x.y);
+                if (a.Y) { const float2 x = X2[o + offa]; Y2[o + offa] = make_float2(mk * x.x, mk * x.y); }
                 if (Mk) Mk[o + offa] = mk;
             }
             if (v1) {
                 const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)));
-                const float2 x = X2[o + offb];
-                Y2[o + offb] = make_float2(mk * x.x, mk * x.y);
+                if (a.Y) { const float2 x = X2[o + offb]; Y2[o + offb] = make_float2(mk * x.x, mk * x.y); }
                 if (Mk) Mk[o + offb] = mk;
             }
         }
@@ -633,7 +642,7 @@ extern "C" {
 
 int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, float* masks, void* ws,
                      size_t ws_bytes, void* stream_) {
-    XSQ_REQUIRE(Mo && X && Y && ws, "xsq_cdae_forward: null argument");
+    XSQ_REQUIRE(Mo && X && (Y || masks) && ws, "xsq_cdae_forward: null argument");
     XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_cdae_forward: Bn=%d S=%d (the conv stack needs >= 3 slices)", Bn, S);
     XSQ_REQUIRE(ws_bytes >= xsq_cdae_workspace(Mo, Bn, S), "xsq_cdae_forward: workspace too small");
     hipStream_t stream = (hipStream_t)stream_;

@@ -98,6 +98,7 @@ struct BandGroup {
     const float* B;
     int Lg, bin0, f, F;
     int64_t base;  // float offset of (bc=0, f, s=0) of this band in the arena
+    int64_t cum;   // complex coefficients per channel-slice before this band's block
 };
 
 // coef = U_window x Wf
@@ -118,6 +119,7 @@ struct BandFwdOp {
         g.M = BC * S; g.N = 2 * b.Lg; g.K = 2 * b.Lg; g.ldb = b.ldw; g.B = W + b.w_off;
         g.Lg = b.Lg; g.bin0 = b.bin0; g.f = b.f; g.F = b.F;
         g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
+        g.cum = b.cum;
         return g;
     }
     __device__ RowA row_a(const Group& g, int m) const {
@@ -158,6 +160,7 @@ struct BandInvOp {
     typedef BandGroup Group;
     struct RowA {
         const float* p;
+        const float* mk;
     };
     const float* coef;
     float* Z;
@@ -165,6 +168,8 @@ struct BandInvOp {
     const float* W;
     int BC, S;
     int row_len;   // > 0: write row-major, phase-ordered (rows of row_len complex entries) for k_slice_irfft
+    const float* mask;   // optional: coefficients = mask * mix (see Band4Args); coef is then the mix arena, BCx channels
+    int BCx;
 
     __device__ Group group(int j) const {
         const BandDev b = bands[j];
@@ -172,6 +177,7 @@ struct BandInvOp {
         g.M = BC * S; g.N = 2 * b.Lg; g.K = 2 * b.Lg; g.ldb = b.ldw; g.B = W + b.w_off;
         g.Lg = b.Lg; g.bin0 = b.ent; g.f = b.f; g.F = b.F;   // bin0 slot carries the entry offset here
         g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
+        g.cum = b.cum;
         return g;
     }
     __device__ int64_t row_off(const Group& g, int m) const {
@@ -180,12 +186,22 @@ struct BandInvOp {
     }
     __device__ RowA row_a(const Group& g, int m) const {
         RowA r;
-        r.p = m < g.M ? coef + row_off(g, m) : nullptr;
+        r.p = nullptr; r.mk = nullptr;
+        if (m >= g.M) return r;
+        if (!mask) { r.p = coef + row_off(g, m); return r; }
+        const int bc = m / S, s = m - bc * S;
+        r.mk = mask + row_off(g, m) / 2;
+        r.p = coef + 2 * ((int64_t)BCx * S * g.cum + (int64_t)g.f * S * g.Lg) + ((int64_t)(bc % BCx) * g.F * S + s) * (2 * g.Lg);
         return r;
     }
     __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
         if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
+        float4 v = *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
+        if (r.mk) {
+            const float2 mk = *reinterpret_cast<const float2*>(r.mk + (k >> 1));
+            v.x *= mk.x; v.y *= mk.x; v.z *= mk.y; v.w *= mk.y;
+        }
+        return v;
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
         const bool c0 = n < g.N, c1 = wide && n + 32 < g.N;
@@ -482,7 +498,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
         auto alloc2 = [&](size_t n) { size_t o = pf.size(); pf.resize(o + n, 0.f); pi.resize(o + n, 0.f); return (int64_t)o; };
         for (int j = 0; j < nbands; ++j) {
             const BandDev& b = P->bands[j];
-            if (b.Lg < 64) { P->bands4_small.push_back(j); continue; }
+            if (b.Lg < 64 || b.Lg > 4 * D4_MPAD) { P->bands4_small.push_back(j); continue; }   // dense engine (gemm_tile.h)
             const int n = b.Lg, m = n / 4;
             Band4Dev d;
             memset(&d, 0, sizeof(d));
@@ -640,7 +656,7 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
         TileTable t4;
         rc = get_dft4_tiles(P, rows, &t4);
         if (rc) return rc;
-        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0};
+        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0};
         XSQ_PROF("band_analysis_dft4", stream);
         hipLaunchKernelGGL(band_dft4_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
@@ -665,8 +681,23 @@ int xsq_slicqt_inverse(xsq_plan* P, const float* coef, int BC, int S, int64_t le
     return xsq_slicqt_inverse_rows(P, coef, BC, S, length, y, nullptr, ws, ws_bytes, stream_);
 }
 
+static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int BCx, int BC, int S, int64_t length, float* y,
+                        const int64_t* row_offsets, void* ws, size_t ws_bytes, void* stream_);
+
 int xsq_slicqt_inverse_rows(xsq_plan* P, const float* coef, int BC, int S, int64_t length, float* y,
                             const int64_t* row_offsets, void* ws, size_t ws_bytes, void* stream_) {
+    return inverse_impl(P, coef, nullptr, 0, BC, S, length, y, row_offsets, ws, ws_bytes, stream_);
+}
+
+int xsq_slicqt_inverse_masked(xsq_plan* P, const float* masks, const float* mix, int BC, int BCx, int S, int64_t length,
+                              float* y, const int64_t* row_offsets, void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(masks && mix, "xsq_slicqt_inverse_masked: null argument");
+    XSQ_REQUIRE(BCx > 0 && BC % BCx == 0, "xsq_slicqt_inverse_masked: %d mix channels do not divide %d mask channels", BCx, BC);
+    return inverse_impl(P, mix, masks, BCx, BC, S, length, y, row_offsets, ws, ws_bytes, stream_);
+}
+
+static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int BCx, int BC, int S, int64_t length, float* y,
+                        const int64_t* row_offsets, void* ws, size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(P && coef && y && ws, "xsq_slicqt_inverse: null argument");
     XSQ_REQUIRE(BC > 0 && S >= 2 && length > 0, "xsq_slicqt_inverse: BC=%d S=%d length=%lld", BC, S,
                 (long long)length);
@@ -691,13 +722,13 @@ int xsq_slicqt_inverse_rows(xsq_plan* P, const float* coef, int BC, int S, int64
     TileTable tt;
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
-    BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0};
+    BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
         rc = get_dft4_tiles(P, rows, &t4);
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
-                     lds_fft(P) ? (int)P->sumFT : 0};
+                     lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
         XSQ_PROF("band_synthesis_dft4", stream);
         hipLaunchKernelGGL(band_dft4_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }

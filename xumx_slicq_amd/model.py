@@ -181,6 +181,28 @@ class Unmix(nn.Module):
         return ws
 
     # -- forward -----------------------------------------------------------------------
+    def masks_arena(self, Xcomplex: List[Tensor]):
+        """Mix-phase models only: (masks, X, B, S) with ``masks`` the real arena (4, B, 2, ...) of sigmoid
+        masks and ``X`` the mix arena -- the estimate Y = masks * X is left to the consumer
+        (``SliCQEngine.backward_masked`` forms it while it loads; Separator.forward uses this)."""
+        X, lead, S = self.table.as_arena(list(Xcomplex))
+        if len(lead) != 2 or lead[1] != 2:
+            raise ValueError(f"expected blocks of shape (nb_samples, 2, F, S, T, 2); got lead dims {lead}")
+        if not all(bool(blk.realtime) for blk in self.sliced_umx):
+            raise _lib.XsqError("masks_arena: the Wiener-EM post-filter needs the estimates; use forward()")
+        B = lead[0]
+        dev = X.device
+        h = self._model(dev)
+        with torch.cuda.device(dev):
+            masks = torch.empty(self.table.numel(8 * B, S, complex_=False), dtype=torch.float32, device=dev)
+            nbytes = _lib.lib.xsq_cdae_workspace(h, B, S)
+            if nbytes == 0:
+                raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
+            ws = self._workspace(dev, nbytes)
+            _lib.check(_lib.lib.xsq_cdae_forward(h, X.data_ptr(), B, S, None, masks.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
+        return masks, X, B, S
+
     def forward(self, Xcomplex: List[Tensor], return_masks=False, wiener_batch_group: int = 0):
         """list over blocks of (B, 2, F_b, S, T_b, 2) -> list of (4, B, 2, F_b, S, T_b, 2)
         [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82.  ``wiener_batch_group`` (extension):

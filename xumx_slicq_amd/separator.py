@@ -8,6 +8,8 @@ outside the accelerated path.
 """
 from __future__ import annotations
 
+import os
+
 import json
 import sys
 from pathlib import Path
@@ -117,9 +119,19 @@ class Separator(nn.Module):
         rows = (torch.arange(4, device=dev).view(4, 1, 1, 1) * nb + torch.arange(nb, device=dev).view(1, 1, nb, 1)) * 2 \
             + torch.arange(2, device=dev).view(1, 1, 1, 2)                       # (4, 1, nb, 2) row of `out`
 
-        def decode(Ylist, length, offsets):
+        # mix-phase models: the CDAE writes the masks only and the inverse transform forms mask * X while it
+        # loads (same products, same order: bitwise equal to decoding the materialised estimates)
+        fused = getattr(self, "fuse_phasemix", os.environ.get("XSQ_FUSE_PHASEMIX", "1") != "0") and all(bool(b.realtime) for b in self.xumx_model.sliced_umx)
+
+        def decode(Xc, length, offsets, group=0):
+            offs = offsets.reshape(-1).contiguous()
+            if fused:
+                masks, X, B, S = self.xumx_model.masks_arena(Xc)
+                eng.backward_masked(masks, X, 8 * B, 2 * B, S, length, out, offs)
+                return
+            Ylist = self.xumx_model(Xc, wiener_batch_group=group)
             arena, lead, S = eng.table.as_arena(list(Ylist))
-            eng.backward(arena, offsets.numel(), S, length, out=out, row_offsets=offsets.reshape(-1).contiguous())
+            eng.backward(arena, offs.numel(), S, length, out=out, row_offsets=offs)
 
         full = N // cs if getattr(self, "batch_chunks", True) else 0
         start0 = 0
@@ -129,9 +141,8 @@ class Separator(nn.Module):
         while full - start0 // cs >= 2 and per_pass >= 2:
             k = min(per_pass, full - start0 // cs)
             a = audio_big[..., start0:start0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
-            Y = self.xumx_model(self.nsgt(a), wiener_batch_group=nb)             # batch = (chunk, b)
             offs = rows * N + start0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
-            decode(Y, cs, offs)
+            decode(self.nsgt(a), cs, offs, group=nb)                             # batch = (chunk, b)
             start0 += k * cs
         for start in range(start0, N, cs):
             audio = audio_big[..., start:min(start + cs, N)]
@@ -139,7 +150,7 @@ class Separator(nn.Module):
             if n_samples < min_samples:
                 audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
                                                       device=dev, dtype=audio.dtype)], dim=-1)
-            decode(self.xumx_model(self.nsgt(audio)), n_samples, rows * N + start)
+            decode(self.nsgt(audio), n_samples, rows * N + start)
         return out
 
     @staticmethod

@@ -138,6 +138,24 @@ class SliCQEngine:
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_slicqt_inverse_rows")
         return y
 
+    def backward_masked(self, masks: Tensor, mix: Tensor, BC: int, BCx: int, S: int, length: int, out: Tensor,
+                        row_offsets: Tensor) -> Tensor:
+        """Inverse transform of masks[bc] * mix[bc % BCx] without materialising the product
+        (the separator's mix-phase path): masks = real arena for BC channels, mix = complex arena
+        for BCx channels.  Output placement as in ``backward``."""
+        h = self.handle(masks.device)
+        with torch.cuda.device(masks.device):
+            nbytes = _lib.lib.xsq_slicqt_inverse_workspace(h, BC, S)
+            if nbytes == 0:
+                raise _lib.XsqError("xsq_slicqt_inverse_workspace: " + _lib.last_error())
+            ws = self.workspace(masks.device, nbytes)
+            assert row_offsets.dtype == torch.int64 and row_offsets.numel() == BC
+            assert out.is_contiguous() and out.dtype == torch.float32
+            _lib.check(_lib.lib.xsq_slicqt_inverse_masked(
+                h, masks.data_ptr(), mix.data_ptr(), BC, BCx, S, length, out.data_ptr(), row_offsets.data_ptr(),
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_slicqt_inverse_masked")
+        return out
+
 
 class NSGTBase(nn.Module):
     """transforms.py:21-94.  Holds the plan; `.nsgt` is the device engine."""
