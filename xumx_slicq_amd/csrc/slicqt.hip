@@ -252,16 +252,22 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
 }
 
 // radix-4 kernel tiles: 64 rows x 64 (or 32) real columns of the m-point DFT
-static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out) {
+// `share` > 0 (masked synthesis): rows r and r + share, r + 2*share, ... read the same mix rows (the targets of one
+// (sample, channel, slice)); their tiles are made neighbours so the mix is fetched once per XCD.  When share is not a
+// multiple of the tile height the last tile of a copy runs into the next copy's first rows and recomputes them
+// (same values, written twice).
+static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) {
     std::lock_guard<std::mutex> lk(P->mu);
-    auto key = std::make_tuple(1, rows, 0);
+    auto key = std::make_tuple(1, rows, share);
     auto it = P->tiles.find(key);
     if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
     std::vector<TileDev> t;
+    const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
     for (int i = P->nbands4 - 1; i >= 0; --i) {
         const int N = 2 * P->bands4_m[i];
-        for (int m0 = 0; m0 < rows; m0 += D4_BM)
-            for (int n0 = 0; n0 < N; n0 += 64) t.push_back(TileDev{i, m0, n0, (N - n0 <= 32) ? 1 : 0});
+        for (int m0 = 0; m0 < span; m0 += D4_BM)
+            for (int n0 = 0; n0 < N; n0 += 64)
+                for (int k = 0; k < copies; ++k) t.push_back(TileDev{i, m0 + k * span, n0, (N - n0 <= 32) ? 1 : 0});
     }
     TileTable tt;
     int rc = upload_tiles(t, &tt);
@@ -725,7 +731,7 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
-        rc = get_dft4_tiles(P, rows, &t4);
+        rc = get_dft4_tiles(P, rows, &t4, mask ? BCx * S : 0);
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
                      lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
