@@ -189,6 +189,26 @@ def test_batched_chunks_equal_the_literal_chunk_loop(seps, name):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener"])
+def test_tail_chunk_beside_the_stacked_pass_is_bitwise_equal(seps, name):
+    """Separator.forward issues the tail chunk on a side stream (own workspaces) beside the stacked pass;
+    repeated calls and the serial order (overlap_tail = False) must give the same bits."""
+    sep = seps[name]
+    sep.chunk_size = 60000
+    x = synth_audio(60000 * 4 + 23456, seed=78).cuda()
+    try:
+        sep.overlap_tail = False
+        a = sep(x).clone()
+        sep.overlap_tail = True
+        outs = [sep(x).clone() for _ in range(3)]
+    finally:
+        sep.overlap_tail = True
+        sep.chunk_size = 2621440
+    torch.cuda.synchronize()
+    for b in outs:
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n", [1, 777, 9030, 9031])
 def test_clips_shorter_than_one_slice_are_zero_padded_like_the_reference(seps, oracle_plan, seeded_sd, n):
     """separator.py:162-168: clips below sllen/2+1 samples are zero-padded, the stems cropped back."""

@@ -172,7 +172,8 @@ class Unmix(nn.Module):
             pass
 
     def _workspace(self, device, nbytes):
-        key = device.index if device.index is not None else torch.cuda.current_device()
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)      # per stream: see SliCQEngine.workspace
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             self._ws[key] = None

@@ -18,7 +18,8 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)          # per stream: see SliCQEngine.workspace
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         _WS[key] = None

@@ -138,19 +138,45 @@ class Separator(nn.Module):
         # stack at most `max_stack` (chunk, sample) pairs per pass: bounds the workspaces (~1.8 GB per
         # stacked full chunk) and keeps BC*S inside one launch for any track length
         per_pass = max(1, getattr(self, "max_stack", 8) // nb)
+        stacked = []                                                                 # (first sample, chunks)
         while full - start0 // cs >= 2 and per_pass >= 2:
             k = min(per_pass, full - start0 // cs)
-            a = audio_big[..., start0:start0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
-            offs = rows * N + start0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
-            decode(self.nsgt(a), cs, offs, group=nb)                             # batch = (chunk, b)
+            stacked.append((start0, k))
             start0 += k * cs
-        for start in range(start0, N, cs):
-            audio = audio_big[..., start:min(start + cs, N)]
-            n_samples = audio.shape[-1]
-            if n_samples < min_samples:
-                audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
-                                                      device=dev, dtype=audio.dtype)], dim=-1)
-            decode(self.nsgt(audio), n_samples, rows * N + start)
+
+        def rest(first):
+            for start in range(first, N, cs):
+                audio = audio_big[..., start:min(start + cs, N)]
+                n_samples = audio.shape[-1]
+                if n_samples < min_samples:
+                    audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
+                                                          device=dev, dtype=audio.dtype)], dim=-1)
+                decode(self.nsgt(audio), n_samples, rows * N + start)
+
+        if not stacked:
+            rest(0)
+            return out
+        # The remaining chunks (the short tail of the track) are launch-bound -- a dozen kernels of a few
+        # hundred workgroups each -- and independent of the stacked pass: they go out FIRST, on a side stream
+        # with its own workspaces, and fill in beside the big launches instead of running after them.
+        main = torch.cuda.current_stream(dev)
+        tail_first = stacked[-1][0] + stacked[-1][1] * cs
+        side = None
+        if tail_first < N and getattr(self, "overlap_tail", True):
+            side = self.__dict__.setdefault("_side_streams", {}).get(dev.index)
+            if side is None:
+                side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rest(tail_first)
+        for (s0, k) in stacked:
+            a = audio_big[..., s0:s0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
+            offs = rows * N + s0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
+            decode(self.nsgt(a), cs, offs, group=nb)                             # batch = (chunk, b)
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            rest(tail_first)
         return out
 
     @staticmethod

@@ -79,8 +79,10 @@ class SliCQEngine:
         return h
 
     def workspace(self, device: torch.device, nbytes: int) -> Tensor:
-        """Grow-only scratch buffer per device (PyTorch owns the memory)."""
-        key = device.index if device.index is not None else torch.cuda.current_device()
+        """Grow-only scratch buffer per (device, stream): calls issued on different streams may overlap
+        (Separator.forward runs the tail chunk beside the stacked pass). PyTorch owns the memory."""
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = None
