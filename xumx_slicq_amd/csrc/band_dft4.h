@@ -50,8 +50,11 @@ struct Band4Args {
 
 constexpr int D4_BM = 64, D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
 
+#ifndef XSQ_D4_WPE
+#define XSQ_D4_WPE __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 template <bool FWD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
+__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4_BM + 64) * D4_LD];
     __shared__ __attribute__((aligned(16))) float2 twl[3 * D4_MPAD];      // w^(r t1), r = 1..3, of this tile's band
     float* const As0 = lds;                               // [buf][r][row][20]

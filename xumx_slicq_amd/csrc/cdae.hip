@@ -20,6 +20,7 @@
 
 #include "../../include/xumx_slicq_hip.h"
 #include "gemm_tile.h"
+#include "gemm_tile_bf3.h"
 #include "plan.h"
 #include "prof.h"
 
@@ -583,6 +584,13 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
     return XSQ_OK;
 }
 
+int xsq_model_set_precision(xsq_model* Mo, int mode) {
+    XSQ_REQUIRE(Mo, "xsq_model_set_precision: null model");
+    XSQ_REQUIRE(mode == 0 || mode == 1, "xsq_model_set_precision: mode %d (0 = fp32, 1 = split bf16)", mode);
+    Mo->precision = mode;
+    return XSQ_OK;
+}
+
 int xsq_model_destroy(xsq_model* Mo) {
     if (!Mo) return XSQ_OK;
     for (auto& kv : Mo->tiles) (void)hipFree(kv.second.d_tiles);
@@ -623,16 +631,19 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     if (layer == 4 && a.gx8) layer = 6;
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt);
     if (rc) return rc;
+    const bool bf3 = Mo->precision == 1 && !a.raw && !a.xin8 && !a.gx8;      // inference operators only
+#define XSQ_LAUNCH(OP, MT_)                                                                                         \
+    do {                                                                                                            \
+        if (bf3) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
+        else hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
+    } while (0)
     switch (layer) {
-        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream);
-            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL1Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL1Op{a}, tt.d_tiles, tt.ntiles); } break;
-        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream);
-            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL2Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL2Op{a}, tt.d_tiles, tt.ntiles); } break;
-        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream);
-            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL3Op, L23_MT>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL3Op{a}, tt.d_tiles, tt.ntiles); } break;
-        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
-            hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL4Op{a}, tt.d_tiles, tt.ntiles); } break;
+        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1); } break;
+        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); XSQ_LAUNCH(CdaeL2Op, L23_MT); } break;
+        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); XSQ_LAUNCH(CdaeL3Op, L23_MT); } break;
+        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream); XSQ_LAUNCH(CdaeL4Op, 1); } break;
     }
+#undef XSQ_LAUNCH
     return XSQ_OK;
 }
 

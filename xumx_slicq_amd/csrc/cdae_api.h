@@ -27,6 +27,7 @@ struct CdaeBlockDev {
 
 struct xsq_model {
     int causal = 0;
+    int precision = 0;             // 0 fp32 MFMA, 1 split-bf16 MFMA (xsq_model_set_precision)
     int nblocks = 0;
     int64_t sumFT = 0;             // complex coefficients per channel-slice
     std::vector<xsq::BlockHost> table;

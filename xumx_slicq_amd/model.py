@@ -24,6 +24,11 @@ from . import _lib
 from .arena import BlockTable
 from .weights import freq_filter
 
+import os
+
+# xsq_model_set_precision modes (include/xumx_slicq_hip.h)
+_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
 
 class _CausalConv2d(Conv2d):
     """model.py:274-290: left-pads time by kernel_width-1 (parameter holder here)."""
@@ -105,6 +110,9 @@ class Unmix(nn.Module):
         self._T = np.asarray([s[1] for s in shapes], dtype=np.int32)
         self._handles = {}      # device index -> (version, handle)
         self._ws = {}
+        self.precision = os.environ.get("XSQ_CDAE_PRECISION", "fp32")
+        if self.precision not in _PRECISIONS:
+            raise ValueError(f"XSQ_CDAE_PRECISION={self.precision!r} not in {sorted(_PRECISIONS)}")
 
     def freeze(self):
         for p in self.parameters():
@@ -161,8 +169,18 @@ class Unmix(nn.Module):
             _lib.check(_lib.lib.xsq_model_create(
                 C.byref(out), len(self.table), self._F.ctypes.data, self._T.ctypes.data,
                 1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
+        _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
         self._handles[idx] = (ver, out)
         return out
+
+    def set_precision(self, precision: str):
+        """Arithmetic of the convolution contractions: "fp32" (exact, v_mfma_f32_32x32x2_f32) or "bf16x3"
+        (fp32 operands split into hi + lo bf16, three bf16 MFMAs per product, fp32 accumulation)."""
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision {precision!r} not in {sorted(_PRECISIONS)}")
+        self.precision = precision
+        for (_ver, h) in self._handles.values():
+            _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
 
     def __del__(self):
         try:

@@ -157,25 +157,34 @@ class Separator(nn.Module):
             rest(0)
             return out
         # The remaining chunks (the short tail of the track) are launch-bound -- a dozen kernels of a few
-        # hundred workgroups each -- and independent of the stacked pass: they go out FIRST, on a side stream
-        # with its own workspaces, and fill in beside the big launches instead of running after them.
+        # hundred workgroups each -- and independent of the stacked passes: they go out FIRST, on a side stream
+        # with its own workspaces, and fill in beside the big launches instead of running after them.  The
+        # stacked passes themselves are dealt to `pass_streams` streams (default 1: all on the caller's).
         main = torch.cuda.current_stream(dev)
         tail_first = stacked[-1][0] + stacked[-1][1] * cs
-        side = None
-        if tail_first < N and getattr(self, "overlap_tail", True):
-            side = self.__dict__.setdefault("_side_streams", {}).get(dev.index)
-            if side is None:
-                side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        pool = self.__dict__.setdefault("_side_streams", {}).setdefault(dev.index, [])
+        nstreams = max(1, min(int(getattr(self, "pass_streams", 1)), len(stacked)))
+        overlap_tail = tail_first < N and getattr(self, "overlap_tail", True)
+        while len(pool) < nstreams:                       # pool[0] = tail, pool[1:] = extra pass streams
+            pool.append(torch.cuda.Stream(device=dev))
+        used = []
+        if overlap_tail:
+            pool[0].wait_stream(main)
+            used.append(pool[0])
+            with torch.cuda.stream(pool[0]):
                 rest(tail_first)
-        for (s0, k) in stacked:
-            a = audio_big[..., s0:s0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
-            offs = rows * N + s0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
-            decode(self.nsgt(a), cs, offs, group=nb)                             # batch = (chunk, b)
-        if side is not None:
-            main.wait_stream(side)
-        else:
+        for i, (s0, k) in enumerate(stacked):
+            st = main if i % nstreams == 0 else pool[i % nstreams]
+            if st is not main and st not in used:
+                st.wait_stream(main)
+                used.append(st)
+            with torch.cuda.stream(st):
+                a = audio_big[..., s0:s0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
+                offs = rows * N + s0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
+                decode(self.nsgt(a), cs, offs, group=nb)                         # batch = (chunk, b)
+        for st in used:
+            main.wait_stream(st)
+        if not overlap_tail:
             rest(tail_first)
         return out
 
