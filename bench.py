@@ -34,6 +34,7 @@ CHUNK = 2_621_440
 FS = 44100.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (split-bf16: three MFMAs per product)
 
 
 def algorithmic_work(plan, B, chunk_lengths, wiener):
@@ -142,6 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="arithmetic of the convolution contractions for the headline value (default: exact fp32)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (Separator.forward_graphed)")
     ap.add_argument("--gather", action="store_true",
@@ -179,6 +183,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # keep stdout to the one JSON line
         sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
+    sep.xumx_model.set_precision(args.precision)
     # inputs are resident in HBM before timing starts; without --gather a rank only ever touches
     # its own track, so only that one is materialised
     if args.gather:
@@ -212,6 +217,29 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.profile_enable(False)
+
+    # Extra, outside the timed region, N = 1 only: the same step with the convolution contractions on the
+    # split-bf16 matrix path (xsq_model_set_precision 1), and its stems against the fp32 stems just produced.
+    variants = None
+    if world == 1 and not args.no_variants and args.precision == "fp32":
+        ref_out = out.clone()
+        sep.xumx_model.set_precision("bf16x3")
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(args.steps):
+            vout = step()
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv
+        d = (vout - ref_out).double()
+        variants = {"bf16x3": {
+            "what": "conv contractions as 3 x bf16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; everything else unchanged",
+            "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
+            "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
+                              "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}}
+        sep.xumx_model.set_precision("fp32")
+        del ref_out, vout, d
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,6 +263,8 @@ def main():
                 ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
             else:
                 ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+                if args.precision == "bf16x3" and dom.startswith("cdae_"):
+                    peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)      # useful flops at three bf16 MFMAs per product
             roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                         "avg_launch_ms": round(ms / launches, 4), "launches": launches,
@@ -245,7 +275,9 @@ def main():
             "metric": "real-time factor (audio-s demixed / wall-s), 44.1 kHz stereo, offline model",
             "value": round(audio_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
                                    "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
                                    % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
@@ -254,6 +286,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if variants:
+            result["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:

@@ -306,3 +306,85 @@ def test_fused_phasemix_decode_is_bitwise_equal(realtime):
     b = sep(x).clone()
     assert torch.equal(a, b)
     assert a.abs().max() > 1e-3
+
+
+# ---- split-bf16 ("bf16x3") convolution contractions: xsq_model_set_precision(1) ---------------------------
+# Every fp32 operand is carried as hi + lo bf16 and every product as three bf16 MFMAs with fp32 accumulation
+# (csrc/gemm_tile_bf3.h; layers 2/3 of long inputs on csrc/cdae_slab.h).  The bar is BASELINE.json's own:
+# stems within 1e-4 RMS / 1e-3 max-abs of the torch-cpu reference; measured 1.2e-6 / 1.4e-5.
+@pytest.fixture()
+def bf16x3(seps):
+    for s in seps.values():
+        s.xumx_model.set_precision("bf16x3")
+    yield seps
+    for s in seps.values():
+        s.xumx_model.set_precision("fp32")
+        s.chunk_size = 2621440
+
+
+@pytest.mark.parametrize("n", [9031, 100000])
+@pytest.mark.parametrize("name", ["realtime", "offline_phasemix", "offline_wiener"])
+def test_bf16x3_stems_match_reference_golden(bf16x3, n, name):
+    g = load_golden(f"stems_{n}.npz")
+    sep = bf16x3[name]
+    sep.chunk_size = int(g["chunk_size"])
+    x = synth_audio(n, seed=20260101 + n).cuda()
+    est = sep(x)
+    ref = torch.from_numpy(g[name])
+    got = est.cpu() if n == 9031 else est.cpu()[..., ::7]
+    d = got - ref
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert rms < RMS_TOL and mx < MAX_TOL, (name, n, rms, mx)
+    assert rms < 1e-5 and mx < 1e-4, ("bf16x3 is expected an order of magnitude inside the bar", name, n, rms, mx)
+
+
+def test_bf16x3_masks_match_golden(bf16x3):
+    g = load_golden("cdae_masks_70000.npz")
+    n = int(g["n"])
+    x = synth_audio(n, seed=20260101 + n).cuda()
+    for name, tag in (("offline_wiener", "offline"), ("realtime", "causal")):
+        sep = bf16x3[name]
+        Y, masks = sep.xumx_model(sep.nsgt(x), return_masks=True)
+        for i in KEEP:
+            ref = torch.from_numpy(g[f"mask_{tag}_{i}"])
+            assert float((masks[i].cpu() - ref).abs().max()) < 5e-4, (tag, i)
+
+
+@pytest.mark.parametrize("name,causal,wiener,n", [
+    ("realtime", True, False, 441000),               # S = 50: layers 2/3 on the slab kernels (T >= 86)
+    ("offline_phasemix", False, False, 450000),
+    ("offline_wiener", False, True, 200000),         # S = 24: generic split-bf16 engine
+])
+def test_bf16x3_stems_match_oracle_at_larger_sizes(bf16x3, oracle_plan, seeded_sd, name, causal, wiener, n):
+    from oracle import separator as osep
+    sep = bf16x3[name]
+    sep.chunk_size = 2621440
+    x = synth_audio(n, seed=5 + n)
+    est = sep(x.cuda()).cpu()
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=causal, wiener=wiener)
+    d = est - ref
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert rms < RMS_TOL and mx < MAX_TOL, (name, rms, mx)
+    assert rms < 1e-5 and mx < 1e-4, (name, rms, mx)
+
+
+def test_precision_switch_is_clean(seps):
+    """fp32 -> bf16x3 -> fp32 on one model handle: the fp32 bits come back, bf16x3 is deterministic, and the
+    full-chunk stacked + tail path (slab kernels beside the side-stream tail) stays bitwise reproducible."""
+    sep = seps["offline_phasemix"]
+    sep.chunk_size = 2621440
+    x = synth_audio(2 * 2621440 + 98240, seed=123).cuda()
+    try:
+        a = sep(x).clone()
+        sep.xumx_model.set_precision("bf16x3")
+        b1 = sep(x).clone()
+        b2 = sep(x).clone()
+        sep.xumx_model.set_precision("fp32")
+        c = sep(x).clone()
+    finally:
+        sep.xumx_model.set_precision("fp32")
+    assert torch.equal(a, c) and torch.equal(b1, b2)
+    d = (b1 - a).double()
+    assert float(d.pow(2).mean().sqrt()) < 1e-5 and float(d.abs().max()) < 1e-4
+    with pytest.raises(ValueError):
+        sep.xumx_model.set_precision("fp8")

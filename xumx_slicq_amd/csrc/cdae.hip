@@ -15,6 +15,7 @@
 // of a layer run in ONE grouped launch driven by a tile table.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restri
                                                            const CdaeBlockDev* __restrict__ blocks,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ scale, int nblocks,
-                                                           int BC, int S, int64_t nquads) {
+                                                           int BC, int S, int64_t nquads, int split) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= nquads) return;
     const int64_t i = 4 * q;
@@ -58,7 +59,13 @@ __global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restri
     o.y = (sqrtf(z0.z * z0.z + z0.w * z0.w) + mu) * sc;
     o.z = (sqrtf(z1.x * z1.x + z1.y * z1.y) + mu) * sc;
     o.w = (sqrtf(z1.z * z1.z + z1.w * z1.w) + mu) * sc;
+    if (split) { bf3_words2(o.x, o.y, o.x, o.y); bf3_words2(o.z, o.w, o.z, o.w); }
     xin[q] = o;
+}
+
+__global__ __launch_bounds__(256) void k_split_pool(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = bf3_word(src[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -91,7 +98,22 @@ __device__ inline void split_row(int m, int Fo, int To, int& b, int& f, int& t) 
 
 // BN shift + ReLU, channels-last store (layers 1-3): column n and n+32 of 52 padded channels
 __device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0, int n, const f32x16& a0,
-                                                    const f32x16& a1, bool raw) {
+                                                    const f32x16& a1, bool raw, bool split = false) {
+    if (split) {       // operand format of the split-bf16 engine: (bf16 hi << 16) | bf16 lo per value
+        const float s0 = g.shift[n];
+        const bool c1 = n + 32 < CS;
+        const float s1 = c1 ? g.shift[n + 32] : 0.f;
+        float* d0 = g.out + (int64_t)row0 * CS + n;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float w0, w1, u0 = 0.f, u1 = 0.f;
+            bf3_words2(fmaxf(a0[r] + s0, 0.f), fmaxf(a0[r + 1] + s0, 0.f), w0, w1);
+            if (c1) bf3_words2(fmaxf(a1[r] + s1, 0.f), fmaxf(a1[r + 1] + s1, 0.f), u0, u1);
+            if (row0 + acc_row(r) < g.M) { d0[acc_row(r) * CS] = w0; if (c1) d0[acc_row(r) * CS + 32] = u0; }
+            if (row0 + acc_row(r + 1) < g.M) { d0[acc_row(r + 1) * CS] = w1; if (c1) d0[acc_row(r + 1) * CS + 32] = u1; }
+        }
+        return;
+    }
     const float s0 = g.shift[n];
     const bool c1 = n + 32 < CS;
     const float s1 = c1 ? g.shift[n + 32] : 0.f;
@@ -117,7 +139,7 @@ struct CdaeL1Op {
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F1; g.To = a.T1; g.Fi = b.F; g.Ti = a.S * b.T;
         g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = 2 * b.kf * b.T; g.ldb = b.ld1;
-        g.B = a.pool + b.w1[tgt]; g.shift = a.pool + b.s1[tgt];
+        g.B = (a.poolB ? a.poolB : a.pool) + b.w1[tgt]; g.shift = a.pool + b.s1[tgt];
         g.in = a.xin8 ? a.xin8 + (int64_t)a.Bn * 8 * a.S * b.cum + (int64_t)tgt * a.Bn * 2 * b.F * g.Ti
                       : a.xin + (int64_t)a.Bn * 2 * a.S * b.cum;
         g.out = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
@@ -152,7 +174,7 @@ struct CdaeL1Op {
         return v;
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
 };
 
@@ -168,7 +190,7 @@ struct CdaeL2Op {
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F2; g.To = a.T2; g.Fi = b.F1; g.Ti = a.T1;
         g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = b.kf * 4 * CS;
-        g.B = a.pool + b.w2[tgt]; g.shift = a.pool + b.s2[tgt];
+        g.B = (a.poolB ? a.poolB : a.pool) + b.w2[tgt]; g.shift = a.pool + b.s2[tgt];
         g.in = a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
         g.out = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
         return g;
@@ -188,7 +210,7 @@ struct CdaeL2Op {
         return *reinterpret_cast<const float4*>(r.p + (int64_t)df * g.Ti * CS + rem);
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
 };
 
@@ -204,7 +226,7 @@ struct CdaeL3Op {
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F1; g.To = a.T1; g.Fi = b.F2; g.Ti = a.T2;
         g.M = a.Bn * g.Fo * g.To; g.N = CS; g.K = b.kf * 4 * CS; g.ldb = b.kf * 4 * CS;
-        g.B = a.pool + b.w3[tgt]; g.shift = a.pool + b.s3[tgt];
+        g.B = (a.poolB ? a.poolB : a.pool) + b.w3[tgt]; g.shift = a.pool + b.s3[tgt];
         g.in = a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)b.cumF2 + (int64_t)tgt * b.F2);
         g.out = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
         return g;
@@ -227,7 +249,7 @@ struct CdaeL3Op {
         return *reinterpret_cast<const float4*>(r.p - (int64_t)df * g.Ti * CS + rem);
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
-        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0);
+        relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
 };
 
@@ -245,7 +267,7 @@ struct CdaeL4Op {
         g.F = b.F; g.T = b.T; g.hop = b.hop; g.kf = b.kf; g.tgt = tgt; g.cum = b.cum;
         g.Fo = b.F; g.To = a.gx8 ? a.T1 + 1 : 2 * a.S; g.Fi = b.F1; g.Ti = a.T1;
         g.M = a.Bn * g.Fo * g.To; g.N = b.T; g.K = b.kf * 2 * CS; g.ldb = b.ld4;
-        g.B = a.pool + b.w4[tgt]; g.shift = a.pool + b.b4[tgt];
+        g.B = (a.poolB ? a.poolB : a.pool) + b.w4[tgt]; g.shift = a.pool + b.b4[tgt];
         g.in = a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)b.cumF1 + (int64_t)tgt * b.F1);
         g.out = nullptr;
         return g;
@@ -378,6 +400,10 @@ struct CdaeL4Op {
     }
 };
 
+}  // namespace xsq
+#include "cdae_slab.h"
+namespace xsq {
+
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
@@ -385,9 +411,9 @@ static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 
 
 static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
 
-static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int mt23 = L23_MT) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(layer, Bn, S);
+    auto key = std::make_tuple(layer + 16 * mt23, Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
@@ -418,8 +444,35 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
                     for (int tgt = 0; tgt < NT; ++tgt)
                         t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
         } else {
-            for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N, 128 * L23_MT);
+            for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N, 128 * mt23);
         }
+    }
+    TileTable tt;
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
+// tiles of the slab kernels (cdae_slab.h): 256 consecutive rows inside one batch item, all 64 columns
+static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(layer + 64, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].kf > Mo->blocks[y].kf; });
+    std::vector<TileDev> t;
+    for (int b : order) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        const int64_t perb = layer == 2 ? (int64_t)d.F2 * T2 : (int64_t)d.F1 * T1;
+        for (int tgt = 0; tgt < NT; ++tgt)
+            for (int bi = 0; bi < Bn; ++bi)
+                for (int64_t r = 0; r < perb; r += SLAB_ROWS) t.push_back(TileDev{b * 4 + tgt, (int)(bi * perb + r), 0, 0});
     }
     TileTable tt;
     tt.ntiles = (int)t.size();
@@ -587,6 +640,12 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
 int xsq_model_set_precision(xsq_model* Mo, int mode) {
     XSQ_REQUIRE(Mo, "xsq_model_set_precision: null model");
     XSQ_REQUIRE(mode == 0 || mode == 1, "xsq_model_set_precision: mode %d (0 = fp32, 1 = split bf16)", mode);
+    if (mode == 1 && !Mo->d_pool_split) {      // one-off: the weight pool in the split operand format
+        XSQ_HIP(hipMalloc(&Mo->d_pool_split, (size_t)Mo->pool_floats * 4));
+        hipLaunchKernelGGL(k_split_pool, dim3((unsigned)((Mo->pool_floats + 255) / 256)), dim3(256), 0, 0, Mo->d_pool,
+                           Mo->d_pool_split, Mo->pool_floats);
+        XSQ_HIP(hipDeviceSynchronize());
+    }
     Mo->precision = mode;
     return XSQ_OK;
 }
@@ -594,7 +653,7 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
 int xsq_model_destroy(xsq_model* Mo) {
     if (!Mo) return XSQ_OK;
     for (auto& kv : Mo->tiles) (void)hipFree(kv.second.d_tiles);
-    (void)hipFree(Mo->d_pool); (void)hipFree(Mo->d_mean); (void)hipFree(Mo->d_scale);
+    (void)hipFree(Mo->d_pool); (void)hipFree(Mo->d_pool_split); (void)hipFree(Mo->d_mean); (void)hipFree(Mo->d_scale);
     (void)hipFree(Mo->d_blocks); (void)hipFree(Mo->d_cum); (void)hipFree(Mo->d_blockF);
     delete Mo;
     return XSQ_OK;
@@ -613,12 +672,12 @@ size_t xsq_cdae_workspace(const xsq_model* Mo, int Bn, int S) {
 namespace xsq {
 
 int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
-                          int Bn, int S, hipStream_t stream) {
+                          int Bn, int S, hipStream_t stream, int split) {
     const int64_t total = (int64_t)Bn * 2 * S * Mo->sumFT;
     XSQ_PROF("magnitude_whiten", stream);
     hipLaunchKernelGGL(k_magnitude_whiten, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
                        (const float4*)X, (float4*)xin, Mo->d_cum, Mo->d_blocks, mean, scale, Mo->nblocks, Bn * 2, S,
-                       total / 4);
+                       total / 4, split);
     return XSQ_OK;
 }
 
@@ -629,18 +688,31 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
             XSQ_REQUIRE((int64_t)2 * a.Bn * d.F * a.S * d.T < ((int64_t)1 << 31),
                         "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block; split the batch", a.Bn, a.S);
     if (layer == 4 && a.gx8) layer = 6;
-    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt);
+    const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
+    static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
+    const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
+    if (bf3 && !(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86) {
+        // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
+        int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
+        if (rc) return rc;
+        if (layer == 2) { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream);
+            hipLaunchKernelGGL(cdae_slab_kernel<false>, dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles); }
+        else { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream);
+            hipLaunchKernelGGL(cdae_slab_kernel<true>, dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles); }
+        return XSQ_OK;
+    }
+    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23);
     if (rc) return rc;
-    const bool bf3 = Mo->precision == 1 && !a.raw && !a.xin8 && !a.gx8;      // inference operators only
 #define XSQ_LAUNCH(OP, MT_)                                                                                         \
     do {                                                                                                            \
-        if (bf3) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
-        else hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
+        if (!bf3) hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
+        else if (variant & 2) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 2>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
+        else hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 1>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
     } while (0)
     switch (layer) {
         case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1); } break;
-        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); XSQ_LAUNCH(CdaeL2Op, L23_MT); } break;
-        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); XSQ_LAUNCH(CdaeL3Op, L23_MT); } break;
+        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL2Op, 2); else XSQ_LAUNCH(CdaeL2Op, 1); } break;
+        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL3Op, 2); else XSQ_LAUNCH(CdaeL3Op, 1); } break;
         default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream); XSQ_LAUNCH(CdaeL4Op, 1); } break;
     }
 #undef XSQ_LAUNCH
@@ -663,8 +735,11 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act1 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
-    cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream);
+    const int split = Mo->precision == 1 ? 1 : 0;
+    cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream, split);
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0, nullptr, nullptr};
+    a.split = split;
+    a.poolB = split ? Mo->d_pool_split : nullptr;
     for (int layer = 1; layer <= 4; ++layer) {
         const int rc = cdae_launch_layer(Mo, layer, a, stream);
         if (rc) return rc;

@@ -35,6 +35,7 @@ struct xsq_model {
     int64_t sumF = 0, sumF1 = 0, sumF2 = 0;
     xsq::CdaeBlockDev* d_blocks = nullptr;
     float* d_pool = nullptr;       // all folded weights / shifts
+    float* d_pool_split = nullptr; // the same pool as (bf16 hi << 16) | bf16 lo words (precision 1)
     int64_t pool_floats = 0;
     float* d_mean = nullptr;       // (sumF) input_mean  (stored as -mean by the reference)
     float* d_scale = nullptr;      // (sumF) input_scale (stored as 1/std)
@@ -63,6 +64,11 @@ struct CdaeArgs {
                           // (target-specific), no left padding, right edge checked; weights = w4 in w1's layout
     float* gx8;           // layer-4 operator as the DATA GRADIENT of layer 1: raw store of (target, b, c, f, u*hop+dt)
                           // with u < T1+1 (padded coordinates s = tau + left pad); weights = w1 in w4's layout
+    // split-bf16 inference (xsq_model_set_precision 1, gemm_tile_bf3.h): xin / act1..3 hold one 32-bit word
+    // per value, (bf16 hi << 16) | bf16 lo, written by the producing kernel; poolB = the weight pool in the
+    // same format (shifts / biases are still read from `pool`)
+    int split = 0;
+    const float* poolB = nullptr;
 };
 
 
@@ -70,7 +76,7 @@ struct CdaeArgs {
 int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name = nullptr);
 // |X| -> whitened magnitude with explicit mean / scale tables (sum_b F_b floats each)
 int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
-                          int Bn, int S, hipStream_t stream);
+                          int Bn, int S, hipStream_t stream, int split = 0);
 
 // backward of the Wiener-EM iteration (wiener.hip), in place on the gradient arena G
 int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, float* G,

@@ -1,0 +1,213 @@
+// Layers 2 and 3 of the CDAE on the split-bf16 matrix path, with the input slab of a tile held ONCE in LDS.
+//
+// Both layers are (kf x 4)-tap convolutions over channels-last activations (model.py:140-170; layer 3 is the
+// transposed convolution written as a gather, cdae.hip).  Seen as an implicit GEMM, row (f, t) of the A
+// operand is, for every df, the run of 4 x 52 consecutive words that starts at position t of input row
+// f +- df: rows t and t + 1 share three of their four positions.  The generic engine (gemm_tile_bf3.h) loads
+// every row's run separately -- each activation crosses the L2 -> LDS path 4 kf times, and with three bf16
+// MFMAs per product that path, not the matrix pipe, bounds the kernel (measured: ~8 TB/s of operand traffic
+// at 25 % of the pipe).  Here a tile is 256 consecutive output rows of one batch item; for each df its
+// DISTINCT input positions (256 + 3 per touched (b, f) row) are copied once, coalesced, into LDS as two
+// planes (hi bf16 | lo bf16), and every MFMA A fragment is read straight out of that image at
+// (row position * 52 + k): the 4x overlap is served by LDS.  B (the weights of this df, 64 x 208 words)
+// streams through a double-buffered LDS tile shared by the 8 waves of the workgroup.
+//   L2 -> LDS traffic per 256 rows and df:  A 54 KB + B 53 KB   (generic engine, 2 x 128 rows: 212 + 106 KB)
+//   LDS: 2 x 27.9 KB slab planes + a ring of three 7.3 KB B tiles = 76.6 KB -> two 512-thread workgroups per CU.
+// Plane row stride is 52 bf16 = 104 B: the 32 lanes of a ds_read_b64 fragment read hit 32 distinct even
+// banks (26 r mod 64), conflict-free; B tile rows are 36 words (conflict-free ds_read_b128, gemm_tile_bf3.h).
+#pragma once
+#include "cdae_api.h"
+#include "gemm_tile_bf3.h"
+
+#ifndef XSQ_SLAB_ABL
+#define XSQ_SLAB_ABL 0      // diagnostic builds: 1 no MFMAs, 2 no fragment reads, 4 no B loads, 8 no slab loads, 16 no epilogue
+#endif
+
+namespace xsq {
+
+constexpr int SLAB_ROWS = 256;                 // output rows per tile (8 waves x 32)
+constexpr int SLAB_MAXSEG = 4;                 // (b, f) rows a tile may touch (needs To >= 86)
+constexpr int SLAB_POS = SLAB_ROWS + 3 * SLAB_MAXSEG;
+constexpr int SLAB_KRUN = 4 * CS;              // 208 words per df
+constexpr int SLAB_BLD = 36;                   // B tile row: 32 k-values as (16 hi | 16 lo) x 2 + 4 pad words
+constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored channels (columns 52..63 of the MFMA tile are never stored)
+
+// TRANSPOSED = false: layer 2, in = act1 (Fi = F1 rows of Ti = T1), input row f + df, positions t .. t + 3
+// TRANSPOSED = true : layer 3, in = act2 (Fi = F2 rows of Ti = T2), input row f - df, positions t - 3 .. t
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned short slabH[SLAB_POS * CS + 64];
+    __shared__ __attribute__((aligned(16))) unsigned short slabL[SLAB_POS * CS + 64];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[3 * SLAB_BN * SLAB_BLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const CdaeBlockDev& blk = a.blocks[t.group >> 2];
+    const int tgt = t.group & 3;
+    const int kf = blk.kf;
+    const int Fo = TRANSPOSED ? blk.F1 : blk.F2, To = TRANSPOSED ? a.T1 : a.T2;
+    const int Fi = TRANSPOSED ? blk.F2 : blk.F1, Ti = TRANSPOSED ? a.T2 : a.T1;
+    const float* in = TRANSPOSED ? a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)blk.cumF2 + (int64_t)tgt * blk.F2)
+                                 : a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)blk.cumF1 + (int64_t)tgt * blk.F1);
+    CdaeGroup g;
+    g.out = TRANSPOSED ? a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)blk.cumF1 + (int64_t)tgt * blk.F1)
+                       : a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)blk.cumF2 + (int64_t)tgt * blk.F2);
+    g.shift = a.pool + (TRANSPOSED ? blk.s3[tgt] : blk.s2[tgt]);
+    const float* Bt = a.poolB + (TRANSPOSED ? blk.w3[tgt] : blk.w2[tgt]);
+    const int ldb = kf * SLAB_KRUN;
+
+    // ---- the tile: rows m0 .. m0 + nrows of batch item b, split into segments (one per (b, f) row) --------
+    const int perb = Fo * To;
+    const int b = t.m0 / perb;
+    const int mend = min((b + 1) * perb, t.m0 + SLAB_ROWS);
+    g.M = mend;                                          // the epilogue's row bound
+    const int nrows = mend - t.m0;
+    const int r0 = t.m0 - b * perb;
+    const int f0 = r0 / To, t0 = r0 - f0 * To;
+    // segment i: output rows [seg_r[i], seg_r[i+1]) of the tile, f = f0 + i, first t = (i ? 0 : t0),
+    // slab positions start at seg_r[i] + 3 i
+    // (position j of a segment is input position  ts - PAD + j,  PAD = 3 for the transposed layer)
+    auto seg_start = [&](int i) { return i == 0 ? 0 : min(nrows, i * To - t0); };
+
+    // A-fragment base of this lane's row (bf16 index into the planes)
+    const int myrow = wave * 32 + lrow;
+    int my_seg = 0;
+#pragma unroll
+    for (int i = 1; i < SLAB_MAXSEG; ++i) my_seg += (myrow >= seg_start(i)) ? 1 : 0;
+    const int a_base = (myrow + 3 * my_seg) * CS + 8 * lk;          // + k of the fragment
+
+    // ---- staging assignments ------------------------------------------------------------------------------
+    constexpr int NLD = (SLAB_POS * (CS / 4) + 511) / 512;           // float4 loads per thread and slab (7)
+    float4 sa[NLD];
+
+    auto load_slab = [&](int df) {
+        const int total = (nrows + 3 * SLAB_MAXSEG) * (CS / 4);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 512 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < total) {
+                const int pos = e / (CS / 4), c4 = e - pos * (CS / 4);
+                // which segment holds slab position pos?  segment i starts at seg_start(i) + 3 i
+                int i = 0;
+#pragma unroll
+                for (int s = 1; s < SLAB_MAXSEG; ++s) i += (pos >= seg_start(s) + 3 * s) ? 1 : 0;
+                const int j = pos - (seg_start(i) + 3 * i);              // position inside the segment
+                const int f = f0 + i, ts = i ? 0 : t0;
+                const int fi = TRANSPOSED ? f - df : f + df;
+                const int p = ts - (TRANSPOSED ? 3 : 0) + j;
+                const int len = seg_start(i + 1 < SLAB_MAXSEG ? i + 1 : i) - seg_start(i);   // rows of the segment
+                const int rows_i = (i + 1 < SLAB_MAXSEG) ? len : nrows - seg_start(i);
+                if (!(XSQ_SLAB_ABL & 8) && f < Fo && j < rows_i + 3 && fi >= 0 && fi < Fi && p >= 0 && p < Ti)
+                    v = *reinterpret_cast<const float4*>(in + (((int64_t)b * Fi + fi) * Ti + p) * CS + 4 * c4);
+            }
+            sa[q] = v;
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 512 * q;
+            if (e < SLAB_POS * (CS / 4)) {
+                const unsigned e0 = __builtin_bit_cast(unsigned, sa[q].x), e1 = __builtin_bit_cast(unsigned, sa[q].y);
+                const unsigned e2 = __builtin_bit_cast(unsigned, sa[q].z), e3 = __builtin_bit_cast(unsigned, sa[q].w);
+                *reinterpret_cast<uint2*>(&slabH[4 * e]) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
+                *reinterpret_cast<uint2*>(&slabL[4 * e]) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u));
+            }
+        }
+    };
+    // ---- B stream: one K-step = 52 rows x 32 words, loaded by threads 0..415 (one float4 each) two slots
+    // before it is written into a ring of three LDS tiles, which happens two slots before it is used ------
+    const bool b_ld = tid < SLAB_BN * 8;
+    const int b_row = tid >> 3, b_k = (tid & 7) * 4;                 // word offset inside the K-step
+    const float* bp = Bt + (int64_t)b_row * ldb + b_k;
+    float4 gb[2];
+    auto load_b = [&](int set, int df, int ks) {
+        if (b_ld && !(XSQ_SLAB_ABL & 4)) gb[set] = (32 * ks + b_k < SLAB_KRUN) ? *reinterpret_cast<const float4*>(bp + df * SLAB_KRUN + 32 * ks)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_b = [&](int set, int buf) {
+        if (!b_ld) return;
+        unsigned* row = Bs + buf * SLAB_BN * SLAB_BLD + b_row * SLAB_BLD + 16 * (b_k >> 4);
+        const int q2 = (b_k & 15) >> 1;
+        const unsigned e0 = __builtin_bit_cast(unsigned, gb[set].x), e1 = __builtin_bit_cast(unsigned, gb[set].y);
+        const unsigned e2 = __builtin_bit_cast(unsigned, gb[set].z), e3 = __builtin_bit_cast(unsigned, gb[set].w);
+        *reinterpret_cast<uint2*>(row + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
+        *reinterpret_cast<uint2*>(row + 8 + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u));
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    auto afrag = [&](const unsigned short* plane, int k) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(&plane[a_base + k]);
+        const uint2 hi = *reinterpret_cast<const uint2*>(&plane[a_base + k + 4]);
+        return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    };
+    auto bfrag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); };
+    const int b_frag0 = lrow * SLAB_BLD + 4 * lk;
+    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * SLAB_BLD + 4 * lk;     // columns >= 52 are never stored: any row will do
+
+    // Slots: every df owns 8 slots, 7 K-steps of 32 (the last half empty) and one slot in which the next
+    // slab goes into LDS; slot parity = register set, so all register indices are compile-time.  Global slot
+    // G = 8 * (df index) + ks; the K-step of slot G sits in ring tile G % 3.
+    constexpr int NKS = 7;
+    load_slab(0);
+    load_b(0, 0, 0);
+    load_b(1, 0, 1);
+    store_slab();
+    store_b(0, 0);
+    store_b(1, 1);
+    load_b(0, 0, 2);
+    load_b(1, 0, 3);
+    if (kf > 1) load_slab(1);
+    __syncthreads();
+    int ring = 0;                              // G % 3 of slot (df, 0)
+    for (int df = 0; df < kf; ++df) {
+        const bool more = df + 1 < kf;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < NKS) {
+                const unsigned* Bb = Bs + ((ring + ks) % 3) * SLAB_BN * SLAB_BLD;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int k = 32 * ks + 16 * c;
+                    if (k < SLAB_KRUN) {       // compile-time: the second half of the last K-step does not exist
+                        bf16x8_t ah, al, b0h, b0l, b1h, b1l;
+                        if (XSQ_SLAB_ABL & 2) { ah = al = b0h = b0l = b1h = b1l = __builtin_bit_cast(bf16x8_t, make_uint4(tid, k, ks, c)); }
+                        else {
+                            ah = afrag(slabH, k); al = afrag(slabL, k);
+                            b0h = bfrag(Bb + b_frag0 + 16 * c); b0l = bfrag(Bb + b_frag0 + 16 * c + 8);
+                            b1h = bfrag(Bb + b_frag1 + 16 * c); b1l = bfrag(Bb + b_frag1 + 16 * c + 8);
+                        }
+                        if (XSQ_SLAB_ABL & 1) { acc0[c] += (float)ah[0] + (float)al[1] + (float)b0h[2] + (float)b0l[3]; acc1[c] += (float)b1h[4] + (float)b1l[5]; continue; }
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+                    }
+                }
+            } else if (more) {
+                store_slab();                  // slot 7: every wave has passed the barrier behind the slab's last reader
+                if (df + 2 < kf) load_slab(df + 2);
+            }
+            // K-step of slot G + 2 (held in set ks % 2 since slot G - 2) -> ring tile (G + 2) % 3, last read in slot G - 1
+            if (ks + 2 < NKS) store_b(ks & 1, (ring + ks + 2) % 3);
+            else if (ks + 2 >= 8 && more) store_b(ks & 1, (ring + ks + 2) % 3);           // (df + 1, ks - 6)
+            // refill that set with the K-step of slot G + 4
+            if (ks + 4 < NKS) load_b(ks & 1, df, ks + 4);
+            else if (ks + 4 >= 8 && more) load_b(ks & 1, df + 1, ks - 4);
+            __syncthreads();
+        }
+        ring = (ring + 8) % 3;
+    }
+
+    if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
+    relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, true);
+}
+
+}  // namespace xsq

@@ -11,8 +11,10 @@
 // LDS image of a K-step (16 k-values) of one tile row: [16 x hi bf16 | 16 x lo bf16] = 64 bytes at the
 // fp32 engine's row stride of 20 words (conflict-free ds_read_b128); lane l = (row l&31, half h = l>>5)
 // reads hi[8h .. 8h+7] and lo[8h .. 8h+7] as two 16-byte fragments, which is exactly the operand map of
-// the instruction (element j of the fragment is k = 8h + j, cdna guide section 3).  The split happens
-// in registers between the global load and the LDS write (6 VALU ops per two values).
+// the instruction (element j of the fragment is k = 8h + j, cdna guide section 3).  The split itself is
+// done ONCE per value by whoever produces it (the previous layer's epilogue, the magnitude kernel, the
+// weight pool conversion) and stored as one word (hi << 16) | lo -- same bytes as fp32, so the
+// operators' loaders are unchanged -- because every activation is re-read kf x 4 times by the next layer.
 #pragma once
 #include "gemm_tile.h"
 
@@ -30,15 +32,27 @@ __device__ __forceinline__ void bf3_split2(float x, float y, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
-template <class Op, int MT = 1>
+// the storage format of split operands: one word per value, (bf16 hi << 16) | bf16 lo
+__device__ __forceinline__ void bf3_words2(float x, float y, float& wx, float& wy) {
+    unsigned hi, lo;
+    bf3_split2(x, y, hi, lo);
+    wx = __builtin_bit_cast(float, (hi << 16) | (lo & 0xffffu));
+    wy = __builtin_bit_cast(float, (hi & 0xffff0000u) | (lo >> 16));
+}
+__device__ __forceinline__ float bf3_word(float x) {
+    float wx, wy;
+    bf3_words2(x, 0.f, wx, wy);
+    return wx;
+}
+
+// KS = 16-value k-chunks per K-step (one barrier per K-step; LDS row = KS x (16 hi | 16 lo) + 4 pad words:
+// 20 or 36 words, both conflict-free for ds_read_b128 over 16 consecutive rows)
+template <class Op, int MT = 1, int KS = 1>
 __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const TileDev* __restrict__ tiles, int ntiles) {
-    constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
+    constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = 16 * KS, LD = 16 * KS + 4;
     constexpr int RA = BM / 64;
 
-#ifndef XSQ_BF3_DBG
-#define XSQ_BF3_DBG 0
-#endif
-    __shared__ __attribute__((aligned(16))) unsigned lds[((XSQ_BF3_DBG & 1) ? 25600 : 0) + 2 * (BM + BN) * LD];
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * (BM + BN) * LD];
     unsigned* const As0 = lds;
     unsigned* const Bs0 = lds + 2 * BM * LD;
 
@@ -58,19 +72,25 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const Tile
     const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
     const bool b_on = wide || s_row < 32;
 
-    float4 ga[2][RA];
-    float4 gb[2];
+    float4 ga[2][RA][KS];
+    float4 gb[2][KS];
     auto load_set = [&](int set, int k) {
         if (k < K) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
-            if (b_on) gb[set] = *reinterpret_cast<const float4*>(bp + k);
+            for (int c = 0; c < KS; ++c) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) ga[set][i][c] = op.load_a4(g, ra[i], k + 16 * c + s_kq);     // zeros past K
+                if (b_on) gb[set][c] = (k + 16 * c < K) ? *reinterpret_cast<const float4*>(bp + k + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
+    // Operands arrive PRE-SPLIT (one word (hi << 16) | lo per value, written by the producing kernel / the
+    // weight pool conversion): staging is four byte permutes per 16-byte load, no arithmetic.
     auto put = [&](unsigned* row, const float4& v) {       // words [2q, 2q+1] = hi, [8+2q, 8+2q+1] = lo, q = s_kq/4
-        unsigned h0, l0, h1, l1;
-        bf3_split2(v.x, v.y, h0, l0);
-        bf3_split2(v.z, v.w, h1, l1);
+        const unsigned e0 = __builtin_bit_cast(unsigned, v.x), e1 = __builtin_bit_cast(unsigned, v.y);
+        const unsigned e2 = __builtin_bit_cast(unsigned, v.z), e3 = __builtin_bit_cast(unsigned, v.w);
+        const unsigned h0 = __builtin_amdgcn_perm(e1, e0, 0x07060302u), h1 = __builtin_amdgcn_perm(e3, e2, 0x07060302u);
+        const unsigned l0 = __builtin_amdgcn_perm(e1, e0, 0x05040100u), l1 = __builtin_amdgcn_perm(e3, e2, 0x05040100u);
         *reinterpret_cast<uint2*>(row + (s_kq >> 1)) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(row + 8 + (s_kq >> 1)) = make_uint2(l0, l1);
     };
@@ -78,12 +98,18 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const Tile
         unsigned* Aw = As0 + buf * BM * LD;
         unsigned* Bw = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) put(&Aw[(s_row + 64 * i) * LD], ga[set][i]);
-        put(&Bw[s_row * LD], gb[set]);
+        for (int c = 0; c < KS; ++c) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) put(&Aw[(s_row + 64 * i) * LD + 16 * c], ga[set][i][c]);
+            put(&Bw[s_row * LD + 16 * c], gb[set][c]);
+        }
     };
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ga[0][i] = ga[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    gb[0] = gb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < KS; ++c) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ga[0][i][c] = ga[1][i][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gb[0][c] = gb[1][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     load_set(0, 0);
 
     f32x16 acc0[MT], acc1[MT];
@@ -98,8 +124,10 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const Tile
 
     auto frag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); };
     auto mfma_step = [&](int buf) {
-        const unsigned* As = As0 + buf * BM * LD;
-        const unsigned* Bs = Bs0 + buf * BN * LD;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const unsigned* As = As0 + buf * BM * LD + 16 * c;
+        const unsigned* Bs = Bs0 + buf * BN * LD + 16 * c;
         bf16x8_t ah[MT], al[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) { ah[i] = frag(&As[a_frag + i * 32 * LD]); al[i] = frag(&As[a_frag + i * 32 * LD + 8]); }
@@ -108,7 +136,6 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const Tile
             const bf16x8_t b1h = frag(&Bs[b_frag + 32 * LD]), b1l = frag(&Bs[b_frag + 32 * LD + 8]);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {      // small terms first
-                if (XSQ_BF3_DBG & 2) { acc0[i][0] += (float)ah[i][0] * (float)b0l[1] + (float)al[i][2] * (float)b1h[3] + (float)b0h[1] * (float)b1l[3]; continue; }
                 acc0[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b0h, acc0[i], 0, 0, 0);
                 acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b1h, acc1[i], 0, 0, 0);
                 acc0[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b0l, acc0[i], 0, 0, 0);
@@ -124,6 +151,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const Tile
                 acc0[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], b0h, acc0[i], 0, 0, 0);
             }
         }
+      }
     };
 
     // same pipeline as the fp32 engine: LDS double-buffered (one barrier per K-step), global loads two
