@@ -24,12 +24,16 @@ glob.glob = newest
 
 
 def short(n):
+    import re
     n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")
-    n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("void xsq::grouped_gemm_kernel<128, xsq::", "gemm128<").replace("xsq::", "")
+    n = n.replace("void xsq::cdae_slab_kernel<false>", "slab_bf3<CdaeL2>").replace("void xsq::cdae_slab_kernel<true>", "slab_bf3<CdaeL3>")
+    n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
+    n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+), \d+>", r"gemm<\1>", n)
+    n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("xsq::", "")
     return n.split("(")[0][:48]
 
 
-ours = "gemm|band_dft4|k_|fft|bluestein|c2r|r2c"
+ours = "gemm|slab|band_dft4|k_|fft|bluestein|c2r|r2c"
 st = pd.read_csv(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0])
 st["Kernel"] = st["Name"].map(short)
 st = st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"]]
