@@ -691,14 +691,16 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
     static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
-    if (bf3 && !(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86) {
+    if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
+        (bf3 || !(variant & 8))) {
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
-        if (layer == 2) { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream);
-            hipLaunchKernelGGL(cdae_slab_kernel<false>, dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles); }
-        else { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream);
-            hipLaunchKernelGGL(cdae_slab_kernel<true>, dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles); }
+        XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_gemm" : "cdae_l3_gemm"), stream);
+        if (layer == 2 && bf3) hipLaunchKernelGGL((cdae_slab_kernel<false, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
+        else if (layer == 2) hipLaunchKernelGGL((cdae_slab_kernel<false, false>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
+        else if (bf3) hipLaunchKernelGGL((cdae_slab_kernel<true, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
+        else hipLaunchKernelGGL((cdae_slab_kernel<true, false>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
         return XSQ_OK;
     }
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23);

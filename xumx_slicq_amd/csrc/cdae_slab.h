@@ -34,11 +34,18 @@ constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored cha
 
 // TRANSPOSED = false: layer 2, in = act1 (Fi = F1 rows of Ti = T1), input row f + df, positions t .. t + 3
 // TRANSPOSED = true : layer 3, in = act2 (Fi = F2 rows of Ti = T2), input row f - df, positions t - 3 .. t
-template <bool TRANSPOSED>
+// BF3 = true : operands in the split format, v_mfma_f32_32x32x16_bf16 x 3 (gemm_tile_bf3.h)
+// BF3 = false: plain fp32 operands, v_mfma_f32_32x32x2_f32 with the engine's k permutation (MFMA i of a
+//              16-value chunk takes k = i from the lower half-wave and k = 8 + i from the upper one, gemm_tile.h):
+//              the slab is then ONE fp32 plane (same 55.7 KB; row stride 52 words, conflict-free ds_read_b128)
+template <bool TRANSPOSED, bool BF3>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
-    __shared__ __attribute__((aligned(16))) unsigned short slabH[SLAB_POS * CS + 64];
-    __shared__ __attribute__((aligned(16))) unsigned short slabL[SLAB_POS * CS + 64];
+    constexpr int PLANE = SLAB_POS * CS + 64;                    // bf16 elements per plane (a multiple of 8)
+    __shared__ __attribute__((aligned(16))) unsigned short slab_raw[2 * PLANE];
     __shared__ __attribute__((aligned(16))) unsigned Bs[3 * SLAB_BN * SLAB_BLD];
+    unsigned short* const slabH = slab_raw;                      // BF3: hi plane | lo plane
+    unsigned short* const slabL = slab_raw + PLANE;
+    float* const slabF = reinterpret_cast<float*>(slab_raw);     // fp32: one plane over the same bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     g.out = TRANSPOSED ? a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)blk.cumF1 + (int64_t)tgt * blk.F1)
                        : a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)blk.cumF2 + (int64_t)tgt * blk.F2);
     g.shift = a.pool + (TRANSPOSED ? blk.s3[tgt] : blk.s2[tgt]);
-    const float* Bt = a.poolB + (TRANSPOSED ? blk.w3[tgt] : blk.w2[tgt]);
+    const float* Bt = (BF3 ? a.poolB : a.pool) + (TRANSPOSED ? blk.w3[tgt] : blk.w2[tgt]);
     const int ldb = kf * SLAB_KRUN;
 
     // ---- the tile: rows m0 .. m0 + nrows of batch item b, split into segments (one per (b, f) row) --------
@@ -109,7 +116,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int e = tid + 512 * q;
-            if (e < SLAB_POS * (CS / 4)) {
+            if (!BF3) {
+                if (e < SLAB_POS * (CS / 4)) *reinterpret_cast<float4*>(&slabF[4 * e]) = sa[q];
+            } else if (e < SLAB_POS * (CS / 4)) {
                 const unsigned e0 = __builtin_bit_cast(unsigned, sa[q].x), e1 = __builtin_bit_cast(unsigned, sa[q].y);
                 const unsigned e2 = __builtin_bit_cast(unsigned, sa[q].z), e3 = __builtin_bit_cast(unsigned, sa[q].w);
                 *reinterpret_cast<uint2*>(&slabH[4 * e]) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     };
     auto store_b = [&](int set, int buf) {
         if (!b_ld) return;
+        if (!BF3) { *reinterpret_cast<float4*>(Bs + buf * SLAB_BN * SLAB_BLD + b_row * SLAB_BLD + b_k) = gb[set]; return; }
         unsigned* row = Bs + buf * SLAB_BN * SLAB_BLD + b_row * SLAB_BLD + 16 * (b_k >> 4);
         const int q2 = (b_k & 15) >> 1;
         const unsigned e0 = __builtin_bit_cast(unsigned, gb[set].x), e1 = __builtin_bit_cast(unsigned, gb[set].y);
@@ -147,8 +157,8 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
     };
     auto bfrag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); };
-    const int b_frag0 = lrow * SLAB_BLD + 4 * lk;
-    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * SLAB_BLD + 4 * lk;     // columns >= 52 are never stored: any row will do
+    const int b_frag0 = lrow * SLAB_BLD + (BF3 ? 4 : 8) * lk;
+    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * SLAB_BLD + (BF3 ? 4 : 8) * lk;     // columns >= 52 are never stored: any row will do
 
     // Slots: every df owns 8 slots, 7 K-steps of 32 (the last half empty) and one slot in which the next
     // slab goes into LDS; slot parity = register set, so all register indices are compile-time.  Global slot
@@ -175,6 +185,22 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                 for (int c = 0; c < 2; ++c) {
                     const int k = 32 * ks + 16 * c;
                     if (k < SLAB_KRUN) {       // compile-time: the second half of the last K-step does not exist
+                        if constexpr (!BF3) {
+                            const float* Bf = reinterpret_cast<const float*>(Bb);
+                            const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
+                            const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
+                            const float4 p0 = *reinterpret_cast<const float4*>(&Bf[b_frag0 + 16 * c]), p1 = *reinterpret_cast<const float4*>(&Bf[b_frag0 + 16 * c + 4]);
+                            const float4 q0 = *reinterpret_cast<const float4*>(&Bf[b_frag1 + 16 * c]), q1 = *reinterpret_cast<const float4*>(&Bf[b_frag1 + 16 * c + 4]);
+                            const float av[8] = {alo.x, alo.y, alo.z, alo.w, ahi.x, ahi.y, ahi.z, ahi.w};
+                            const float b0[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                            const float b1[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                            for (int kk = 0; kk < 8; ++kk) {
+                                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b0[kk], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b1[kk], acc1, 0, 0, 0);
+                            }
+                            continue;
+                        }
                         bf16x8_t ah, al, b0h, b0l, b1h, b1l;
                         if (XSQ_SLAB_ABL & 2) { ah = al = b0h = b0l = b1h = b1l = __builtin_bit_cast(bf16x8_t, make_uint4(tid, k, ks, c)); }
                         else {
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     }
 
     if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
-    relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, true);
+    relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, BF3);
 }
 
 }  // namespace xsq
