@@ -50,6 +50,9 @@ struct Band4Args {
 
 constexpr int D4_BM = 64, D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
 
+#ifndef XSQ_D4_ABL
+#define XSQ_D4_ABL 0      // diagnostic builds: 1 no MFMAs, 2 no operand loads, 4 no matrix loads, 8 no epilogue, 16 no epilogue stores
+#endif
 #ifndef XSQ_D4_WPE
 #define XSQ_D4_WPE __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
@@ -71,16 +74,19 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     const int s_row = tid >> 2, s_kq = tid & 3;
     const int row = t.m0 + s_row;
     const bool row_ok = row < M;
-    const int bc = row / a.S, s = row - bc * a.S;
-    const float* xrow = nullptr;
-    const float* mrow = nullptr;
-    if (row_ok) {
-        if (FWD) xrow = a.src + (int64_t)row * 2 * a.nbins;
-        else if (!a.mask) xrow = a.src + 2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
-        else {
-            mrow = a.mask + (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
-            xrow = a.src + 2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + s) * Lg);
-        }
+    const int rowc = row_ok ? row : M - 1;             // rows past M load row M-1 (any valid memory) and are zeroed below
+    const int bc = rowc / a.S, s = rowc - bc * a.S;
+    // 32-bit element offsets from the (uniform) arena pointers: the arenas hold < 2^31 floats (checked by the
+    // host) and two lane-varying 64-bit pointers would not fit under the 3-workgroups-per-CU register cap
+    const float* const xbase = a.src;
+    const float* const mbase = a.mask;
+    const bool masked = !FWD && a.mask != nullptr;
+    int xoff, moff = 0;
+    if (FWD) xoff = rowc * 2 * a.nbins;
+    else if (!masked) xoff = (int)(2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg));
+    else {
+        moff = (int)(BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
+        xoff = (int)(2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + s) * Lg));
     }
     const float* win = a.pool + bd.win_off;
     const int mpad = (m_ + 7) & ~7;
@@ -89,62 +95,81 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     const float* bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
     const bool b_on = wide || s_row < 32;
 
-    float2 gx[4][2];       // quarters a = 0..3, two consecutive t1
+    // Operand staging.  load_set only ISSUES loads -- unconditionally, from clamped addresses, nothing consumed --
+    // so that the K-step's ~9 loads per lane are in flight together while the previous step's MFMAs run; every
+    // product, select and butterfly happens in store_set.  (With the mask multiply / window multiply / bounds
+    // predicates inside load_set the compiler had to wait for each quarter's loads in turn: four global round
+    // trips per K-step, none of them overlapped with the MFMAs -- 45 us per tile, measured.)
+    struct __attribute__((aligned(8))) F4 { float x, y, z, w; };     // two consecutive complex values, 8-byte aligned
+    struct __attribute__((aligned(4))) F2 { float x, y; };           // two consecutive masks / window values
+    F4 raw[4];             // INV: quarters a = 0..3, complex (tc, tc + 1);  FWD: element e = 0: quarters 0,1 / ...
+    float2 rawf[4][2];     // FWD: spectrum values of quarter a, element e
+    F2 aux[4];             // INV: masks (tc, tc + 1) of quarter a;  FWD: window values
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
     int g_t1 = 0;          // t1 of the staged pair (twiddles are read from LDS in store_set)
-    struct __attribute__((aligned(8))) F4 { float x, y, z, w; };     // two consecutive complex values, 8-byte aligned
-    struct __attribute__((aligned(4))) F2 { float x, y; };           // two consecutive masks
 
+    auto fwd_idx = [&](int tt, int q4, float& cj) {        // spectrum bin of window index tt + q4*m, Hermitian reflection
+        int idx = bd.bin0 + tt + ((q4 + 2) & 3) * m_;
+        cj = 1.f;
+        if (idx < 0) { idx = -idx; cj = -1.f; }
+        else if (idx > a.L / 2) { idx = a.L - idx; cj = -1.f; }
+        return idx;
+    };
     auto load_set = [&](int k0) {      // k0 = first real k of the K-step (16 per step = 8 complex t1)
         const int t1 = (k0 >> 1) + 2 * s_kq;
         g_t1 = t1;
-        if (!FWD) {       // synthesis: the pair (t1, t1 + 1) of every quarter is one 16-byte load (+ one 8-byte mask load)
-            const bool ok0 = row_ok && t1 < m_, ok1 = row_ok && t1 + 1 < m_;
+        const int tc = t1 < m_ - 1 ? t1 : m_ - 2;          // the pair (tc, tc + 1) always lies inside the quarter
+        if ((XSQ_D4_ABL & 2) && k0 > 0) { if (b_on && !(XSQ_D4_ABL & 4)) gb = *reinterpret_cast<const float4*>(bp + k0); return; }
+        if (!FWD) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                gx[q4][0] = gx[q4][1] = make_float2(0.f, 0.f);
-                const float* p = xrow + 2 * (t1 + q4 * m_);
-                if (ok1) { const F4 v = *reinterpret_cast<const F4*>(p); gx[q4][0] = make_float2(v.x, v.y); gx[q4][1] = make_float2(v.z, v.w); }
-                else if (ok0) gx[q4][0] = *reinterpret_cast<const float2*>(p);
-                if (mrow) {
-                    const float* pm = mrow + t1 + q4 * m_;
-                    float mk0 = 0.f, mk1 = 0.f;
-                    if (ok1) { const F2 v = *reinterpret_cast<const F2*>(pm); mk0 = v.x; mk1 = v.y; }
-                    else if (ok0) mk0 = pm[0];
-                    gx[q4][0].x *= mk0; gx[q4][0].y *= mk0; gx[q4][1].x *= mk1; gx[q4][1].y *= mk1;
-                }
+                raw[q4] = *reinterpret_cast<const F4*>(xbase + (xoff + 2 * (tc + q4 * m_)));
+                if (masked) aux[q4] = *reinterpret_cast<const F2*>(mbase + (moff + tc + q4 * m_));
             }
-            if (b_on) gb = *reinterpret_cast<const float4*>(bp + k0);
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int tt = t1 + e;
-            const bool ok = row_ok && tt < m_;
+        } else {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                float2 v = make_float2(0.f, 0.f);
-                if (ok) {
-                    if (FWD) {
-                        const int q = tt + q4 * m_;                        // window index
-                        int idx = bd.bin0 + tt + ((q4 + 2) & 3) * m_;      // spectrum bin of that index
-                        float cj = 1.f;
-                        if (idx < 0) { idx = -idx; cj = -1.f; }
-                        else if (idx > a.L / 2) { idx = a.L - idx; cj = -1.f; }
-                        const float2 u = *reinterpret_cast<const float2*>(xrow + 2 * idx);
-                        const float gq = win[q];
-                        v = make_float2(u.x * gq, cj * u.y * gq);
-                    } else {
-                        v = *reinterpret_cast<const float2*>(xrow + 2 * (tt + q4 * m_));      // (not reached: synthesis returns above)
-                    }
+                aux[q4] = *reinterpret_cast<const F2*>(win + tc + q4 * m_);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float cj;
+                    rawf[q4][e] = *reinterpret_cast<const float2*>(xbase + (xoff + 2 * fwd_idx(tc + e, q4, cj)));
                 }
-                gx[q4][e] = v;
             }
         }
-        if (b_on) gb = *reinterpret_cast<const float4*>(bp + k0);
+        if (b_on && (!(XSQ_D4_ABL & 4) || k0 == 0)) gb = *reinterpret_cast<const float4*>(bp + k0);
     };
     auto store_set = [&](int buf) {
         float* Aw = As0 + buf * 4 * D4_BM * D4_LD + s_row * D4_LD + 4 * s_kq;
+        // unpack the staged pair: element e is t1 + e; the loads were taken at (tc, tc + 1)
+        const int t1 = g_t1;
+        const int tc = t1 < m_ - 1 ? t1 : m_ - 2;
+        const bool ok0 = row_ok && t1 < m_, ok1 = row_ok && t1 + 1 < m_;
+        const bool shifted = t1 != tc;                     // t1 = m - 1 (odd m): element 0 is the SECOND value of the loaded pair
+        float2 gx[4][2];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float2 v0, v1;
+            if (!FWD) {
+                v0 = shifted ? make_float2(raw[q4].z, raw[q4].w) : make_float2(raw[q4].x, raw[q4].y);
+                v1 = make_float2(raw[q4].z, raw[q4].w);
+                if (masked) {
+                    const float mk0 = shifted ? aux[q4].y : aux[q4].x, mk1 = aux[q4].y;
+                    v0.x *= mk0; v0.y *= mk0; v1.x *= mk1; v1.y *= mk1;
+                }
+            } else {
+                float cj0, cj1;
+                (void)fwd_idx(tc, q4, cj0);
+                (void)fwd_idx(tc + 1, q4, cj1);
+                const float g0 = shifted ? aux[q4].y : aux[q4].x, g1 = aux[q4].y;
+                const float2 u0 = shifted ? rawf[q4][1] : rawf[q4][0], u1 = rawf[q4][1];
+                const float c0 = shifted ? cj1 : cj0;
+                v0 = make_float2(u0.x * g0, c0 * u0.y * g0);
+                v1 = make_float2(u1.x * g1, cj1 * u1.y * g1);
+            }
+            gx[q4][0] = ok0 ? v0 : make_float2(0.f, 0.f);
+            gx[q4][1] = ok1 ? v1 : make_float2(0.f, 0.f);
+        }
         float4 y[4];
         float2 gt[3][2];
 #pragma unroll
@@ -215,8 +240,10 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j) {
+                        if (XSQ_D4_ABL & 1) { acc[i][j][kk] += av[i][kk] * bv[j][kk]; continue; }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+                    }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     // The four waves hold interleaved parts of every output row, so the tile is transposed through
     // LDS (32 rows x 256 floats at a time, row stride 260) and written as 16-byte stores of two
     // consecutive complex outputs per lane -- full 128-byte lines instead of 4-byte scatters.
+    if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][9] == 1.2345e-30f) __builtin_trap(); return; }
     constexpr int TLD = 260;
     float* const Tt = lds;                       // reuses the staging buffers (33,280 B needed)
     const int kq0 = t.n0 >> 1;                   // first k of the tile
@@ -271,7 +299,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
                     const int rb = mrow / a.S, rs = mrow - rb * a.S;
                     d = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg + pos);
                 }
-                *reinterpret_cast<float4*>(d) = v;
+                if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
             }
         }
     }
