@@ -122,21 +122,35 @@ struct GatherSched {
 // SIGN = +1 uses the conjugate twiddles.
 template <int SIGN>
 __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restrict__ w1, const float2* w2s, int tid) {
-    for (int bf = tid; bf < FFT_R1 * FFT_R3; bf += 256) {
-        const int k1 = bf / FFT_R3, n3 = bf - k1 * FFT_R3;
-        float2* base = Z + k1 * FFT_M1 + n3;
+    // 645 butterflies over 256 threads = 3 rounds; the 14 step-1 twiddles of round i + 1 are requested before
+    // round i computes (they come from L2: one exposed round trip per round otherwise)
+    constexpr int NB = FFT_R1 * FFT_R3, ROUNDS = (NB + 255) / 256;
+    float2 w[2][FFT_R2];
+    auto load_w = [&](int set, int bf) {
+        const int bfc = bf < NB ? bf : NB - 1;
+        const int k1 = bfc / FFT_R3, n3 = bfc - k1 * FFT_R3;
         const float2* wb = w1 + k1 * FFT_M1 + n3;
-        float2 v[FFT_R2], w[FFT_R2];
 #pragma unroll
-        for (int n2 = 0; n2 < FFT_R2; ++n2) w[n2] = wb[n2 * FFT_R3];
+        for (int n2 = 0; n2 < FFT_R2; ++n2) w[set][n2] = wb[n2 * FFT_R3];
+    };
+    load_w(0, tid);
 #pragma unroll
-        for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = base[n2 * FFT_R3];
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int bf = tid + 256 * r;
+        if (r + 1 < ROUNDS) load_w((r + 1) & 1, bf + 256);
+        if (bf < NB) {
+            const int k1 = bf / FFT_R3, n3 = bf - k1 * FFT_R3;
+            float2* base = Z + k1 * FFT_M1 + n3;
+            float2 v[FFT_R2];
 #pragma unroll
-        for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = SIGN < 0 ? c_mul(v[n2], w[n2]) : c_mulc(v[n2], w[n2]);
-        dft_small<FFT_R2, SIGN>(v, [&](int k2, float2 X) {
-            const float2 t = w2s[k2 * FFT_R3 + n3];
-            base[k2 * FFT_R3] = SIGN < 0 ? c_mul(X, t) : c_mulc(X, t);
-        });
+            for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = base[n2 * FFT_R3];
+#pragma unroll
+            for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = SIGN < 0 ? c_mul(v[n2], w[r & 1][n2]) : c_mulc(v[n2], w[r & 1][n2]);
+            dft_small<FFT_R2, SIGN>(v, [&](int k2, float2 X) {
+                const float2 t = w2s[k2 * FFT_R3 + n3];
+                base[k2 * FFT_R3] = SIGN < 0 ? c_mul(X, t) : c_mulc(X, t);
+            });
+        }
     }
     __syncthreads();
     for (int bf = tid; bf < FFT_R1 * FFT_R2; bf += 256) {
@@ -196,12 +210,22 @@ __global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x,
     // real post-processing: U[k] = E + G, U[N-k] = conj(E - G), E = (Z[k] + conj Z[N-k])/2,
     // G = -i/2 * W_L^k * (Z[k] - conj Z[N-k])
     float2* Ur = U + (int64_t)row * (FFT_N + 1);
-    for (int k = tid; k <= FFT_N / 2; k += 256) {
+    // the 18 W_L^k of this lane are requested together, ahead of the loop: a table load inside the loop body
+    // (waited for in every iteration, and on this target a wait for a load also waits for the stores issued
+    // before it) made the loop one memory round trip per iteration
+    constexpr int NPP = (FFT_N / 2 + 256) / 256;           // 18 iterations cover k = 0 .. N/2
+    float2 wlr[NPP];
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) { const int k = tid + 256 * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int k = tid + 256 * i;
+        if (k > FFT_N / 2) break;
         const float2 zk = Z[fft_pos(k)];
         const float2 zn = Z[fft_pos(k == 0 ? 0 : FFT_N - k)];
         const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const float2 D = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-        const float2 td = c_mul(T.wl[k], D);
+        const float2 td = c_mul(wlr[i], D);
         const float2 G = make_float2(td.y, -td.x);   // -i * td
         Ur[k] = c_add(E, G);
         Ur[FFT_N - k] = make_float2(E.x - G.x, -(E.y - G.y));
@@ -257,12 +281,19 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
     }
     // real pre-processing in place: Zin[k] = E + i O, Zin[N-k] = conj(E) + i conj(O),
     // E = U[k] + conj U[N-k], O = (U[k] - conj U[N-k]) * conj(W_L^k)   (no 1/2: output = L * irfft)
-    for (int k = tid; k <= FFT_N / 2; k += 256) {
+    constexpr int NPP = (FFT_N / 2 + 256) / 256;           // 18 iterations; table values requested together (see k_slice_rfft)
+    float2 wlr[NPP];
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) { const int k = tid + 256 * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int k = tid + 256 * i;
+        if (k > FFT_N / 2) break;
         float2 uk = Z[k], un = Z[FFT_N - k];
         if (k == 0) { uk.y = 0.f; un.y = 0.f; }   // irfft ignores Im of DC / Nyquist (nsigtf.py:103)
         const float2 E = make_float2(uk.x + un.x, uk.y - un.y);
         const float2 D = make_float2(uk.x - un.x, uk.y + un.y);
-        const float2 O = c_mulc(D, T.wl[k]);
+        const float2 O = c_mulc(D, wlr[i]);
         Z[k] = make_float2(E.x - O.y, E.y + O.x);
         if (k != 0) Z[FFT_N - k] = make_float2(E.x + O.y, O.x - E.y);
     }
