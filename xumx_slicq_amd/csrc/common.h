@@ -34,6 +34,14 @@ void set_error(const char* fmt, ...);
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Sixteen zero bytes in device memory: an out-of-range operand load can be pointed here instead of being
+// branched around (used by the band operators of slicqt.hip, whose loads must stay unpredicated next to the
+// mask stream).
+// (not `const`: a constant-address-space object next to a global pointer in one select turns the load into a
+// flat_load, which counts against both memory counters)
+static __device__ float4 g_zero16;       // zero-initialised, never written
+__device__ __forceinline__ const float* zero16() { return reinterpret_cast<const float*>(&g_zero16); }
+
 struct TileDev;
 // tiles of one group: 128-row x 64-column tiles, plus a 32-column tile when the N tail is <= 32
 template <class Vec>

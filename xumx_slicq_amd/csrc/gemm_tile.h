@@ -18,6 +18,8 @@
 // up front and the 16 MFMAs then run back to back.  LDS is double-buffered (one barrier per
 // K-step); the next K-step's global loads are in flight during the MFMAs.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 // Diagnostic builds only (tools/ablate.sh): bit 0 skip MFMAs, bit 1 skip A global loads,
@@ -29,6 +31,13 @@
 namespace xsq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Optional second operand stream of an operator (e.g. the masks of the masked synthesis): `typedef ... Aux`,
+// `Aux load_aux(g, row, k)` is issued next to load_a4 and `float4 finish(v, aux)` is applied when the K-step
+// goes into LDS -- never inside the load phase, where consuming a value means waiting for it.
+struct NoAux {};
+template <class Op, class = void> struct aux_of { typedef NoAux type; static constexpr bool on = false; };
+template <class Op> struct aux_of<Op, std::void_t<typename Op::Aux>> { typedef typename Op::Aux type; static constexpr bool on = true; };
 
 // Blocks b and b+8 share an XCD (observed round-robin placement; speed only, never
 // correctness).  Tiles that are neighbours in the table share the B matrix of their group and
@@ -82,11 +91,18 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     // HBM/L2 round trip, so a distance of one left the loads on the critical path.
     float4 ga[2][RA];
     float4 gb[2];
+    typename aux_of<Op>::type gx[2][RA];
+    // (Measured: issuing the loads unconditionally -- out-of-range addresses redirected to a zero buffer so that
+    // the compiler can count the loads in flight instead of waiting with vmcnt(0) -- made the short-K operators
+    // SLOWER (layer 1: 0.74 -> 0.85 ms): two extra load sets per tile and a 64-bit select per address.)
     auto load_set = [&](int set, int k) {          // set is a compile-time constant at every call site
         if (k < K) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                if (!(XSQ_ABLATE & 2) || k == 0) ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
+                if (!(XSQ_ABLATE & 2) || k == 0) {
+                    ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
+                    if constexpr (aux_of<Op>::on) gx[set][i] = op.load_aux(g, ra[i], k + s_kq);
+                }
             if (b_on && (!(XSQ_ABLATE & 4) || k == 0)) gb[set] = *reinterpret_cast<const float4*>(bp + k);
         }
     };
@@ -94,8 +110,11 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         float* Aw = As0 + buf * BM * LD;
         float* Bw = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<float4*>(&Aw[(s_row + 64 * i) * LD + s_kq]) = ga[set][i];
+        for (int i = 0; i < RA; ++i) {
+            float4 v = ga[set][i];
+            if constexpr (aux_of<Op>::on) v = op.finish(v, gx[set][i]);
+            *reinterpret_cast<float4*>(&Aw[(s_row + 64 * i) * LD + s_kq]) = v;
+        }
         *reinterpret_cast<float4*>(&Bw[s_row * LD + s_kq]) = gb[set];
     };
 #pragma unroll

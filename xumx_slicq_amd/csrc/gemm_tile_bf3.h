@@ -49,6 +49,7 @@ __device__ __forceinline__ float bf3_word(float x) {
 // 20 or 36 words, both conflict-free for ds_read_b128 over 16 consecutive rows)
 template <class Op, int MT = 1, int KS = 1>
 __global__ __launch_bounds__(256) void grouped_gemm_bf3_kernel(Op op, const TileDev* __restrict__ tiles, int ntiles) {
+    static_assert(!aux_of<Op>::on, "operators with an aux stream run on the fp32 engine");
     constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = 16 * KS, LD = 16 * KS + 4;
     constexpr int RA = BM / 64;
 

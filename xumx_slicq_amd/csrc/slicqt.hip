@@ -130,13 +130,12 @@ struct BandFwdOp {
     // two complex bins per call; bins outside [0, L/2] come from the Hermitian mirror (their
     // conjugation is folded into the signs of Wf's imaginary rows)
     __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r.p == nullptr || k >= g.K) return v;
+        const bool ok = r.p != nullptr && k < g.K;                       // out of range: both loads read zero16()
         int i0 = g.bin0 + (k >> 1), i1 = i0 + 1;
         i0 = i0 < 0 ? -i0 : (i0 > L / 2 ? L - i0 : i0);
         i1 = i1 < 0 ? -i1 : (i1 > L / 2 ? L - i1 : i1);
-        const float2 a = *reinterpret_cast<const float2*>(r.p + 2 * i0);
-        const float2 b = *reinterpret_cast<const float2*>(r.p + 2 * i1);
+        const float2 a = *reinterpret_cast<const float2*>(ok ? r.p + 2 * i0 : zero16());
+        const float2 b = *reinterpret_cast<const float2*>(ok ? r.p + 2 * i1 : zero16());
         return make_float4(a.x, a.y, b.x, b.y);
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
@@ -195,12 +194,18 @@ struct BandInvOp {
         return r;
     }
     __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
-        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v = *reinterpret_cast<const float4*>(r.p + k);  // rows are 32-byte aligned (Lg % 4 == 0)
-        if (r.mk) {
-            const float2 mk = *reinterpret_cast<const float2*>(r.mk + (k >> 1));
-            v.x *= mk.x; v.y *= mk.x; v.z *= mk.y; v.w *= mk.y;
-        }
+        const bool ok = r.p != nullptr && k < g.K;
+        return *reinterpret_cast<const float4*>(ok ? r.p + k : zero16());  // rows are 32-byte aligned (Lg % 4 == 0)
+    }
+    // masked synthesis: the two masks of the K-chunk travel beside the coefficients and are applied when the
+    // K-step goes into LDS (gemm_tile.h, aux hook)
+    typedef float2 Aux;
+    __device__ Aux load_aux(const Group& g, const RowA& r, int k) const {
+        const bool ok = r.mk != nullptr && k < g.K;
+        return *reinterpret_cast<const float2*>(ok ? r.mk + (k >> 1) : zero16());
+    }
+    __device__ float4 finish(float4 v, const Aux& mk) const {
+        if (mask) { v.x *= mk.x; v.y *= mk.x; v.z *= mk.y; v.w *= mk.y; }      // uniform
         return v;
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool wide) const {
