@@ -91,7 +91,6 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     const float* win = a.pool + bd.win_off;
     const int mpad = (m_ + 7) & ~7;
     const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
-    for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the prologue barrier below
     const float* bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
     const bool b_on = wide || s_row < 32;
 
@@ -208,7 +207,15 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lrow = lane & 31, lk = lane >> 5;
+    // epilogue constants of this lane (synthesis: the two dual-window values), requested here with the first
+    // operand loads and the twiddle table -- one memory round trip for the prologue instead of three, none in the epilogue
+    const int e_c4 = tid & 63;                   // float4 slot of an output row: complex outputs 2*c4, 2*c4+1
+    const int e_q = 4 * (t.n0 >> 1) + 2 * e_c4;
+    const bool e_on = e_c4 < (wide ? 64 : 32) && e_q < Lg;
+    float e_w0 = 1.f, e_w1 = 1.f;
     load_set(0);
+    if (!FWD && e_on) { e_w0 = win[e_q]; e_w1 = win[e_q + 1]; }
+    for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the barrier below
     __syncthreads();             // twiddle table complete
     store_set(0);
     __syncthreads();
@@ -263,7 +270,6 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][9] == 1.2345e-30f) __builtin_trap(); return; }
     constexpr int TLD = 260;
     float* const Tt = lds;                       // reuses the staging buffers (33,280 B needed)
-    const int kq0 = t.n0 >> 1;                   // first k of the tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -275,13 +281,11 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
             for (int r = 0; r < 16; ++r) Tt[(acc_row(r) + 4 * lk) * TLD + col] = acc[i][j][r];
         }
         __syncthreads();
-        const int c4 = tid & 63;                 // float4 slot of the row: complex outputs 2*c4, 2*c4+1
-        const int q = 4 * kq0 + 2 * c4;
-        if (c4 < (wide ? 64 : 32) && q < Lg) {
-            float w0 = 1.f, w1 = 1.f;
+        const int c4 = e_c4, q = e_q;
+        if (e_on) {
+            const float w0 = e_w0, w1 = e_w1;
             int pos = q;
             if (!FWD) {
-                w0 = win[q]; w1 = win[q + 1];
                 pos = q + 2 * m_;                // spectrum position p = (q + Lg/2) mod Lg
                 if (pos >= Lg) pos -= Lg;
             }

@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ scale, int nblocks,
                                                            int BC, int S, int64_t nquads, int split) {
+    // block boundaries in LDS: the binary search below was seven DEPENDENT global loads per thread
+    __shared__ int64_t cum_s[128];
+    for (int i = threadIdx.x; i < nblocks && i < 128; i += 256) cum_s[i] = cum[i];
+    __syncthreads();
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= nquads) return;
     const int64_t i = 4 * q;
@@ -47,10 +51,10 @@ __global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restri
     int lo = 0, hi = nblocks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (per * cum[mid] <= i) lo = mid; else hi = mid - 1;
+        if (per * (nblocks <= 128 ? cum_s[mid] : cum[mid]) <= i) lo = mid; else hi = mid - 1;
     }
     const CdaeBlockDev& b = blocks[lo];
-    const int64_t r = i - per * cum[lo];
+    const int64_t r = i - per * (nblocks <= 128 ? cum_s[lo] : cum[lo]);
     const int f = (int)((r / ((int64_t)S * b.T)) % b.F);
     const float mu = mean[b.cumF + f], sc = scale[b.cumF + f];
     const float4 z0 = X[2 * q], z1 = X[2 * q + 1];
