@@ -89,11 +89,13 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
     return w
 
 
-_PMC_NAMES = {"cdae_l1_gemm": "gemm<CdaeL1Op>", "cdae_l2_gemm": "gemm<CdaeL2Op>", "cdae_l3_gemm": "gemm<CdaeL3Op>",
-              "cdae_l4_gemm": "gemm<CdaeL4Op>", "band_synthesis_gemm": "gemm<BandInvOp>",
-              "band_analysis_gemm": "gemm<BandFwdOp>", "band_synthesis_dft4": "band_dft4<inverse>",
-              "band_analysis_dft4": "band_dft4<forward>", "slice_irfft": "k_slice_irfft", "slice_rfft": "k_slice_rfft",
-              "overlap_add": "k_overlap_add", "magnitude_whiten": "k_magnitude_whiten"}
+# event name -> the kernels launched under it (layers 2/3: the slab kernel for long inputs, the generic engine for the tail)
+_PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["slab<CdaeL2>", "gemm<CdaeL2Op>"],
+              "cdae_l3_gemm": ["slab<CdaeL3>", "gemm<CdaeL3Op>"],
+              "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
+              "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4<inverse>"],
+              "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
+              "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"]}
 
 
 def pmc_traffic(kernel):
@@ -106,14 +108,17 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
     if not files or kernel not in _PMC_NAMES:
         return None
+    total, launches = 0.0, 0
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if row["Kernel"] == _PMC_NAMES[kernel]:
+            if row["Kernel"] in _PMC_NAMES[kernel]:
                 try:
-                    return int((2.0 * float(row["fetch_KB_mean_raw"]) + float(row["write_KB_mean_raw"])) * 1024)
+                    n = int(float(row["launches"]))
+                    total += n * (2.0 * float(row["fetch_KB_mean_raw"]) + float(row["write_KB_mean_raw"])) * 1024
+                    launches += n
                 except (KeyError, ValueError):
                     return None
-    return None
+    return int(total / launches) if launches else None
 
 
 def cpu_baseline(threads):

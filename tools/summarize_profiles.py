@@ -26,7 +26,8 @@ glob.glob = newest
 def short(n):
     import re
     n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")
-    n = n.replace("void xsq::cdae_slab_kernel<false>", "slab_bf3<CdaeL2>").replace("void xsq::cdae_slab_kernel<true>", "slab_bf3<CdaeL3>")
+    n = n.replace("void xsq::cdae_slab_kernel<false, true>", "slab_bf3<CdaeL2>").replace("void xsq::cdae_slab_kernel<true, true>", "slab_bf3<CdaeL3>")
+    n = n.replace("void xsq::cdae_slab_kernel<false, false>", "slab<CdaeL2>").replace("void xsq::cdae_slab_kernel<true, false>", "slab<CdaeL3>")
     n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+), \d+>", r"gemm<\1>", n)
     n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("xsq::", "")
