@@ -22,6 +22,7 @@
 #include "../../include/xumx_slicq_hip.h"
 #include "gemm_tile.h"
 #include "gemm_tile_bf3.h"
+#include "gemm_tile_bf6.h"
 #include "plan.h"
 #include "prof.h"
 
@@ -643,7 +644,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
 
 int xsq_model_set_precision(xsq_model* Mo, int mode) {
     XSQ_REQUIRE(Mo, "xsq_model_set_precision: null model");
-    XSQ_REQUIRE(mode == 0 || mode == 1, "xsq_model_set_precision: mode %d (0 = fp32, 1 = split bf16)", mode);
+    XSQ_REQUIRE(mode >= 0 && mode <= 2, "xsq_model_set_precision: mode %d (0 = fp32, 1 = bf16x3, 2 = bf16x6)", mode);
     if (mode == 1 && !Mo->d_pool_split) {      // one-off: the weight pool in the split operand format
         XSQ_HIP(hipMalloc(&Mo->d_pool_split, (size_t)Mo->pool_floats * 4));
         hipLaunchKernelGGL(k_split_pool, dim3((unsigned)((Mo->pool_floats + 255) / 256)), dim3(256), 0, 0, Mo->d_pool,
@@ -693,9 +694,10 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block; split the batch", a.Bn, a.S);
     if (layer == 4 && a.gx8) layer = 6;
     const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
+    const bool bf6 = Mo->precision == 2 && !a.raw && !a.xin8 && !a.gx8;       // fp32 operands, cut in the kernel
     static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
-    if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
+    if (!bf6 && !(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
         (bf3 || !(variant & 8))) {
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
@@ -711,7 +713,8 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     if (rc) return rc;
 #define XSQ_LAUNCH(OP, MT_)                                                                                         \
     do {                                                                                                            \
-        if (!bf3) hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
+        if (bf6) hipLaunchKernelGGL((grouped_gemm_bf6_kernel<OP>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);           \
+        else if (!bf3) hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
         else if (variant & 2) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 2>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
         else hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 1>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
     } while (0)

@@ -27,7 +27,7 @@ from .weights import freq_filter
 import os
 
 # xsq_model_set_precision modes (include/xumx_slicq_hip.h)
-_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
 class _CausalConv2d(Conv2d):
