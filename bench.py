@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3"],
                     help="arithmetic of the convolution contractions for the headline value (default: exact fp32)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--graph", action="store_true",
@@ -228,23 +228,28 @@ def main():
     variants = None
     if world == 1 and not args.no_variants and args.precision == "fp32":
         ref_out = out.clone()
-        sep.xumx_model.set_precision("bf16x3")
-        for _ in range(max(1, args.warmup)):
-            step()
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(args.steps):
-            vout = step()
-        torch.cuda.synchronize()
-        tv = time.perf_counter() - tv
-        d = (vout - ref_out).double()
-        variants = {"bf16x3": {
-            "what": "conv contractions as 3 x bf16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; everything else unchanged",
-            "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
-            "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
-                              "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}}
+        variants = {}
+        what = {"bf16x6": "conv contractions as 6 x bf16 MFMA on fp32 operands cut exactly into three bf16 pieces (dropped terms <= 2^-23 |ab|: fp32-grade), fp32 accumulate; everything else unchanged",
+                "bf16x3": "conv contractions as 3 x bf16 MFMA on hi/lo-split fp32 operands (~2^-17 per product), fp32 accumulate; everything else unchanged"}
+        for prec in ("bf16x6", "bf16x3"):
+            sep.xumx_model.set_precision(prec)
+            for _ in range(max(1, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(args.steps):
+                vout = step()
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            d = (vout - ref_out).double()
+            variants[prec] = {
+                "what": what[prec],
+                "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
+                "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
+                                  "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}
+            del vout, d
         sep.xumx_model.set_precision("fp32")
-        del ref_out, vout, d
+        del ref_out
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -268,8 +273,8 @@ def main():
                 ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
             else:
                 ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
-                if args.precision == "bf16x3" and dom.startswith("cdae_"):
-                    peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)      # useful flops at three bf16 MFMAs per product
+                if args.precision != "fp32" and dom.startswith("cdae_"):      # useful flops at 3 / 6 bf16 MFMAs per product
+                    peak = round(BF16_MFMA_PEAK_TFLOPS / (3.0 if args.precision == "bf16x3" else 6.0), 1)
             roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                         "avg_launch_ms": round(ms / launches, 4), "launches": launches,
@@ -281,7 +286,8 @@ def main():
             "value": round(audio_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16x6": "f32 (conv contractions: exact 3-way bf16 cut, 6 bf16 MFMAs per product, fp32 accumulate)",
+                      "bf16x3": "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
                                    "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"

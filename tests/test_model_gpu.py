@@ -388,3 +388,49 @@ def test_precision_switch_is_clean(seps):
     assert float(d.pow(2).mean().sqrt()) < 1e-5 and float(d.abs().max()) < 1e-4
     with pytest.raises(ValueError):
         sep.xumx_model.set_precision("fp8")
+
+
+# ---- bf16x6: exact three-way bf16 cut of every fp32 operand, six MFMAs per product (xsq_model_set_precision 2) -----
+# The dropped partial products are <= 2^-23 |ab|, one fp32 rounding: the stems must sit as close to the reference
+# as the fp32 MFMA path does (both ~1.1e-7 RMS on the CPU oracle), far inside the 1e-4 / 1e-3 bar.
+@pytest.mark.parametrize("name,causal,wiener,n", [
+    ("realtime", True, False, 441000),               # S = 50: layers 2/3 on the slab kernels
+    ("offline_phasemix", False, False, 450000),
+    ("offline_wiener", False, True, 200000),         # S = 24: generic bf16x6 engine
+])
+def test_bf16x6_is_fp32_grade(seps, oracle_plan, seeded_sd, name, causal, wiener, n):
+    from oracle import separator as osep
+    sep = seps[name]
+    sep.chunk_size = 2621440
+    x = synth_audio(n, seed=5 + n)
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=causal, wiener=wiener)
+    err = {}
+    try:
+        for prec in ("fp32", "bf16x6"):
+            sep.xumx_model.set_precision(prec)
+            d = sep(x.cuda()).cpu() - ref
+            err[prec] = (float(d.pow(2).mean().sqrt()), float(d.abs().max()))
+    finally:
+        sep.xumx_model.set_precision("fp32")
+    assert err["bf16x6"][0] < RMS_TOL and err["bf16x6"][1] < MAX_TOL, err
+    assert err["bf16x6"][0] < 1e-6 and err["bf16x6"][1] < 1e-5, err
+    assert err["bf16x6"][0] < 2.0 * err["fp32"][0] + 1e-8, ("bf16x6 should be as close to the reference as fp32 MFMA", err)
+
+
+@pytest.mark.parametrize("n", [9031, 100000])
+@pytest.mark.parametrize("name", ["realtime", "offline_phasemix", "offline_wiener"])
+def test_bf16x6_stems_match_reference_golden(seps, n, name):
+    g = load_golden(f"stems_{n}.npz")
+    sep = seps[name]
+    try:
+        sep.xumx_model.set_precision("bf16x6")
+        sep.chunk_size = int(g["chunk_size"])
+        est = sep(synth_audio(n, seed=20260101 + n).cuda())
+    finally:
+        sep.xumx_model.set_precision("fp32")
+        sep.chunk_size = 2621440
+    ref = torch.from_numpy(g[name])
+    got = est.cpu() if n == 9031 else est.cpu()[..., ::7]
+    d = got - ref
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    assert rms < 1e-6 and mx < 1e-5, (name, n, rms, mx)

@@ -1,5 +1,5 @@
-"""fp32 vs split-bf16 convolution contractions: stem error (against the fp32 path, which is pinned to the
-reference at 1.4e-7 RMS) and step time on the 240 s bench track."""
+"""fp32 vs the bf16 modes of the convolution contractions on the 240 s bench track: stem error against the fp32
+path (itself pinned to the reference at 1.1e-7 RMS) and step time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,11 +7,12 @@ from xumx_slicq_amd import _lib
 from xumx_slicq_amd.separator import seeded_separator
 from xumx_slicq_amd.synth import synth_audio
 dev = torch.device("cuda", 0)
+modes = sys.argv[1:] or ["bf16x6", "bf16x3"]
 for wiener in (False, True):
     sep = seeded_separator(realtime=False, wiener=wiener, device=dev)
     x = synth_audio(10_584_000, seed=20260101).to(dev)
     res = {}
-    for prec in ("fp32", "bf16x3"):
+    for prec in ["fp32"] + modes:
         sep.xumx_model.set_precision(prec)
         for _ in range(2):
             out = sep(x)
@@ -25,6 +26,7 @@ for wiener in (False, True):
         prof = _lib.profile_read(); _lib.profile_enable(False)
         res[prec] = out.clone()
         print(f"wiener={wiener} {prec}: {dt*1e3:.3f} ms/step", {k: round(v[0] / 5, 3) for k, v in prof.items() if "cdae" in k}, flush=True)
-    d = (res["bf16x3"] - res["fp32"]).double()
-    print(f"wiener={wiener}: bf16x3 vs fp32 stems: rms {d.pow(2).mean().sqrt():.3e} max {d.abs().max():.3e} "
-          f"(stem rms {res['fp32'].double().pow(2).mean().sqrt():.3e}, max {res['fp32'].abs().max():.3e})", flush=True)
+    for prec in modes:
+        d = (res[prec] - res["fp32"]).double()
+        print(f"wiener={wiener}: {prec} vs fp32 stems: rms {d.pow(2).mean().sqrt():.3e} max {d.abs().max():.3e} "
+              f"(stem rms {res['fp32'].double().pow(2).mean().sqrt():.3e}, max {res['fp32'].abs().max():.3e})", flush=True)

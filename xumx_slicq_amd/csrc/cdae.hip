@@ -697,16 +697,16 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     const bool bf6 = Mo->precision == 2 && !a.raw && !a.xin8 && !a.gx8;       // fp32 operands, cut in the kernel
     static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
-    if (!bf6 && !(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
-        (bf3 || !(variant & 8))) {
+    if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
+        (bf3 || bf6 || !(variant & 8))) {
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_gemm" : "cdae_l3_gemm"), stream);
-        if (layer == 2 && bf3) hipLaunchKernelGGL((cdae_slab_kernel<false, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
-        else if (layer == 2) hipLaunchKernelGGL((cdae_slab_kernel<false, false>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
-        else if (bf3) hipLaunchKernelGGL((cdae_slab_kernel<true, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
-        else hipLaunchKernelGGL((cdae_slab_kernel<true, false>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles);
+#define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
+        if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else XSQ_SLAB(false, 0); }
+        else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else XSQ_SLAB(true, 0); }
+#undef XSQ_SLAB
         return XSQ_OK;
     }
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23);

@@ -12,12 +12,13 @@
 // (row position * 52 + k): the 4x overlap is served by LDS.  B (the weights of this df, 64 x 208 words)
 // streams through a double-buffered LDS tile shared by the 8 waves of the workgroup.
 //   L2 -> LDS traffic per 256 rows and df:  A 54 KB + B 53 KB   (generic engine, 2 x 128 rows: 212 + 106 KB)
-//   LDS: 2 x 27.9 KB slab planes + a ring of three 7.3 KB B tiles = 76.6 KB -> two 512-thread workgroups per CU.
+//   LDS: 2 x 27.9 KB slab planes + two B tiles (7.3 KB; 10.6 KB for bf16x6) -> two 512-thread workgroups per CU.
 // Plane row stride is 52 bf16 = 104 B: the 32 lanes of a ds_read_b64 fragment read hit 32 distinct even
 // banks (26 r mod 64), conflict-free; B tile rows are 36 words (conflict-free ds_read_b128, gemm_tile_bf3.h).
 #pragma once
 #include "cdae_api.h"
 #include "gemm_tile_bf3.h"
+#include "gemm_tile_bf6.h"
 
 #ifndef XSQ_SLAB_ABL
 #define XSQ_SLAB_ABL 0      // diagnostic builds: 1 no MFMAs, 2 no fragment reads, 4 no B loads, 8 no slab loads, 16 no epilogue
@@ -30,19 +31,24 @@ constexpr int SLAB_MAXSEG = 4;                 // (b, f) rows a tile may touch (
 constexpr int SLAB_POS = SLAB_ROWS + 3 * SLAB_MAXSEG;
 constexpr int SLAB_KRUN = 4 * CS;              // 208 words per df
 constexpr int SLAB_BLD = 36;                   // B tile row: 32 k-values as (16 hi | 16 lo) x 2 + 4 pad words
+constexpr int SLAB_BLD6 = 52;                  // bf16x6: 2 chunks x 3 pieces x 8 words + 4 pad words (13 x 4: conflict-free)
 constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored channels (columns 52..63 of the MFMA tile are never stored)
 
 // TRANSPOSED = false: layer 2, in = act1 (Fi = F1 rows of Ti = T1), input row f + df, positions t .. t + 3
 // TRANSPOSED = true : layer 3, in = act2 (Fi = F2 rows of Ti = T2), input row f - df, positions t - 3 .. t
-// BF3 = true : operands in the split format, v_mfma_f32_32x32x16_bf16 x 3 (gemm_tile_bf3.h)
-// BF3 = false: plain fp32 operands, v_mfma_f32_32x32x2_f32 with the engine's k permutation (MFMA i of a
+// MODE 1 (bf16x3): operands in the split format, v_mfma_f32_32x32x16_bf16 x 3 (gemm_tile_bf3.h)
+// MODE 0 (fp32)  : plain fp32 operands, v_mfma_f32_32x32x2_f32 with the engine's k permutation (MFMA i of a
 //              16-value chunk takes k = i from the lower half-wave and k = 8 + i from the upper one, gemm_tile.h):
 //              the slab is then ONE fp32 plane (same 55.7 KB; row stride 52 words, conflict-free ds_read_b128)
-template <bool TRANSPOSED, bool BF3>
+// MODE 2 (bf16x6): plain fp32 operands, fp32 slab plane; the A fragment is cut into its three bf16 pieces when
+//              it is read (gemm_tile_bf6.h), the B tile holds the three pieces of the weights; six bf16 MFMAs
+template <bool TRANSPOSED, int MODE>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
+    constexpr bool BF3 = MODE == 1, BF6 = MODE == 2;
+    constexpr int BLD = BF6 ? SLAB_BLD6 : SLAB_BLD;               // words per B tile row
     constexpr int PLANE = SLAB_POS * CS + 64;                    // bf16 elements per plane (a multiple of 8)
     __shared__ __attribute__((aligned(16))) unsigned short slab_raw[2 * PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned Bs[3 * SLAB_BN * SLAB_BLD];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2 * SLAB_BN * BLD];
     unsigned short* const slabH = slab_raw;                      // BF3: hi plane | lo plane
     unsigned short* const slabL = slab_raw + PLANE;
     float* const slabF = reinterpret_cast<float*>(slab_raw);     // fp32: one plane over the same bytes
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         }
     };
     // ---- B stream: one K-step = 52 rows x 32 words, loaded by threads 0..415 (one float4 each) two slots
-    // before it is written into a ring of three LDS tiles, which happens two slots before it is used ------
+    // before it is written into the LDS tile that the NEXT slot reads (two tiles, two register sets) ------------
     const bool b_ld = tid < SLAB_BN * 8;
     const int b_row = tid >> 3, b_k = (tid & 7) * 4;                 // word offset inside the K-step
     const float* bp = Bt + (int64_t)b_row * ldb + b_k;
@@ -138,13 +144,22 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     };
     auto store_b = [&](int set, int buf) {
         if (!b_ld) return;
-        if (!BF3) { *reinterpret_cast<float4*>(Bs + buf * SLAB_BN * SLAB_BLD + b_row * SLAB_BLD + b_k) = gb[set]; return; }
-        unsigned* row = Bs + buf * SLAB_BN * SLAB_BLD + b_row * SLAB_BLD + 16 * (b_k >> 4);
-        const int q2 = (b_k & 15) >> 1;
+        unsigned* row = Bs + buf * SLAB_BN * BLD + b_row * BLD;
+        if (MODE == 0) { *reinterpret_cast<float4*>(row + b_k) = gb[set]; return; }
+        const int c = b_k >> 4, q2 = (b_k & 15) >> 1;
+        if (BF6) {
+            unsigned a1, a2, a3, b1, b2, b3;
+            bf6_cut2(gb[set].x, gb[set].y, a1, a2, a3);
+            bf6_cut2(gb[set].z, gb[set].w, b1, b2, b3);
+            *reinterpret_cast<uint2*>(row + 24 * c + q2) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(row + 24 * c + 8 + q2) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(row + 24 * c + 16 + q2) = make_uint2(a3, b3);
+            return;
+        }
         const unsigned e0 = __builtin_bit_cast(unsigned, gb[set].x), e1 = __builtin_bit_cast(unsigned, gb[set].y);
         const unsigned e2 = __builtin_bit_cast(unsigned, gb[set].z), e3 = __builtin_bit_cast(unsigned, gb[set].w);
-        *reinterpret_cast<uint2*>(row + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
-        *reinterpret_cast<uint2*>(row + 8 + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u));
+        *reinterpret_cast<uint2*>(row + 16 * c + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
+        *reinterpret_cast<uint2*>(row + 16 * c + 8 + q2) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x05040100u), __builtin_amdgcn_perm(e3, e2, 0x05040100u));
     };
 
     f32x16 acc0, acc1;
@@ -157,35 +172,33 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
     };
     auto bfrag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); };
-    const int b_frag0 = lrow * SLAB_BLD + (BF3 ? 4 : 8) * lk;
-    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * SLAB_BLD + (BF3 ? 4 : 8) * lk;     // columns >= 52 are never stored: any row will do
+    const int b_frag0 = lrow * BLD + (MODE == 0 ? 8 : 4) * lk;
+    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * BLD + (MODE == 0 ? 8 : 4) * lk;     // columns >= 52 are never stored: any row will do
+#define XSQ_MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
 
-    // Slots: every df owns 8 slots, 7 K-steps of 32 (the last half empty) and one slot in which the next
-    // slab goes into LDS; slot parity = register set, so all register indices are compile-time.  Global slot
-    // G = 8 * (df index) + ks; the K-step of slot G sits in ring tile G % 3.
+    // Slots: every df owns 8 slots -- 7 K-steps of 32 (the last half empty) and one in which the next slab goes
+    // into LDS -- so that slot parity = LDS tile = register set and every index below is compile-time.  The
+    // K-step of slot s is loaded in slot s - 3, written to tile s & 1 in slot s - 1 (last read in slot s - 2).
     constexpr int NKS = 7;
     load_slab(0);
     load_b(0, 0, 0);
-    load_b(1, 0, 1);
     store_slab();
     store_b(0, 0);
-    store_b(1, 1);
+    load_b(1, 0, 1);
     load_b(0, 0, 2);
-    load_b(1, 0, 3);
     if (kf > 1) load_slab(1);
     __syncthreads();
-    int ring = 0;                              // G % 3 of slot (df, 0)
     for (int df = 0; df < kf; ++df) {
         const bool more = df + 1 < kf;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             if (ks < NKS) {
-                const unsigned* Bb = Bs + ((ring + ks) % 3) * SLAB_BN * SLAB_BLD;
+                const unsigned* Bb = Bs + (ks & 1) * SLAB_BN * BLD;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int k = 32 * ks + 16 * c;
                     if (k < SLAB_KRUN) {       // compile-time: the second half of the last K-step does not exist
-                        if constexpr (!BF3) {
+                        if constexpr (MODE == 0) {
                             const float* Bf = reinterpret_cast<const float*>(Bb);
                             const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
                             const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
@@ -199,38 +212,51 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b0[kk], acc0, 0, 0, 0);
                                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b1[kk], acc1, 0, 0, 0);
                             }
-                            continue;
+                        } else if constexpr (MODE == 2) {
+                            const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
+                            const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
+                            unsigned u1[4], u2[4], u3[4];
+                            bf6_cut2(alo.x, alo.y, u1[0], u2[0], u3[0]);
+                            bf6_cut2(alo.z, alo.w, u1[1], u2[1], u3[1]);
+                            bf6_cut2(ahi.x, ahi.y, u1[2], u2[2], u3[2]);
+                            bf6_cut2(ahi.z, ahi.w, u1[3], u2[3], u3[3]);
+                            const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, make_uint4(u1[0], u1[1], u1[2], u1[3]));
+                            const bf16x8_t a2 = __builtin_bit_cast(bf16x8_t, make_uint4(u2[0], u2[1], u2[2], u2[3]));
+                            const bf16x8_t a3 = __builtin_bit_cast(bf16x8_t, make_uint4(u3[0], u3[1], u3[2], u3[3]));
+                            const unsigned* B0 = Bb + b_frag0 + 24 * c;
+                            const unsigned* B1 = Bb + b_frag1 + 24 * c;
+                            const bf16x8_t p1 = bfrag(B0), p2 = bfrag(B0 + 8), p3 = bfrag(B0 + 16);
+                            const bf16x8_t q1 = bfrag(B1), q2 = bfrag(B1 + 8), q3 = bfrag(B1 + 16);
+                            XSQ_MF(a1, p3, acc0); XSQ_MF(a1, q3, acc1);      // smallest terms first
+                            XSQ_MF(a3, p1, acc0); XSQ_MF(a3, q1, acc1);
+                            XSQ_MF(a2, p2, acc0); XSQ_MF(a2, q2, acc1);
+                            XSQ_MF(a1, p2, acc0); XSQ_MF(a1, q2, acc1);
+                            XSQ_MF(a2, p1, acc0); XSQ_MF(a2, q1, acc1);
+                            XSQ_MF(a1, p1, acc0); XSQ_MF(a1, q1, acc1);
+                        } else {
+                            const bf16x8_t ah = afrag(slabH, k), al = afrag(slabL, k);
+                            const bf16x8_t b0h = bfrag(Bb + b_frag0 + 16 * c), b0l = bfrag(Bb + b_frag0 + 16 * c + 8);
+                            const bf16x8_t b1h = bfrag(Bb + b_frag1 + 16 * c), b1l = bfrag(Bb + b_frag1 + 16 * c + 8);
+                            XSQ_MF(al, b0h, acc0); XSQ_MF(al, b1h, acc1);
+                            XSQ_MF(ah, b0l, acc0); XSQ_MF(ah, b1l, acc1);
+                            XSQ_MF(ah, b0h, acc0); XSQ_MF(ah, b1h, acc1);
                         }
-                        bf16x8_t ah, al, b0h, b0l, b1h, b1l;
-                        if (XSQ_SLAB_ABL & 2) { ah = al = b0h = b0l = b1h = b1l = __builtin_bit_cast(bf16x8_t, make_uint4(tid, k, ks, c)); }
-                        else {
-                            ah = afrag(slabH, k); al = afrag(slabL, k);
-                            b0h = bfrag(Bb + b_frag0 + 16 * c); b0l = bfrag(Bb + b_frag0 + 16 * c + 8);
-                            b1h = bfrag(Bb + b_frag1 + 16 * c); b1l = bfrag(Bb + b_frag1 + 16 * c + 8);
-                        }
-                        if (XSQ_SLAB_ABL & 1) { acc0[c] += (float)ah[0] + (float)al[1] + (float)b0h[2] + (float)b0l[3]; acc1[c] += (float)b1h[4] + (float)b1l[5]; continue; }
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
                     }
                 }
             } else if (more) {
                 store_slab();                  // slot 7: every wave has passed the barrier behind the slab's last reader
                 if (df + 2 < kf) load_slab(df + 2);
             }
-            // K-step of slot G + 2 (held in set ks % 2 since slot G - 2) -> ring tile (G + 2) % 3, last read in slot G - 1
-            if (ks + 2 < NKS) store_b(ks & 1, (ring + ks + 2) % 3);
-            else if (ks + 2 >= 8 && more) store_b(ks & 1, (ring + ks + 2) % 3);           // (df + 1, ks - 6)
-            // refill that set with the K-step of slot G + 4
-            if (ks + 4 < NKS) load_b(ks & 1, df, ks + 4);
-            else if (ks + 4 >= 8 && more) load_b(ks & 1, df + 1, ks - 4);
+            // K-step of slot s1 = ks + 1 -> tile s1 & 1 (read last in slot ks - 1); its register set is then refilled
+            // with the K-step of slot s3 = ks + 3
+            if (ks + 1 < NKS) store_b((ks + 1) & 1, (ks + 1) & 1);
+            else if (ks + 1 == 8 && more) store_b(0, 0);                               // (df + 1, 0)
+            if (ks + 3 < NKS) load_b((ks + 3) & 1, df, ks + 3);
+            else if (ks + 3 >= 8 && more) load_b((ks + 3) & 1, df + 1, ks + 3 - 8);
             __syncthreads();
         }
-        ring = (ring + 8) % 3;
     }
+#undef XSQ_MF
 
     if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
     relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, BF3);

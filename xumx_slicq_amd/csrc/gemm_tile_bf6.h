@@ -30,7 +30,10 @@ __device__ __forceinline__ void bf6_cut2(float x, float y, unsigned& p1, unsigne
 template <class Op>
 __global__ __launch_bounds__(256) void grouped_gemm_bf6_kernel(Op op, const TileDev* __restrict__ tiles, int ntiles) {
     static_assert(!aux_of<Op>::on, "operators with an aux stream run on the fp32 engine");
-    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = 16, LD = 28;
+#ifndef XSQ_BF6_LD
+#define XSQ_BF6_LD 28
+#endif
+    constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = 16, LD = XSQ_BF6_LD;
     constexpr int RA = BM / 64;
 
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * (BM + BN) * LD];
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf6_kernel(Op op, const Tile
     typename Op::RowA ra[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) ra[i] = op.row_a(g, t.m0 + s_row + 64 * i);
+    // (weights pre-cut on the device -- 24 B per four values, three 8-byte loads -- measured no faster than cutting
+    // them here from one 16-byte load)
     const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
     const bool b_on = wide || s_row < 32;
 
