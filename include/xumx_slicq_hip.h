@@ -128,12 +128,16 @@ int xsq_model_create(xsq_model** out, int nblocks, const int32_t* F, const int32
                      int causal, const float* params, int64_t nparams);
 int xsq_model_destroy(xsq_model* model);
 /* Arithmetic of the four convolution layers (the contraction only; epilogues, BatchNorm folding,
- * sigmoid and every other kernel of the path stay fp32):
- *   0  exact fp32 on v_mfma_f32_32x32x2_f32 (default; what the parity fixtures were pinned with)
- *   1  split bf16 ("bf16x3"): every fp32 operand carried as hi + lo bf16, three bf16 MFMAs per
- *      product, fp32 accumulation -- ~2^-17 relative per product (finer than the TF32 convolutions
- *      the reference's torch-cuda backend runs by default, model.py:130-181 under
- *      torch.backends.cudnn.allow_tf32), ~3x less matrix-pipe time.  Inference only.          */
+ * sigmoid and every other kernel of the path stay fp32).  Inference only.
+ *   0  fp32 operands on v_mfma_f32_32x32x2_f32 (default; what the parity fixtures were pinned with)
+ *   1  "bf16x3": every fp32 operand carried as hi + lo bf16, three bf16 MFMAs per product, fp32
+ *      accumulation -- ~2^-17 relative per product (finer than the TF32 convolutions the
+ *      reference's torch-cuda backend runs by default, model.py:130-181 under
+ *      torch.backends.cudnn.allow_tf32), 3/16 of the matrix-pipe time.
+ *   2  "bf16x6": every fp32 operand cut EXACTLY into three bf16 pieces, the six partial products of
+ *      weight >= 2^-16 on bf16 MFMAs, fp32 accumulation; what is dropped is <= 2^-23 |ab| per
+ *      product, one fp32 rounding -- measured as close to the torch-cpu reference as mode 0
+ *      (1.1e-7 RMS), 6/16 of the matrix-pipe time.                                              */
 int xsq_model_set_precision(xsq_model* model, int mode);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)
