@@ -75,7 +75,8 @@ class Separator(nn.Module):
         """``forward`` replayed from a HIP graph captured per input shape (launch-bound shapes: the
         2.2 s tail chunk or streaming-sized inputs spend more time between launches than inside them).
         The result tensor is owned by the graph and overwritten by the next call of the same shape."""
-        key = (tuple(audio_big.shape), audio_big.device.index, self.chunk_size)
+        key = (tuple(audio_big.shape), audio_big.device.index, self.chunk_size, getattr(self.xumx_model, "precision", "fp32"),
+               bool(getattr(self, "overlap_tail", True)))
         cache = self.__dict__.setdefault("_graphs", {})
         entry = cache.get(key)
         if entry is None:
