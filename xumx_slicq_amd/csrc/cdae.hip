@@ -704,8 +704,9 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         if (rc) return rc;
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_gemm" : "cdae_l3_gemm"), stream);
 #define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
-        if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else XSQ_SLAB(false, 0); }
-        else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else XSQ_SLAB(true, 0); }
+        const bool exw = !(variant & 64);      // fp32: exact-width columns (MODE 3) unless switched back to MODE 0
+        if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else if (exw) XSQ_SLAB(false, 3); else XSQ_SLAB(false, 0); }
+        else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
 #undef XSQ_SLAB
         return XSQ_OK;
     }

@@ -40,11 +40,18 @@ constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored cha
 // MODE 0 (fp32)  : plain fp32 operands, v_mfma_f32_32x32x2_f32 with the engine's k permutation (MFMA i of a
 //              16-value chunk takes k = i from the lower half-wave and k = 8 + i from the upper one, gemm_tile.h):
 //              the slab is then ONE fp32 plane (same 55.7 KB; row stride 52 words, conflict-free ds_read_b128)
+// MODE 3 (fp32, exact-width columns): as MODE 0, but the 52 stored channels are not padded to 64 MFMA columns:
+//              columns 0..31 on v_mfma_f32_32x32x2_f32, 32..47 on two v_mfma_f32_16x16x4_f32 row blocks, 48..51 on
+//              the vector ALU (32 v_fmac per lane and chunk, on the A fragment the lane already holds; the two
+//              half-waves' partial sums meet in the epilogue): 768 instead of 1024 matrix-pipe cycles per 32 rows
+//              x 16 k.  (v_mfma_f32_4x4x1_16B_f32 would fit the four columns exactly -- lane maps probed with
+//              tools/probe/mfma4x4.hip -- but measured ~7x slower than the whole rest of the kernel.)
 // MODE 2 (bf16x6): plain fp32 operands, fp32 slab plane; the A fragment is cut into its three bf16 pieces when
 //              it is read (gemm_tile_bf6.h), the B tile holds the three pieces of the weights; six bf16 MFMAs
 template <bool TRANSPOSED, int MODE>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
-    constexpr bool BF3 = MODE == 1, BF6 = MODE == 2;
+    constexpr bool BF3 = MODE == 1, BF6 = MODE == 2, EXW = MODE == 3;
+    constexpr bool F32T = MODE == 0 || MODE == 3;                // fp32 B tile / fp32 slab plane
     constexpr int BLD = BF6 ? SLAB_BLD6 : SLAB_BLD;               // words per B tile row
     constexpr int PLANE = SLAB_POS * CS + 64;                    // bf16 elements per plane (a multiple of 8)
     __shared__ __attribute__((aligned(16))) unsigned short slab_raw[2 * PLANE];
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     auto store_b = [&](int set, int buf) {
         if (!b_ld) return;
         unsigned* row = Bs + buf * SLAB_BN * BLD + b_row * BLD;
-        if (MODE == 0) { *reinterpret_cast<float4*>(row + b_k) = gb[set]; return; }
+        if (F32T) { *reinterpret_cast<float4*>(row + b_k) = gb[set]; return; }
         const int c = b_k >> 4, q2 = (b_k & 15) >> 1;
         if (BF6) {
             unsigned a1, a2, a3, b1, b2, b3;
@@ -172,9 +179,25 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
     };
     auto bfrag = [&](const unsigned* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); };
-    const int b_frag0 = lrow * BLD + (MODE == 0 ? 8 : 4) * lk;
-    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * BLD + (MODE == 0 ? 8 : 4) * lk;     // columns >= 52 are never stored: any row will do
+    const int b_frag0 = lrow * BLD + (F32T ? 8 : 4) * lk;
+    const int b_frag1 = min(lrow + 32, SLAB_BN - 1) * BLD + (F32T ? 8 : 4) * lk;     // columns >= 52 are never stored: any row will do
 #define XSQ_MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+    // MODE 3: operands of the two 16-row blocks (lane = row l & 15, k quad q = l >> 4) and of the vector columns
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int q16 = lane >> 4;
+    int a16_base[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int r16 = wave * 32 + 16 * rb + (lane & 15);
+        int sg = 0;
+#pragma unroll
+        for (int i = 1; i < SLAB_MAXSEG; ++i) sg += (r16 >= seg_start(i)) ? 1 : 0;
+        a16_base[rb] = (r16 + 3 * sg) * CS + 4 * q16;
+    }
+    const int b16_frag = (32 + (lane & 15)) * BLD + 4 * q16;
+    const int bv_frag = 48 * BLD + 8 * lk;
+    f32x4_t acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float accv[4] = {0.f, 0.f, 0.f, 0.f};
 
     // Slots: every df owns 8 slots -- 7 K-steps of 32 (the last half empty) and one in which the next slab goes
     // into LDS -- so that slot parity = LDS tile = register set and every index below is compile-time.  The
@@ -198,7 +221,38 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                 for (int c = 0; c < 2; ++c) {
                     const int k = 32 * ks + 16 * c;
                     if (k < SLAB_KRUN) {       // compile-time: the second half of the last K-step does not exist
-                        if constexpr (MODE == 0) {
+                        if constexpr (MODE == 3) {
+                            const float* Bf = reinterpret_cast<const float*>(Bb);
+                            const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
+                            const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
+                            const float4 p0 = *reinterpret_cast<const float4*>(&Bf[b_frag0 + 16 * c]), p1 = *reinterpret_cast<const float4*>(&Bf[b_frag0 + 16 * c + 4]);
+                            const float4 x0 = *reinterpret_cast<const float4*>(&slabF[a16_base[0] + k]);
+                            const float4 x1 = *reinterpret_cast<const float4*>(&slabF[a16_base[1] + k]);
+                            const float4 y = *reinterpret_cast<const float4*>(&Bf[b16_frag + 16 * c]);
+                            const float av[8] = {alo.x, alo.y, alo.z, alo.w, ahi.x, ahi.y, ahi.z, ahi.w};
+                            const float b0[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                            for (int kk = 0; kk < 8; ++kk) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b0[kk], acc0, 0, 0, 0);
+                            const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w}, yb[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (XSQ_SLAB_ABL & 64) continue;
+                                acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], yb[j], acc16[0], 0, 0, 0);
+                                acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], yb[j], acc16[1], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {   // channels 48..51 on the vector ALU: this lane's row, its 8 k-values
+                                const float4 v0 = *reinterpret_cast<const float4*>(&Bf[bv_frag + cc * BLD + 16 * c]);
+                                const float4 v1 = *reinterpret_cast<const float4*>(&Bf[bv_frag + cc * BLD + 16 * c + 4]);
+                                // volatile asm: plain fmaf chains were sunk past the K-step barrier with their operands spilled
+                                // (2 KB of scratch per lane, 7x slower); packed v_pk_fma_f32 is not available in this build (Makefile)
+                                asm volatile("v_fmac_f32 %0, %1, %9\n\tv_fmac_f32 %0, %2, %10\n\tv_fmac_f32 %0, %3, %11\n\tv_fmac_f32 %0, %4, %12\n\t"
+                                             "v_fmac_f32 %0, %5, %13\n\tv_fmac_f32 %0, %6, %14\n\tv_fmac_f32 %0, %7, %15\n\tv_fmac_f32 %0, %8, %16"
+                                             : "+v"(accv[cc])
+                                             : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]),
+                                               "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+                            }
+                        } else if constexpr (MODE == 0) {
                             const float* Bf = reinterpret_cast<const float*>(Bb);
                             const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
                             const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
@@ -259,6 +313,38 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
 #undef XSQ_MF
 
     if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
+    if constexpr (EXW) {
+        const int rowb = t.m0 + wave * 32;
+        {   // columns 0..31
+            const float sh = g.shift[lrow];
+            float* d0 = g.out + (int64_t)(rowb + 4 * lk) * CS + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rowb + 4 * lk + acc_row(r) < g.M) d0[acc_row(r) * CS] = fmaxf(acc0[r] + sh, 0.f);
+        }
+        {   // columns 32..47: C[4 q + r][l & 15] of each 16-row block
+            const int col = 32 + (lane & 15);
+            const float sh = g.shift[col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowb + 16 * rb + 4 * q16 + r;
+                    if (row < g.M) g.out[(int64_t)row * CS + col] = fmaxf(acc16[rb][r] + sh, 0.f);
+                }
+        }
+        {   // columns 48..51: the two half-waves hold the partial sums over their 8 k-values of every chunk
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) accv[cc] += __shfl_xor(accv[cc], 32);
+            const int row = rowb + lrow;
+            if (lk == 0 && row < g.M) {
+                const float4 sh = *reinterpret_cast<const float4*>(g.shift + 48);
+                *reinterpret_cast<float4*>(g.out + (int64_t)row * CS + 48) =
+                    make_float4(fmaxf(accv[0] + sh.x, 0.f), fmaxf(accv[1] + sh.y, 0.f), fmaxf(accv[2] + sh.z, 0.f), fmaxf(accv[3] + sh.w, 0.f));
+            }
+        }
+        return;
+    }
     relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, BF3);
 }
 
