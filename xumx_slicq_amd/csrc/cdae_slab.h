@@ -197,6 +197,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     const int b16_frag = (32 + (lane & 15)) * BLD + 4 * q16;
     const int bv_frag = 48 * BLD + 8 * lk;
     f32x4_t acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int NV = TRANSPOSED ? H1 - 48 : H2 - 48;        // real channels past 47: 2 (layer 3 -> 50) or 3 (layer 2 -> 51); the rest is zero padding
     float accv[4] = {0.f, 0.f, 0.f, 0.f};
 
     // Slots: every df owns 8 slots -- 7 K-steps of 32 (the last half empty) and one in which the next slab goes
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                                 acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], yb[j], acc16[1], 0, 0, 0);
                             }
 #pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) {   // channels 48..51 on the vector ALU: this lane's row, its 8 k-values
+                            for (int cc = 0; cc < NV; ++cc) {  // channels 48.. on the vector ALU: this lane's row, its 8 k-values
                                 const float4 v0 = *reinterpret_cast<const float4*>(&Bf[bv_frag + cc * BLD + 16 * c]);
                                 const float4 v1 = *reinterpret_cast<const float4*>(&Bf[bv_frag + cc * BLD + 16 * c + 4]);
                                 // volatile asm: plain fmaf chains were sunk past the K-step barrier with their operands spilled
