@@ -26,8 +26,10 @@ glob.glob = newest
 def short(n):
     import re
     n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")
-    n = n.replace("void xsq::cdae_slab_kernel<false, true>", "slab_bf3<CdaeL2>").replace("void xsq::cdae_slab_kernel<true, true>", "slab_bf3<CdaeL3>")
-    n = n.replace("void xsq::cdae_slab_kernel<false, false>", "slab<CdaeL2>").replace("void xsq::cdae_slab_kernel<true, false>", "slab<CdaeL3>")
+    m = re.match(r"void xsq::cdae_slab_kernel<(true|false), (\d)>", n)
+    if m:
+        return {"0": "slab", "3": "slab", "1": "slab_bf3", "2": "slab_bf6"}[m.group(2)] + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
+    n = re.sub(r"void xsq::grouped_gemm_bf6_kernel<xsq::(\w+)>", r"gemm_bf6<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+), \d+>", r"gemm<\1>", n)
     n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("xsq::", "")
