@@ -132,6 +132,41 @@ __device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0
     }
 }
 
+// the same for the exact-width column layout of the fp32 engines (gemm_tile.h XW = 1, cdae_slab.h MODE 3):
+// columns 0..31 in the 32x32 accumulator, 32..47 in two 16x16 blocks, 48..47+nv as half-wave partial sums
+__device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int rowb, int lane, const f32x16& a0,
+                                                       const f32x4 (&a16)[2], float (&av)[4], int nv) {
+    const int lrow = lane & 31, lk = lane >> 5, q16 = lane >> 4;
+    {
+        const float sh = g.shift[lrow];
+        float* d0 = g.out + (int64_t)(rowb + 4 * lk) * CS + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rowb + 4 * lk + acc_row(r) < g.M) d0[acc_row(r) * CS] = fmaxf(a0[r] + sh, 0.f);
+    }
+    {
+        const int col = 32 + (lane & 15);
+        const float sh = g.shift[col];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + 16 * rb + 4 * q16 + r;
+                if (row < g.M) g.out[(int64_t)row * CS + col] = fmaxf(a16[rb][r] + sh, 0.f);
+            }
+    }
+    {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) av[cc] = cc < nv ? av[cc] + __shfl_xor(av[cc], 32) : 0.f;
+        const int row = rowb + lrow;
+        if (lk == 0 && row < g.M) {
+            const float4 sh = *reinterpret_cast<const float4*>(g.shift + 48);
+            *reinterpret_cast<float4*>(g.out + (int64_t)row * CS + 48) =
+                make_float4(fmaxf(av[0] + sh.x, 0.f), fmaxf(av[1] + sh.y, 0.f), fmaxf(av[2] + sh.z, 0.f), fmaxf(av[3] + sh.w, 0.f));
+        }
+    }
+}
+
 // ---- layer 1 -----------------------------------------------------------------------------
 struct CdaeL1Op {
     typedef CdaeGroup Group;
@@ -181,6 +216,10 @@ struct CdaeL1Op {
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
+    static constexpr int NV = H1 - 48;        // real output channels past 47
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
+    }
 };
 
 // ---- layer 2 -----------------------------------------------------------------------------
@@ -216,6 +255,10 @@ struct CdaeL2Op {
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
+    }
+    static constexpr int NV = H2 - 48;        // real output channels past 47
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
     }
 };
 
@@ -255,6 +298,10 @@ struct CdaeL3Op {
     }
     __device__ void epilogue(const Group& g, int row0, int n, const f32x16& a0, const f32x16& a1, bool) const {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
+    }
+    static constexpr int NV = H1 - 48;        // real output channels past 47
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
     }
 };
 
@@ -697,6 +744,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     const bool bf6 = Mo->precision == 2 && !a.raw && !a.xin8 && !a.gx8;       // fp32 operands, cut in the kernel
     static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
+    const bool xw = !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && layer <= 3 && !(variant & 128);   // fp32 inference: no column padding
     if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
         (bf3 || bf6 || !(variant & 8))) {
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
@@ -712,18 +760,19 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     }
     int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23);
     if (rc) return rc;
-#define XSQ_LAUNCH(OP, MT_)                                                                                         \
+#define XSQ_LAUNCH(OP, MT_, XW_)                                                                                    \
     do {                                                                                                            \
         if (bf6) hipLaunchKernelGGL((grouped_gemm_bf6_kernel<OP>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);           \
+        else if (!bf3 && xw) hipLaunchKernelGGL((grouped_gemm_kernel<OP, 1, XW_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
         else if (!bf3) hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
         else if (variant & 2) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 2>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
         else hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 1>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
     } while (0)
     switch (layer) {
-        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1); } break;
-        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL2Op, 2); else XSQ_LAUNCH(CdaeL2Op, 1); } break;
-        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL3Op, 2); else XSQ_LAUNCH(CdaeL3Op, 1); } break;
-        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream); XSQ_LAUNCH(CdaeL4Op, 1); } break;
+        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1, 1); } break;
+        case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL2Op, 2, 0); else XSQ_LAUNCH(CdaeL2Op, 1, 1); } break;
+        case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL3Op, 2, 0); else XSQ_LAUNCH(CdaeL3Op, 1, 1); } break;
+        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream); XSQ_LAUNCH(CdaeL4Op, 1, 0); } break;
     }
 #undef XSQ_LAUNCH
     return XSQ_OK;

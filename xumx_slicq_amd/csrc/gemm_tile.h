@@ -59,9 +59,14 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 
 // MT = 32-row MFMA tiles per wave along M: tile height BM = 128 * MT (MT = 2 for the long, regular
 // CDAE layers: twice the MFMAs per barrier and per B-tile load).
-template <class Op, int MT = 1>
+// XW = 1 (operators whose 64-column tile holds 52 stored channels, Op::NV real ones past 47; MT = 1): the second
+// 32-column block is not padded -- channels 32..47 run on two v_mfma_f32_16x16x4_f32 row blocks and 48..47+NV on
+// the vector ALU (cdae_slab.h, MODE 3, explains the layout); the operator supplies epilogue_xw.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class Op, int MT = 1, int XW = 0>
 __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
                                                             int ntiles) {
+    static_assert(XW == 0 || MT == 1, "exact-width columns: MT = 1 only");
     constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
     constexpr int RA = BM / 64;     // A rows staged per thread
 
@@ -132,6 +137,13 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const int lrow = lane & 31, lk = lane >> 5;
     const int a_frag = (wave * 32 * MT + lrow) * LD + 8 * lk;
     const int b_frag = lrow * LD + 8 * lk;
+    // XW: 16-row blocks (lane = row l & 15, k quad l >> 4) and the vector columns
+    const int q16 = lane >> 4;
+    const int a16_frag = (wave * 32 + (lane & 15)) * LD + 4 * q16;
+    const int b16_frag = (32 + (lane & 15)) * LD + 4 * q16;
+    const int bv_frag = 48 * LD + 8 * lk;
+    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float accv[4] = {0.f, 0.f, 0.f, 0.f};
 
     auto mfma_step = [&](int buf) {
         const float* As = As0 + buf * BM * LD;
@@ -147,7 +159,34 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         const float4 b0_lo = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag]);
         const float4 b0_hi = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 4]);
         const float b0[8] = {b0_lo.x, b0_lo.y, b0_lo.z, b0_lo.w, b0_hi.x, b0_hi.y, b0_hi.z, b0_hi.w};
-        if (wide) {
+        if constexpr (XW == 1) {
+            if (wide) {
+                const float4 x0 = *reinterpret_cast<const float4*>(&As[a16_frag]);
+                const float4 x1 = *reinterpret_cast<const float4*>(&As[a16_frag + 16 * LD]);
+                const float4 y = *reinterpret_cast<const float4*>(&Bs[b16_frag]);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b0[kk], acc0[0], 0, 0, 0);
+                const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w}, yb[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], yb[j], acc16[0], 0, 0, 0);
+                    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], yb[j], acc16[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int cc = 0; cc < Op::NV; ++cc) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(&Bs[bv_frag + cc * LD]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&Bs[bv_frag + cc * LD + 4]);
+                    asm volatile("v_fmac_f32 %0, %1, %9\n\tv_fmac_f32 %0, %2, %10\n\tv_fmac_f32 %0, %3, %11\n\tv_fmac_f32 %0, %4, %12\n\t"
+                                 "v_fmac_f32 %0, %5, %13\n\tv_fmac_f32 %0, %6, %14\n\tv_fmac_f32 %0, %7, %15\n\tv_fmac_f32 %0, %8, %16"
+                                 : "+v"(accv[cc])
+                                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[0][4]), "v"(a[0][5]), "v"(a[0][6]), "v"(a[0][7]),
+                                   "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b0[kk], acc0[0], 0, 0, 0);
+            }
+        } else if (wide) {
             const float4 b1_lo = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD]);
             const float4 b1_hi = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD + 4]);
             const float b1[8] = {b1_lo.x, b1_lo.y, b1_lo.z, b1_lo.w, b1_hi.x, b1_hi.y, b1_hi.z, b1_hi.w};
@@ -199,6 +238,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
             for (int r = 0; r < 16; ++r) sacc += acc0[i][r] + acc1[i][r];
         if (sacc == 1.2345e-30f) __builtin_trap();
         return;
+    }
+    if constexpr (XW == 1) {
+        if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv); return; }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
