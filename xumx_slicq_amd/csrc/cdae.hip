@@ -450,6 +450,30 @@ struct CdaeL4Op {
             }
         }
     }
+    // 16-column blocks of the exact-width tiles (gemm_tile.h, XW = 2): lane = column n0 + (l & 15), its four
+    // registers are rows 4 (l >> 4) .. + 3 of each of the two 16-row blocks
+    __device__ void epilogue16(const Group& g, int rowb, int lane, int n0, const f32x4 (&acc)[2]) const {
+        const int n = n0 + (lane & 15), q16 = lane >> 4;
+        if (n >= g.N) return;
+        const int c = n >= g.hop, dt = n - c * g.hop;
+        const float bias = g.shift[c];
+        const int FST = g.F * a.S * g.T, perb = g.Fo * g.To;
+        const float2* X2 = reinterpret_cast<const float2*>(a.X) + (int64_t)a.Bn * 2 * a.S * g.cum;
+        float2* Y2 = a.Y ? reinterpret_cast<float2*>(a.Y) + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST : nullptr;
+        float* Mk = a.masks ? a.masks + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST : nullptr;
+        const int off = c * FST + dt;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = rowb + 16 * rb + 4 * q16 + r;
+                if (m >= g.M) continue;
+                const int o = m * g.hop + (m / perb) * FST + off;
+                const float mk = __builtin_amdgcn_rcpf(1.f + __expf(-(acc[rb][r] + bias)));
+                if (Y2) { const float2 x = X2[o]; Y2[o] = make_float2(mk * x.x, mk * x.y); }
+                if (Mk) Mk[o] = mk;
+            }
+    }
 };
 
 }  // namespace xsq
@@ -463,9 +487,9 @@ static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 
 
 static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
 
-static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int mt23 = L23_MT) {
+static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int mt23 = L23_MT, bool n16 = false) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(layer + 16 * mt23, Bn, S);
+    auto key = std::make_tuple(layer + 16 * mt23 + (n16 ? 128 : 0), Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
@@ -493,8 +517,11 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             // keep their tiles of one (row, column) patch adjacent so the re-reads hit the XCD's L2
             for (int64_t m0 = 0; m0 < M; m0 += 128)
                 for (int n0 = 0; n0 < N; n0 += 64)
-                    for (int tgt = 0; tgt < NT; ++tgt)
-                        t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, (N - n0 <= 32) ? 1 : 0});
+                    for (int tgt = 0; tgt < NT; ++tgt) {
+                        const int rem = N - n0;      // n16 (layer 4, fp32 inference): widths 16 / 32 / 48 / 64, see gemm_tile.h XW = 2
+                        const int kind = n16 ? (rem <= 16 ? 2 : rem <= 32 ? 1 : rem <= 48 ? 3 : 0) : (rem <= 32 ? 1 : 0);
+                        t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, kind});
+                    }
         } else {
             for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N, 128 * mt23);
         }
@@ -758,7 +785,8 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 #undef XSQ_SLAB
         return XSQ_OK;
     }
-    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23);
+    const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity
+    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23, n16);
     if (rc) return rc;
 #define XSQ_LAUNCH(OP, MT_, XW_)                                                                                    \
     do {                                                                                                            \
@@ -772,7 +800,9 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1, 1); } break;
         case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL2Op, 2, 0); else XSQ_LAUNCH(CdaeL2Op, 1, 1); } break;
         case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL3Op, 2, 0); else XSQ_LAUNCH(CdaeL3Op, 1, 1); } break;
-        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream); XSQ_LAUNCH(CdaeL4Op, 1, 0); } break;
+        default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
+            if (n16) hipLaunchKernelGGL((grouped_gemm_kernel<CdaeL4Op, 1, 2>), dim3(tt.ntiles), dim3(256), 0, stream, CdaeL4Op{a}, tt.d_tiles, tt.ntiles);
+            else XSQ_LAUNCH(CdaeL4Op, 1, 0); } break;
     }
 #undef XSQ_LAUNCH
     return XSQ_OK;

@@ -62,6 +62,9 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 // XW = 1 (operators whose 64-column tile holds 52 stored channels, Op::NV real ones past 47; MT = 1): the second
 // 32-column block is not padded -- channels 32..47 run on two v_mfma_f32_16x16x4_f32 row blocks and 48..47+NV on
 // the vector ALU (cdae_slab.h, MODE 3, explains the layout); the operator supplies epilogue_xw.
+// XW = 2 (layer 4, whose N = coefficients per slice is any multiple of 4 from 16 to 292): tiles come in four widths,
+// TileDev.narrow = 0: 64 columns (two 32x32 blocks), 1: 32, 3: 48 (32x32 block + 16x16x4 blocks), 2: 16 (16x16x4
+// blocks only); the operator supplies epilogue16 for the 16-column blocks.  Padding N to 32/64 cost 38 % there.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class Op, int MT = 1, int XW = 0>
 __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const int wave = tid >> 6;
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     const bool wide = t.narrow == 0;          // wave-uniform
+    const int kind = XW == 2 ? t.narrow : (wide ? 0 : 1);
     const typename Op::Group g = op.group(t.group);
     const int K = (XSQ_ABLATE & 32) ? 16 : g.K;      // bit 5: one K-step only (epilogue cost in isolation)
 
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
 #pragma unroll
     for (int i = 0; i < RA; ++i) ra[i] = op.row_a(g, t.m0 + s_row + 64 * i);
     const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
-    const bool b_on = wide || s_row < 32;
+    const bool b_on = wide || s_row < (XW == 2 ? (kind == 1 ? 32 : kind == 3 ? 48 : 16) : 32);
 
     // Global loads run TWO K-steps ahead of the MFMAs (two register sets, loop unrolled by two so
     // the set index is static): with 4 waves sharing a SIMD one K-step lasts about as long as an
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     // XW: 16-row blocks (lane = row l & 15, k quad l >> 4) and the vector columns
     const int q16 = lane >> 4;
     const int a16_frag = (wave * 32 + (lane & 15)) * LD + 4 * q16;
-    const int b16_frag = (32 + (lane & 15)) * LD + 4 * q16;
+    const int b16_frag = ((XW == 2 && kind == 2 ? 0 : 32) + (lane & 15)) * LD + 4 * q16;
     const int bv_frag = 48 * LD + 8 * lk;
     f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float accv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -159,7 +163,29 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         const float4 b0_lo = (XSQ_ABLATE & 8) ? fb_lo : *reinterpret_cast<const float4*>(&Bs[b_frag]);
         const float4 b0_hi = (XSQ_ABLATE & 8) ? fb_hi : *reinterpret_cast<const float4*>(&Bs[b_frag + 4]);
         const float b0[8] = {b0_lo.x, b0_lo.y, b0_lo.z, b0_lo.w, b0_hi.x, b0_hi.y, b0_hi.z, b0_hi.w};
-        if constexpr (XW == 1) {
+        if constexpr (XW == 2) {
+            if (kind != 2) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b0[kk], acc0[0], 0, 0, 0);
+            }
+            if (kind == 0) {
+                const float4 b1_lo = *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD]);
+                const float4 b1_hi = *reinterpret_cast<const float4*>(&Bs[b_frag + 32 * LD + 4]);
+                const float b1[8] = {b1_lo.x, b1_lo.y, b1_lo.z, b1_lo.w, b1_hi.x, b1_hi.y, b1_hi.z, b1_hi.w};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b1[kk], acc1[0], 0, 0, 0);
+            } else if (kind >= 2) {
+                const float4 x0 = *reinterpret_cast<const float4*>(&As[a16_frag]);
+                const float4 x1 = *reinterpret_cast<const float4*>(&As[a16_frag + 16 * LD]);
+                const float4 y = *reinterpret_cast<const float4*>(&Bs[b16_frag]);
+                const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w}, yb[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], yb[j], acc16[0], 0, 0, 0);
+                    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], yb[j], acc16[1], 0, 0, 0);
+                }
+            }
+        } else if constexpr (XW == 1) {
             if (wide) {
                 const float4 x0 = *reinterpret_cast<const float4*>(&As[a16_frag]);
                 const float4 x1 = *reinterpret_cast<const float4*>(&As[a16_frag + 16 * LD]);
@@ -241,6 +267,12 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     }
     if constexpr (XW == 1) {
         if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv); return; }
+    }
+    if constexpr (XW == 2) {
+        if (kind >= 2) op.epilogue16(g, t.m0 + wave * 32, lane, t.n0 + (kind == 3 ? 32 : 0), acc16);
+        if (kind == 2) return;
+        op.epilogue(g, t.m0 + wave * 32 + 4 * lk, t.n0 + lrow, acc0[0], acc1[0], kind == 0);
+        return;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
