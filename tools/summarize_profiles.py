@@ -31,7 +31,7 @@ def short(n):
         return {"0": "slab", "3": "slab", "1": "slab_bf3", "2": "slab_bf6"}[m.group(2)] + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
     n = re.sub(r"void xsq::grouped_gemm_bf6_kernel<xsq::(\w+)>", r"gemm_bf6<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
-    n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+), \d+>", r"gemm<\1>", n)
+    n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+)(?:, \d+)*>", r"gemm<\1>", n)
     n = n.replace("void xsq::grouped_gemm_kernel<xsq::", "gemm<").replace("xsq::", "")
     return n.split("(")[0][:48]
 
