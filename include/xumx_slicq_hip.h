@@ -218,6 +218,9 @@ int xsq_train_step(xsq_train* t, const float* X, const float* Yt, int B, int S, 
                    float lr, float weight_decay, int apply_update, double* loss_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 int xsq_train_read(xsq_train* t, int what, float* host_out);
+/* Arithmetic of the GEMM-shaped forward / data-gradient kernels of the step: 0 fp32 MFMA (default), 2 bf16x6 (see
+ * xsq_model_set_precision; the reference trains these layers under bf16 autocast, training.py:473-476).          */
+int xsq_train_set_precision(xsq_train* t, int mode);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on

@@ -88,11 +88,11 @@ def test_fixture_has_a_relu_kink(oracle_plan, seeded_sd, tag, causal):
         assert pre[0] < 5e-6 and pre[1] > 1e-4, pre[:3]
 
 
-def _trainer(realtime):
+def _trainer(realtime, precision="fp32"):
     from xumx_slicq_amd.separator import seeded_separator
     from xumx_slicq_amd.training import Trainer
     sep = seeded_separator(realtime=realtime)
-    return sep, Trainer(sep.xumx_model, (sep.nsgt, sep.insgt, sep.cnorm))
+    return sep, Trainer(sep.xumx_model, (sep.nsgt, sep.insgt, sep.cnorm), precision=precision)
 
 
 @pytest.mark.gpu
@@ -110,6 +110,19 @@ def test_hip_training_gradients_match_reference(tag, realtime):
     after = tr.state_dict()
     for k in before:      # gradients-only leaves parameters and running statistics alone
         assert torch.equal(before[k], after[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,realtime", [("realtime", True), ("offline", False)])
+def test_hip_training_gradients_bf16x6(tag, realtime):
+    """The same check with the forward / data-gradient contractions on the bf16x6 matrix path (exact three-way
+    operand cut, six MFMAs per product; the reference itself trains these layers under bf16 autocast)."""
+    g = load_golden("training_step.npz")
+    x, y_t = _inputs(int(g["n"]))
+    sep, tr = _trainer(realtime, precision="bf16x6")
+    loss, mse, msk = tr.step(x, y_t, apply_update=False)
+    worst = _check(g, tag, mse, msk, tr.gradients(), rtol=2e-3, kink_rtol=0.15)
+    assert worst < 2e-3
 
 
 @pytest.mark.gpu

@@ -15,11 +15,12 @@ ap.add_argument("--seq-dur", type=float, default=2.0)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--realtime", action="store_true")
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6"])
 a = ap.parse_args()
 n = int(a.seq_dur * 44100)
 with redirect_stdout(sys.stderr):
     sep = seeded_separator(realtime=a.realtime)
-tr = Trainer(sep.xumx_model, (sep.nsgt, sep.insgt, sep.cnorm))
+tr = Trainer(sep.xumx_model, (sep.nsgt, sep.insgt, sep.cnorm), precision=a.precision)
 y_t = torch.stack([0.5 * synth_audio(n, seed=700 + j, nb_samples=a.batch) for j in range(4)]).cuda()
 x = y_t.sum(0)
 losses = []
@@ -37,5 +38,5 @@ _lib.profile_enable(False)
 kern = {k: round(ms / a.steps, 3) for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
 print(json.dumps({"metric": "training steps/s", "value": 1.0 / dt, "ms_per_step": dt * 1e3, "chunks_per_s": a.batch / dt,
                   "batch": a.batch, "seq_dur": a.seq_dur, "model": "realtime" if a.realtime else "offline",
-                  "dtype": "f32", "losses": [round(l, 5) for l in losses], "kernels_ms": kern,
+                  "dtype": "f32" if a.precision == "fp32" else "f32 (GEMM contractions as bf16x6)", "losses": [round(l, 5) for l in losses], "kernels_ms": kern,
                   "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2**30}))

@@ -768,7 +768,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block; split the batch", a.Bn, a.S);
     if (layer == 4 && a.gx8) layer = 6;
     const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
-    const bool bf6 = Mo->precision == 2 && !a.raw && !a.xin8 && !a.gx8;       // fp32 operands, cut in the kernel
+    const bool bf6 = Mo->precision == 2;       // fp32 operands, cut in the kernel (any operator / epilogue: also the training step)
     static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
     const bool xw = !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && layer <= 3 && !(variant & 128);   // fp32 inference: no column padding

@@ -588,6 +588,13 @@ static int kf_of_t(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }
 
 extern "C" {
 
+int xsq_train_set_precision(xsq_train* T, int mode) {
+    XSQ_REQUIRE(T && T->model, "xsq_train_set_precision: null handle");
+    XSQ_REQUIRE(mode == 0 || mode == 2, "xsq_train_set_precision: mode %d (0 = fp32, 2 = bf16x6)", mode);
+    T->model->precision = mode;
+    return XSQ_OK;
+}
+
 int xsq_train_destroy(xsq_train* T) {
     if (!T) return XSQ_OK;
     if (T->model) xsq_model_destroy(T->model);

@@ -30,7 +30,7 @@ class Trainer:
     the trained tensors back in the reference's layout."""
 
     def __init__(self, unmix: Unmix, encoder, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 device: str | torch.device = "cuda"):
+                 device: str | torch.device = "cuda", precision: str = "fp32"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.XsqError("training runs on a ROCm device only; there is no CPU fallback")
@@ -51,6 +51,10 @@ class Trainer:
             _lib.check(_lib.lib.xsq_train_create(C.byref(self._h), len(self.table), self._F.ctypes.data,
                                                  self._T.ctypes.data, 1 if self.causal else 0,
                                                  params.ctypes.data, params.size), "xsq_train_create")
+        if precision not in ("fp32", "bf16x6"):
+            raise ValueError(f"precision {precision!r}: the training step offers 'fp32' and 'bf16x6'")
+        self.precision = precision
+        _lib.check(_lib.lib.xsq_train_set_precision(self._h, 2 if precision == "bf16x6" else 0), "xsq_train_set_precision")
         self._ws = None
         self.steps = 0
 
