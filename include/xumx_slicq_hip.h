@@ -229,6 +229,10 @@ int xsq_train_set_precision(xsq_train* t, int mode);
  * names, same order as ms[] / launches[]); returns the number of entries.              */
 int xsq_profile_enable(int on);
 int xsq_profile_reset(void);
+/* Time only the kernel launched under this event name (NULL or "": all kernels).  Two event records around every
+ * launch cost ~0.1 ms per 24-launch step; bench.py times every kernel in its warm-up steps and only the dominant
+ * one inside the timed region.                                                                              */
+int xsq_profile_filter(const char* name);
 int xsq_profile_read(char* names, size_t names_bytes, double* ms, int64_t* launches,
                      int max_entries);
 

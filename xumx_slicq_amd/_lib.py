@@ -75,6 +75,7 @@ _SIGS = {
     "xsq_train_set_precision": (C.c_int, [_vp, C.c_int]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),
+    "xsq_profile_filter": (C.c_int, [C.c_char_p]),
     "xsq_profile_read": (C.c_int, [C.c_char_p, C.c_size_t, _vp, _vp, C.c_int]),
     "xsq_wiener_em": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
 }
@@ -107,6 +108,11 @@ def profile_enable(on: bool = True):
 
 def profile_reset():
     lib.xsq_profile_reset()
+
+
+def profile_filter(name=None):
+    """Time only the kernel launched under this event name (None: all kernels)."""
+    lib.xsq_profile_filter(name.encode() if name else None)
 
 
 def profile_read() -> dict:

@@ -5,13 +5,14 @@
 
 namespace xsq {
 bool prof_enabled();
+bool prof_wanted(const char* name);
 void prof_begin(const char* name, hipStream_t stream);
 void prof_end(hipStream_t stream);
 
 struct ProfScope {
     hipStream_t s;
     bool on;
-    ProfScope(const char* name, hipStream_t stream) : s(stream), on(prof_enabled()) {
+    ProfScope(const char* name, hipStream_t stream) : s(stream), on(prof_wanted(name)) {
         if (on) prof_begin(name, s);
     }
     ~ProfScope() {

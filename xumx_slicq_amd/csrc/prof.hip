@@ -15,6 +15,7 @@ struct Pending {
 };
 static std::mutex g_mu;
 static bool g_on = false;
+static std::string g_only;          // when non-empty: only the kernel of this event name is timed (xsq_profile_filter)
 static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_pool;
 static std::map<std::string, std::pair<double, int64_t>> g_acc;   // name -> (ms, launches)
@@ -31,6 +32,7 @@ static hipEvent_t get_event() {
 }
 
 bool prof_enabled() { return g_on; }
+bool prof_wanted(const char* name) { return g_on && (g_only.empty() || g_only == name); }
 
 void prof_begin(const char* name, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -68,6 +70,12 @@ extern "C" {
 int xsq_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+    return XSQ_OK;
+}
+
+int xsq_profile_filter(const char* name) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = name ? name : "";
     return XSQ_OK;
 }
 
