@@ -75,8 +75,9 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
             f3 += 2 * B * F1 * T1 * (51 * kf * 4) * 50 * 4
             f4 += 2 * B * F1 * T1 * 50 * (2 * kf * T) * 4
         add("cdae_l1_gemm", "mfma", f1)
-        add("cdae_l2_gemm", "mfma", f2)
-        add("cdae_l3_gemm", "mfma", f3)
+        # layers 2/3 of long inputs run on the slab kernels (csrc/cdae_slab.h: T >= 86), short ones on the generic engine
+        add("cdae_l2_slab" if T2 >= 86 else "cdae_l2_gemm", "mfma", f2)
+        add("cdae_l3_slab" if T1 >= 86 else "cdae_l3_gemm", "mfma", f3)
         add("cdae_l4_gemm", "mfma", f4)
         add("band_synthesis_dft4", "mfma", r8 * 2 * int((long_ * long_).sum()))
         add("band_synthesis_gemm", "mfma", r8 * 8 * int((short_ * short_).sum()))
@@ -89,9 +90,9 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
     return w
 
 
-# event name -> the kernels launched under it (layers 2/3: the slab kernel for long inputs, the generic engine for the tail)
-_PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["slab<CdaeL2>", "gemm<CdaeL2Op>"],
-              "cdae_l3_gemm": ["slab<CdaeL3>", "gemm<CdaeL3Op>"],
+# event name -> the kernel launched under it, as named by tools/summarize_profiles.py in profiles/*_kernel_stats.csv
+_PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2Op>"], "cdae_l3_gemm": ["gemm<CdaeL3Op>"],
+              "cdae_l2_slab": ["slab<CdaeL2>"], "cdae_l3_slab": ["slab<CdaeL3>"],
               "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
               "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4<inverse>"],
               "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],

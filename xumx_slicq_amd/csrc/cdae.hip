@@ -777,7 +777,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
-        XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_gemm" : "cdae_l3_gemm"), stream);
+        XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);      // its own event name: one kernel, one name
 #define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
         const bool exw = !(variant & 64);      // fp32: exact-width columns (MODE 3) unless switched back to MODE 0
         if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else if (exw) XSQ_SLAB(false, 3); else XSQ_SLAB(false, 0); }
