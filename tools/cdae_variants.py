@@ -16,4 +16,4 @@ for _ in range(5): out = sep(x)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 prof = _lib.profile_read()
-print("variant", os.environ.get("XSQ_BF3_VARIANT", "0"), f"{dt*1e3:.3f} ms/step", {k: round(v[0] / 5, 3) for k, v in prof.items() if "cdae" in k}, "checksum", float(out.double().abs().sum()), flush=True)
+print("variant", os.environ.get("XSQ_CDAE_VARIANT", "0"), f"{dt*1e3:.3f} ms/step", {k: round(v[0] / 5, 3) for k, v in prof.items() if "cdae" in k}, "checksum", float(out.double().abs().sum()), flush=True)

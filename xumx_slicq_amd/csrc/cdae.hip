@@ -769,7 +769,11 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     if (layer == 4 && a.gx8) layer = 6;
     const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
     const bool bf6 = Mo->precision == 2;       // fp32 operands, cut in the kernel (any operator / epilogue: also the training step)
-    static const int variant = getenv("XSQ_BF3_VARIANT") ? atoi(getenv("XSQ_BF3_VARIANT")) : 0;   // experiment: bit 0 MT = 2 (L2/L3), bit 1 KS = 2
+    // Diagnostic A/B switches (default 0 = the product configuration; results stay correct in every setting):
+    //   1 bf16x3 generic engine with 256-row tiles      2 ... with 32-value K-steps      4 no slab kernels at all
+    //   8 no slab kernels on the fp32 path              64 fp32 slab kernels padded to 64 columns (MODE 0)
+    //   128 generic fp32 engine padded to 64 columns    256 layer 4 with 32/64-column tiles only
+    static const int variant = getenv("XSQ_CDAE_VARIANT") ? atoi(getenv("XSQ_CDAE_VARIANT")) : 0;
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
     const bool xw = !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && layer <= 3 && !(variant & 128);   // fp32 inference: no column padding
     if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
