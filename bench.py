@@ -5,26 +5,37 @@ Metric (BASELINE.json): audio-seconds demixed / wall-seconds, 44.1 kHz stereo, o
 model, timed around the `separator(audio)` call with the model resident and warm, file
 I/O excluded (the reference's own convention, xumx_slicq_v2/inference.py:28-31).
 
-Workload = BASELINE.json configs[1]: offline conv stack (Bark-262 sliCQT), ONE 240 s track
-(10,584,000 samples = 4 full 59.4 s chunks + a 98,240-sample tail), Wiener off (mix-phase),
-seeded synthetic audio and seeded synthetic weights (no dataset / checkpoint offline).
+N = 1 (default), workload "track240" = BASELINE.json configs[1]: offline conv stack (Bark-262
+sliCQT), ONE 240 s track (10,584,000 samples = 4 full 59.4 s chunks + a 98,240-sample tail),
+Wiener off (mix-phase), seeded synthetic audio and weights (no dataset / checkpoint offline).
 A "step" = one full pass sliCQT -> CDAE -> phasemix -> isliCQT over that track, input already
-resident in HBM.  With --gpus N (one process per GPU under torch.distributed.run, RCCL)
-every rank demixes its own track per step -> weak scaling; tracks are independent objects, so
-there is no data-path collective (only the timing barrier / max-reduce); --gather adds the
-RCCL all-gather of all stems to all ranks for reference.  value = total audio-s / max-rank time.
+resident in HBM.  The same line carries, outside the timed region: the per-kernel HBM / MFMA
+roofline fractions, configs[2] (Wiener-EM on) and configs[4] (the B = 16 training step) as
+`variants`, the split-bf16 arithmetic variants, and the CPU oracle on this box's host cores.
 
-One JSON line on stdout from rank 0.
+N > 1, workload "testset50" = BASELINE.json configs[3]: 50 seeded track lengths in [150, 420] s
+flattened into (track, chunk) work items, dealt longest-first to the ranks (one process per GPU,
+RCCL), every rank runs its full-size chunks stacked along the batch axis, and the stems of every
+item are all-gathered to every rank and placed into per-track (4, 1, 2, N_t) tensors -- the final
+waveform concat of separator.py:231.  A "step" = the whole 50-track set once (fixed total work:
+"scaling": "strong").  value = total audio-s / max-rank time.  Beside it (`variants`): the same
+step without the collective, and the whole set on rank 0 alone (the single-GPU rate on the SAME
+workload, for an efficiency figure that does not mix workloads).
+
+`python3 bench.py --gpus N` (no launcher) starts its own ranks: a fresh
+`python -m torch.distributed.run` child BEFORE anything touches the GPU, rank 0's JSON line is
+relayed, the child's exit status is returned.  Under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment.  One JSON line on stdout from rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,6 +46,16 @@ FS = 44100.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (split-bf16: three MFMAs per product)
+TESTSET_SEED, TESTSET_TRACKS = 20260104, 50
+METRIC = "real-time factor (audio-s demixed / wall-s), 44.1 kHz stereo, offline model"
+
+
+def testset_lengths(ntracks=TESTSET_TRACKS):
+    """a fixed seeded list of durations in [150 s, 420 s] (the reference does not state
+    the MUSDB18-HQ test-set durations)."""
+    import numpy as np
+    rng = np.random.default_rng(TESTSET_SEED)
+    return [int(d * FS) for d in rng.uniform(150.0, 420.0, ntracks)]
 
 
 def algorithmic_work(plan, B, chunk_lengths, wiener):
@@ -54,9 +75,10 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         S = plan.num_slices(n)
         T1, T2 = 2 * S - 1, 2 * S - 4
         r2, r8 = 2 * B * S, 8 * B * S
-        # hand-written LDS slice FFTs (window / band-spectrum gather fused in)
+        # hand-written LDS slice FFTs (window / band-spectrum gather / overlap-add fused in)
         add("slice_rfft", "hbm", 2 * B * n * 4 + r2 * nbins * 8)
         add("slice_irfft", "hbm", r8 * sumFT * 8 + r8 * L * 4)
+        add("slice_irfft_ola", "hbm", r8 * sumFT * 8 + 8 * B * n * 4)
         # rocFFT fallback path (other plans)
         add("slice_window", "hbm", 2 * B * n * 4 + r2 * L * 4)
         add("rfft_L", "hbm", r2 * L * 4 + r2 * nbins * 8)
@@ -66,18 +88,20 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         add("band_analysis_dft4", "mfma", r2 * 2 * int((long_ * long_).sum()))
         add("band_analysis_gemm", "mfma", r2 * 8 * int((short_ * short_).sum()))
         add("magnitude_whiten", "hbm", r2 * sumFT * 12)
-        f1 = f2 = f3 = f4 = 0
+        f1 = f2 = f4 = 0
         for (_, F, T) in plan.blocks:
             kf = freq_filter(F)
             F1, F2 = F - kf + 1, F - 2 * kf + 2
             f1 += 2 * B * F1 * T1 * (2 * kf * T) * 50 * 4
             f2 += 2 * B * F2 * T2 * (50 * kf * 4) * 51 * 4
-            f3 += 2 * B * F1 * T1 * (51 * kf * 4) * 50 * 4
             f4 += 2 * B * F1 * T1 * 50 * (2 * kf * T) * 4
         add("cdae_l1_gemm", "mfma", f1)
-        # layers 2/3 of long inputs run on the slab kernels (csrc/cdae_slab.h: T >= 86), short ones on the generic engine
+        # layers 2/3 of long inputs run on the slab kernels (csrc/cdae_slab.h: T >= 86), short ones on the generic engine.
+        # Layer 3 is a ConvTranspose: its algorithmic count is per INPUT position (F2 x T2 x 51 x 50 x kf x 4 MACs,
+        # SURVEY.md 8(d)) = layer 2's; the gather form the kernel runs also visits the zero-padded border taps
+        # (F1 x T1 output rows), which are not counted here.
         add("cdae_l2_slab" if T2 >= 86 else "cdae_l2_gemm", "mfma", f2)
-        add("cdae_l3_slab" if T1 >= 86 else "cdae_l3_gemm", "mfma", f3)
+        add("cdae_l3_slab" if T1 >= 86 else "cdae_l3_gemm", "mfma", f2)
         add("cdae_l4_gemm", "mfma", f4)
         add("band_synthesis_dft4", "mfma", r8 * 2 * int((long_ * long_).sum()))
         add("band_synthesis_gemm", "mfma", r8 * 8 * int((short_ * short_).sum()))
@@ -96,17 +120,21 @@ _PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2O
               "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
               "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4<inverse>"],
               "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
-              "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"]}
+              "slice_irfft_ola": ["k_slice_irfft_ola"],
+              "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"],
+              "wiener_stats": ["k_wiener_stats"], "wiener_apply": ["k_wiener_apply"]}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (tools/collect_profiles.sh -> tools/summarize_profiles.py; FETCH_SIZE doubled for gfx950 as
-    MI355X_MICROARCH.md prescribes, WRITE_SIZE as is; both are KB per dispatch, averaged over the
-    launches of a step).  None when no profile of the current kernels is committed."""
+def pmc_traffic(kernel, tag=None):
+    """HBM bytes per STEP of `kernel` (all its launches of one 240 s track) from the committed rocprofv3 PMC
+    passes of this same command (tools/collect_profiles.sh -> tools/summarize_profiles.py; FETCH_SIZE doubled
+    for gfx950 as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is; both are KB per dispatch, averaged over
+    the launches of a step) and the launch count it was averaged over.  None when no profile of the current
+    kernels is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv"))
+                   if (tag is None) == ("wiener" not in os.path.basename(f)))
     if not files or kernel not in _PMC_NAMES:
         return None
     total, launches = 0.0, 0
@@ -119,12 +147,13 @@ def pmc_traffic(kernel):
                     launches += n
                 except (KeyError, ValueError):
                     return None
-    return int(total / launches) if launches else None
+    return (int(total), launches) if launches else None
 
 
 def cpu_baseline(threads):
     """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this
     box's host cores on a bounded sample: one 30 s clip through the same configuration."""
+    import torch
     from oracle import separator as osep
     from oracle import slicqt as oslicqt
     from xumx_slicq_amd.synth import synth_audio
@@ -139,7 +168,84 @@ def cpu_baseline(threads):
     osep.separate(plan, sd, x, causal=False, wiener=False)
     dt = time.perf_counter() - t0
     return {"value": round(n / FS / dt, 3), "unit": "x real-time", "cores": threads, "kind": "port",
-            "sample": "30 s stereo clip (1,323,000 samples), offline conv stack + mix-phase, oracle/ torch-CPU fp32"}
+            "sample": "30 s stereo clip (1,323,000 samples), offline conv stack + mix-phase, oracle/ torch-CPU fp32 "
+                      "(the port, timed here; for comparison only: the reference ITSELF ran this configuration's full "
+                      "240 s track at 1.87 x real-time on 8 cores of the build container, BASELINE.md section 2)"}
+
+
+def roofline_tables(work, prof_step, steps_in_prof, wiener=False):
+    """Per-kernel fractions from one fully instrumented step: HBM-bound kernels against 8 TB/s, matrix kernels
+    against the fp32 MFMA peak.  achieved = algorithmic work of the step's launches / their summed duration."""
+    hbm, mfma = [], []
+    for k, (ms, launches) in sorted(prof_step.items(), key=lambda kv: -kv[1][0]):
+        if k not in work or ms <= 0:
+            continue
+        bound, amount = work[k]
+        sec = ms / steps_in_prof * 1e-3
+        if bound == "hbm":
+            ach = amount / sec / 1e9
+            tr = pmc_traffic(k, "wiener" if wiener else None)
+            hbm.append({"kernel": k, "ms_per_step": round(ms / steps_in_prof, 4), "achieved": round(ach, 1), "unit": "GB/s",
+                        "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(amount),
+                        "traffic_per_step": tr[0] if tr else None})
+        else:
+            ach = amount / sec / 1e12
+            mfma.append({"kernel": k, "ms_per_step": round(ms / steps_in_prof, 4), "achieved": round(ach, 2), "unit": "TFLOP/s",
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "algorithmic_flops_per_step": int(amount)})
+    return hbm, mfma
+
+
+def dominant_roofline(dom, prof, work, steps, dt, precision="fp32", wiener=False):
+    ms, launches = prof[dom]
+    bound, amount = work[dom]
+    per_launch = amount * steps / launches          # algorithmic work per launch
+    avg_s = ms / launches * 1e-3
+    if bound == "hbm":
+        ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        if precision != "fp32" and dom.startswith("cdae_"):      # useful flops at 3 / 6 bf16 MFMAs per product
+            peak = round(BF16_MFMA_PEAK_TFLOPS / (3.0 if precision == "bf16x3" else 6.0), 1)
+    tr = pmc_traffic(dom, "wiener" if wiener else None)
+    return {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "traffic": int(tr[0] / tr[1]) if tr else None,
+            "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+            "share_of_step": round(ms / (dt * 1e3), 4)}
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` without a launcher: start the ranks as a fresh child process BEFORE this one
+    has made any GPU call (no exec of a process that has initialised the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_steps(step, steps, world, dist, dev):
+    import torch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt, out
 
 
 def main():
@@ -147,25 +253,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=["track240", "testset50"],
+                    help="default: track240 (configs[1]) at N = 1, testset50 (configs[3]) at N > 1")
+    ap.add_argument("--tracks", type=int, default=TESTSET_TRACKS, help="testset50: number of tracks")
+    ap.add_argument("--stack", type=int, default=4, help="testset50: work items per round / stacked pass")
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3"],
                     help="arithmetic of the convolution contractions for the headline value (default: exact fp32)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra split-bf16 measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements outside the timed region")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a captured HIP graph (Separator.forward_graphed)")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: all-gather every track's stems to every rank inside the timed region")
+                    help="track240: replay the step from a captured HIP graph (Separator.forward_graphed)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="testset50: headline without the all-gather (default: with it; the other one is a variant)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nnodes=1 "
-                     "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
+    workload = args.workload or ("track240" if world == 1 else "testset50")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP library is the product path and there is no CPU fallback")
     local_dev = local_rank % torch.cuda.device_count()     # (several ranks per GPU only in smoke tests)
@@ -181,147 +292,311 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from xumx_slicq_amd import _lib
-    from xumx_slicq_amd.separator import seeded_separator
-    from xumx_slicq_amd.sharding import chunk_items, demix_tracks
-    from xumx_slicq_amd.synth import synth_audio
-
     import contextlib
+    from xumx_slicq_amd.separator import seeded_separator
     with contextlib.redirect_stdout(sys.stderr):     # keep stdout to the one JSON line
         sep = seeded_separator(realtime=False, wiener=args.wiener, device=dev, chunk_size=CHUNK)
     sep.xumx_model.set_precision(args.precision)
-    # inputs are resident in HBM before timing starts; without --gather a rank only ever touches
-    # its own track, so only that one is materialised
-    if args.gather:
-        tracks = [synth_audio(TRACK_SAMPLES, seed=20260101 + t).to(dev) for t in range(world)]
+
+    if workload == "track240":
+        result = bench_track(args, sep, dev, world, rank, dist)
     else:
-        mine = synth_audio(TRACK_SAMPLES, seed=20260101 + rank).to(dev)
-        tracks = [mine if t == rank else torch.empty(1, 2, TRACK_SAMPLES, device="meta")   # shape only
-                  for t in range(world)]
-
-    def step():
-        run = sep.forward_graphed if args.graph else sep
-        if world == 1:
-            return run(tracks[0])
-        return demix_tracks(run, tracks, gather=args.gather)
-
-    # Warm-up steps: every kernel is timed with HIP events on its launch stream (the per-kernel table and the
-    # choice of the dominant kernel).  Timed region: only the dominant kernel keeps its two events per launch --
-    # event records around all 24 launches of a step cost ~0.1 ms of it (tools/prof_overhead.py).
-    _lib.profile_filter(None)
-    _lib.profile_enable(True)
-    for i in range(args.warmup):
-        if i == args.warmup - 1:
-            torch.cuda.synchronize()
-            _lib.profile_reset()        # the table comes from the LAST warm-up step (the first one builds tile tables etc.)
-        step()
-    torch.cuda.synchronize()
-    prof_all = _lib.profile_read() if args.warmup >= 2 else None
-    nwarm = 1
-    dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
-    _lib.profile_filter(dom)            # None (fewer than two warm-up steps): every kernel stays instrumented in the timed region
-    _lib.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = _lib.profile_read()          # the dominant kernel only, over the timed region
-    _lib.profile_enable(False)
-    _lib.profile_filter(None)
-    if prof_all is None:                # no warm-up step to take the table from
-        prof_all, nwarm = prof, args.steps
-        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
-
-    # Extra, outside the timed region, N = 1 only: the same step with the convolution contractions on the
-    # split-bf16 matrix path (xsq_model_set_precision 1), and its stems against the fp32 stems just produced.
-    variants = None
-    if world == 1 and not args.no_variants and args.precision == "fp32":
-        ref_out = out.clone()
-        variants = {}
-        what = {"bf16x6": "conv contractions as 6 x bf16 MFMA on fp32 operands cut exactly into three bf16 pieces (dropped terms <= 2^-23 |ab|: fp32-grade), fp32 accumulate; everything else unchanged",
-                "bf16x3": "conv contractions as 3 x bf16 MFMA on hi/lo-split fp32 operands (~2^-17 per product), fp32 accumulate; everything else unchanged"}
-        for prec in ("bf16x6", "bf16x3"):
-            sep.xumx_model.set_precision(prec)
-            for _ in range(max(1, args.warmup)):
-                step()
-            torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for _ in range(args.steps):
-                vout = step()
-            torch.cuda.synchronize()
-            tv = time.perf_counter() - tv
-            d = (vout - ref_out).double()
-            variants[prec] = {
-                "what": what[prec],
-                "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
-                "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
-                                  "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}
-            del vout, d
-        sep.xumx_model.set_precision("fp32")
-        del ref_out
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    result = None
-    if rank == 0:
-        audio_s = world * args.steps * TRACK_SAMPLES / FS
-        # roofline of the dominant kernel (largest share of the timed region on this rank)
-        plan = sep.nsgt.nsgt.plan
-        my_items = [it.length for it in chunk_items([TRACK_SAMPLES], CHUNK)]
-        work = algorithmic_work(plan, 1, my_items, args.wiener)
-        roofline = None
-        if dom is not None:
-            ms, launches = prof[dom]
-            bound, amount = work[dom]
-            per_launch = amount * args.steps / launches          # algorithmic work per launch
-            avg_s = ms / launches * 1e-3
-            if bound == "hbm":
-                ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
-            else:
-                ach, peak, unit = per_launch / avg_s / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
-                if args.precision != "fp32" and dom.startswith("cdae_"):      # useful flops at 3 / 6 bf16 MFMAs per product
-                    peak = round(BF16_MFMA_PEAK_TFLOPS / (3.0 if args.precision == "bf16x3" else 6.0), 1)
-            roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
-                        "avg_launch_ms": round(ms / launches, 4), "launches": launches,
-                        "share_of_step": round(ms / (dt * 1e3), 4)}
-        kernels = {k: {"ms_per_step": round(v[0] / nwarm, 4), "launches_per_step": v[1] / nwarm}
-                   for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}       # from the instrumented warm-up steps
-        result = {
-            "metric": "real-time factor (audio-s demixed / wall-s), 44.1 kHz stereo, offline model",
-            "value": round(audio_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x6": "f32 (conv contractions: exact 3-way bf16 cut, 6 bf16 MFMAs per product, fp32 accumulate)",
-                      "bf16x3": "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
-                                   "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
-                                   % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
-                       "parallelism": "one track per rank, %d rank(s), %s" % (
-                           world, "RCCL all-gather of stems" if (args.gather and world > 1) else "no data-path collective")},
-            "roofline": roofline,
-            "kernels_source": "warm-up steps (all kernels instrumented); the timed region instruments the roofline kernel only",
-            "kernels": kernels,
-        }
-        if variants:
-            result["variants"] = variants
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+        result = bench_testset(args, sep, dev, world, rank, dist)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+DTYPES = {"fp32": "f32", "bf16x6": "f32 (conv contractions: exact 3-way bf16 cut, 6 bf16 MFMAs per product, fp32 accumulate)",
+          "bf16x3": "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)"}
+
+
+def instrumented_warmup(step, warmup):
+    """Warm-up steps; every kernel is timed with HIP events on its launch stream in the LAST one (the first
+    ones build tile tables etc.).  Returns {kernel: (ms, launches)} of that step, or None."""
+    import torch
+    from xumx_slicq_amd import _lib
+    _lib.profile_filter(None)
+    _lib.profile_enable(True)
+    for i in range(warmup):
+        if i == warmup - 1:
+            torch.cuda.synchronize()
+            _lib.profile_reset()
+        step()
+    torch.cuda.synchronize()
+    return _lib.profile_read() if warmup >= 2 else None
+
+
+def bench_track(args, sep, dev, world, rank, dist):
+    """configs[1] / [2]: one 240 s track per rank (weak scaling, no collective)."""
+    import torch
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.sharding import chunk_items
+    from xumx_slicq_amd.synth import synth_audio
+    track = synth_audio(TRACK_SAMPLES, seed=20260101 + rank).to(dev)      # resident in HBM before timing starts
+    run = sep.forward_graphed if args.graph else sep
+
+    def step():
+        return run(track)
+
+    # Warm-up steps: every kernel is timed with HIP events on its launch stream (the per-kernel table and the
+    # choice of the dominant kernel).  Timed region: only the dominant kernel keeps its two events per launch --
+    # event records around all launches of a step cost ~0.1 ms of it (tools/prof_overhead.py).
+    prof_all = instrumented_warmup(step, args.warmup)
+    dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
+    _lib.profile_filter(dom)            # None (fewer than two warm-up steps): every kernel stays instrumented
+    _lib.profile_reset()
+    dt, out = timed_steps(step, args.steps, world, dist, dev)
+    prof = _lib.profile_read()          # the dominant kernel only, over the timed region
+    _lib.profile_enable(False)
+    _lib.profile_filter(None)
+    nwarm = 1
+    if prof_all is None:                # no warm-up step to take the table from
+        prof_all, nwarm = prof, args.steps
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+
+    plan = sep.nsgt.nsgt.plan
+    my_items = [it.length for it in chunk_items([TRACK_SAMPLES], CHUNK)]
+    variants = {}
+    if world == 1 and not args.no_variants and rank == 0:
+        if args.precision == "fp32":
+            variants.update(variant_precisions(args, sep, step, out))
+        if not args.wiener:
+            variants["wiener"] = variant_wiener(args, dev, track, plan, my_items)
+        variants["train_step"] = variant_train_step(args, sep, dev)
+    if rank != 0:
+        return None
+    audio_s = world * args.steps * TRACK_SAMPLES / FS
+    work = algorithmic_work(plan, 1, my_items, args.wiener)
+    roofline = dominant_roofline(dom, prof, work, args.steps, dt, args.precision, args.wiener) if dom else None
+    hbm, mfma = roofline_tables(work, prof_all, nwarm, args.wiener)
+    kernels = {k: {"ms_per_step": round(v[0] / nwarm, 4), "launches_per_step": v[1] / nwarm}
+               for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+    result = {
+        "metric": METRIC,
+        "value": round(audio_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: offline model (Bark-262 sliCQT), one 240 s stereo track "
+                               "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
+                               % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
+                   "parallelism": "one track per rank, %d rank(s), no data-path collective" % world},
+        "roofline": roofline,
+        "roofline_hbm": hbm,
+        "roofline_mfma": mfma,
+        "kernels_source": "last warm-up step (all kernels instrumented); the timed region instruments the roofline kernel only",
+        "kernels": kernels,
+    }
+    if variants:
+        result["variants"] = variants
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+    return result
+
+
+def variant_precisions(args, sep, step, out):
+    """The same step with the convolution contractions on the split-bf16 matrix path, and its stems against the
+    fp32 stems just produced (outside the timed region, N = 1 only)."""
+    import torch
+    ref_out = out.clone()
+    variants = {}
+    what = {"bf16x6": "conv contractions as 6 x bf16 MFMA on fp32 operands cut exactly into three bf16 pieces (dropped terms <= 2^-23 |ab|: fp32-grade), fp32 accumulate; everything else unchanged",
+            "bf16x3": "conv contractions as 3 x bf16 MFMA on hi/lo-split fp32 operands (~2^-17 per product), fp32 accumulate; everything else unchanged"}
+    for prec in ("bf16x6", "bf16x3"):
+        sep.xumx_model.set_precision(prec)
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(args.steps):
+            vout = step()
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv
+        d = (vout - ref_out).double()
+        variants[prec] = {
+            "what": what[prec],
+            "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
+            "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
+                              "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}
+        del vout, d
+    sep.xumx_model.set_precision("fp32")
+    return variants
+
+
+def variant_wiener(args, dev, track, plan, my_items):
+    """BASELINE configs[2]: the same track with the norbert Wiener-EM post-filter (niter = 1), fp32."""
+    import contextlib
+    import torch
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.separator import seeded_separator
+    with contextlib.redirect_stdout(sys.stderr):
+        sepw = seeded_separator(realtime=False, wiener=True, device=dev, chunk_size=CHUNK)
+
+    def step():
+        return sepw(track)
+
+    prof_all = instrumented_warmup(step, max(2, args.warmup))
+    dom = max(prof_all, key=lambda k: prof_all[k][0])
+    _lib.profile_filter(dom)
+    _lib.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    _lib.profile_filter(None)
+    work = algorithmic_work(plan, 1, my_items, True)
+    hbm, _ = roofline_tables(work, prof_all, 1, True)
+    return {"what": "BASELINE configs[2]: offline model + norbert Wiener-EM (niter=1), same 240 s track, fp32",
+            "value": round(args.steps * TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time",
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "roofline": dominant_roofline(dom, prof, work, args.steps, dt, "fp32", True),
+            "roofline_hbm": [h for h in hbm if h["kernel"].startswith("wiener")],
+            "kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}}
+
+
+def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
+    """BASELINE configs[4] (SURVEY config 5): one training.loop step -- train-mode forward, ComplexMSE + MaskSum,
+    backward incl. the differentiable Wiener-EM, AdamW -- on a batch of 16 two-second chunks, offline model."""
+    import contextlib
+    import torch
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.synth import synth_audio
+    from xumx_slicq_amd.training import Trainer
+    with contextlib.redirect_stdout(sys.stderr):
+        sept = seeded_separator(realtime=False, device=dev)
+    tr = Trainer(sept.xumx_model, (sept.nsgt, sept.insgt, sept.cnorm), device=dev)
+    n = int(seq_dur * FS)
+    y_t = torch.stack([0.5 * synth_audio(n, seed=700 + j, nb_samples=batch) for j in range(4)]).to(dev)
+    x = y_t.sum(0)
+    losses = [tr.step(x, y_t)[0] for _ in range(max(2, args.warmup))]
+    torch.cuda.synchronize()
+    _lib.profile_filter(None)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.step(x, y_t)[0])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    kern = {k: round(ms / args.steps, 4) for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    dom = next(iter(kern))
+    return {"what": "BASELINE configs[4]: training.py step, CDAE fwd+bwd with the X-UMX combined loss (ComplexMSE 14 "
+                    "combinations + MaskSum), differentiable Wiener-EM, AdamW; batch = 16 chunks of 2 s, offline model, "
+                    "fp32 (every kernel event-timed: ~0.2 ms of the step is event overhead)",
+            "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(batch / dt, 1), "steps_per_s": round(1.0 / dt, 2),
+            "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
+            "dominant_kernel": {"kernel": dom, "ms_per_step": kern[dom], "share_of_step": round(kern[dom] / (dt * 1e3), 4)},
+            "kernels_ms": dict(list(kern.items())[:12])}
+
+
+def bench_testset(args, sep, dev, world, rank, dist):
+    """configs[3]: the 50-track set as one chunk batch over the ranks, stems all-gathered (see module docstring)."""
+    import torch
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.sharding import ShardedDemixer
+    from xumx_slicq_amd.synth import synth_audio_device
+    lengths = testset_lengths(args.tracks)
+    total_s = sum(lengths) / FS
+    cache = {}
+
+    def get_chunk(it):          # resident in HBM before timing starts; a rank only materialises its own items
+        key = (it.track, it.chunk)
+        if key not in cache:
+            cache[key] = synth_audio_device(it.length, seed=20260101 + 64 * it.track + it.chunk, device=dev)
+        return cache[key]
+
+    gather = not args.no_gather
+    dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack)
+    for q in dmx.plan.rounds:
+        for p in q[rank]:
+            get_chunk(p.item)
+    torch.cuda.synchronize()
+
+    prof_all = instrumented_warmup(dmx.run, args.warmup)
+    dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
+    _lib.profile_filter(dom)
+    _lib.profile_reset()
+    dt, _ = timed_steps(dmx.run, args.steps, world, dist, dev)
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    _lib.profile_filter(None)
+
+    variants = {}
+    if not args.no_variants:
+        # (a) the same step with the other exchange setting
+        if world > 1:
+            other = ShardedDemixer(sep, lengths, get_chunk, dev, gather=not gather, stack=args.stack)
+            for _ in range(max(1, args.warmup)):
+                other.run()
+            dto, _ = timed_steps(other.run, args.steps, world, dist, dev)
+            variants["no_gather" if gather else "gather"] = {
+                "what": ("the same sharded step WITHOUT the all-gather: every rank keeps the stems of its own items (no data-path collective)"
+                         if gather else "the same sharded step WITH the RCCL all-gather of all stems to all ranks + placement"),
+                "value": round(args.steps * total_s / dto, 2), "unit": "x real-time", "ms_per_step": round(dto / args.steps * 1e3, 3)}
+            del other
+        # (b) the whole set on rank 0 alone: the single-GPU rate on the SAME workload
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            if world > 1:
+                solo = ShardedDemixer(sep, lengths, get_chunk, dev, gather=False, stack=args.stack, only_rank=0)
+                for q in solo.plan.rounds:
+                    for p in q[0]:
+                        get_chunk(p.item)
+                solo.run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                nsolo = max(1, min(args.steps, 3))
+                for _ in range(nsolo):
+                    solo.run()
+                torch.cuda.synchronize()
+                ds = (time.perf_counter() - t0) / nsolo
+                rtf1 = total_s / ds
+                variants["single_rank_same_workload"] = {
+                    "what": "the whole 50-track set on rank 0 alone (no collective), timed after the multi-rank region",
+                    "value": round(rtf1, 2), "unit": "x real-time", "ms_per_step": round(ds * 1e3, 3),
+                    "efficiency_of_headline": round(args.steps * total_s / dt / (world * rtf1), 4)}
+                del solo
+        if world > 1:
+            dist.barrier()
+    if rank != 0:
+        return None
+    plan = sep.nsgt.nsgt.plan
+    my_items = [it.length for q in dmx.plan.rounds for it in (p.item for p in q[0])]
+    work = algorithmic_work(plan, 1, my_items, args.wiener)
+    roofline = dominant_roofline(dom, prof, work, args.steps, dt, args.precision, args.wiener) if dom else None
+    hbm, mfma = roofline_tables(work, prof_all, 1, args.wiener) if prof_all else ([], [])
+    stems_gb = 8 * 4 * sum(lengths) / 1e9
+    result = {
+        "metric": METRIC,
+        "value": round(args.steps * total_s / dt, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d seeded track lengths in [150, 420] s (%.0f s of stereo audio, %d chunk "
+                               "work items of <= 2,621,440 samples) as one chunk batch, offline model (Bark-262 sliCQT), %s, "
+                               "seeded synthetic weights" % (len(lengths), total_s, sum(len(q) for q in dmx.plan.queues),
+                                                              "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
+                   "parallelism": "chunk items dealt longest-first to %d rank(s) (imbalance %.4f), %d items per stacked round, %s"
+                                  % (world, dmx.plan.imbalance(), args.stack,
+                                     ("RCCL all_gather_into_tensor of the stems per round (%.1f GB per step to every rank), overlapped "
+                                      "with the next round's kernels, then placement into per-track tensors" % stems_gb)
+                                     if dmx.gather else "no data-path collective")},
+        "roofline": roofline,
+        "roofline_hbm": hbm,
+        "roofline_mfma": mfma,
+    }
+    if variants:
+        result["variants"] = variants
+    return result
 
 
 if __name__ == "__main__":

@@ -208,7 +208,10 @@ int xsq_magnitude_stats(int nblocks, const int32_t* F, const int32_t* T, const f
  *     apply_update 0: gradients only (parameters and running statistics untouched)
  *     loss_out HOST double[2]: complex-MSE term, mask-sum term (the step synchronises the stream,
  *              as loss.item() at training.py:110 does)
- *   xsq_train_read: what = 0 parameters, 1 gradients -> HOST float[nparams].                    */
+ *   xsq_train_read: what = 0 parameters, 1 gradients, 2 / 3 AdamW first / second moments -> HOST
+ *   float[nparams].  xsq_train_write restores parameters (0) or a moment pool (2 / 3) from the host and
+ *   xsq_train_step_count reads (set < 0) or restores the AdamW step counter: together they are the
+ *   optimizer.state_dict() the reference checkpoints for resuming (training.py:419-430).        */
 typedef struct xsq_train xsq_train;
 int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32_t* T, int causal,
                      const float* params, int64_t nparams);
@@ -218,6 +221,8 @@ int xsq_train_step(xsq_train* t, const float* X, const float* Yt, int B, int S, 
                    float lr, float weight_decay, int apply_update, double* loss_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 int xsq_train_read(xsq_train* t, int what, float* host_out);
+int xsq_train_write(xsq_train* t, int what, const float* host_in);
+int64_t xsq_train_step_count(xsq_train* t, int64_t set);
 /* Arithmetic of the GEMM-shaped forward / data-gradient kernels of the step: 0 fp32 MFMA (default), 2 bf16x6 (see
  * xsq_model_set_precision; the reference trains these layers under bf16 autocast, training.py:473-476).          */
 int xsq_train_set_precision(xsq_train* t, int mode);

@@ -434,3 +434,102 @@ def test_bf16x6_stems_match_reference_golden(seps, n, name):
     d = got - ref
     rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
     assert rms < 1e-6 and mx < 1e-5, (name, n, rms, mx)
+
+
+def test_separator_load_checkpoint_equals_seeded_separator(tmp_path, seeded_sd, seps):
+    """Drop-in loader happy path on the device: a reference-style model directory -> Separator.load -> the same
+    bits as the separator built from the same tensors in memory (separator.py:50-93, 286-293, 321-356)."""
+    from test_model_cpu import write_checkpoint
+    from xumx_slicq_amd.separator import Separator
+    x = synth_audio(70000, seed=5).cuda()
+    for realtime, name in ((False, "offline_wiener"), (True, "realtime")):
+        write_checkpoint(tmp_path, seeded_sd, realtime=realtime)
+        sep = Separator.load(model_path=str(tmp_path), device="cuda", warmup=1 if realtime else 0)
+        seps[name].chunk_size = 2621440
+        assert torch.equal(sep(x), seps[name](x)), name
+        d = sep.to_dict(sep(x))
+        assert list(d) == ["bass", "vocals", "other", "drums"] and d["vocals"].shape == (1, 2, 70000)
+
+
+def test_per_block_call_matches_the_grouped_launch_and_the_reference_masks(seps):
+    """sliced_umx[i](Xblock, abs(Xblock)) (model.py:76-80, 213-271) as a one-block launch."""
+    from xumx_slicq_amd.phase import abs_of_real_complex
+    g = load_golden("cdae_masks_70000.npz")
+    n = int(g["n"])
+    x = synth_audio(n, seed=20260101 + n).cuda()
+    for name, tag in (("offline_wiener", "offline"), ("realtime", "causal")):
+        sep = seps[name]
+        X = sep.nsgt(x)
+        Yall, Mall = sep.xumx_model(X, return_masks=True)
+        for i in KEEP:
+            mag = abs_of_real_complex(X[i])
+            keep_x, keep_m = X[i].clone(), mag.clone()
+            Y, M = sep.xumx_model.sliced_umx[i](X[i], mag)
+            assert torch.equal(X[i], keep_x) and torch.equal(mag, keep_m), "inputs must not be modified"
+            assert Y.shape == Yall[i].shape and M.shape == Mall[i].shape
+            assert float((M - Mall[i]).abs().max()) < 1e-6 and float((Y - Yall[i]).abs().max()) < 1e-5, (tag, i)
+            assert float((M.cpu() - torch.from_numpy(g[f"mask_{tag}_{i}"])).abs().max()) < 5e-5, (tag, i)
+    blk = seps["realtime"].xumx_model.sliced_umx[2]
+    with pytest.raises(ValueError):
+        blk(X[1], abs_of_real_complex(X[1]))
+
+
+def test_graph_cache_follows_parameter_and_postfilter_changes(seeded_sd):
+    """A captured forward holds raw pointers into the model handle: after load_state_dict / a post-filter switch
+    the stale graph must be dropped, not replayed (it would run the old weights out of freed memory)."""
+    import copy
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.weights import seeded_state_dict
+    sep = seeded_separator(realtime=False, wiener=False)
+    sep.chunk_size = 60000
+    x = synth_audio(150000, seed=43).cuda()
+    g1 = sep.forward_graphed(x).clone()
+    assert torch.equal(g1, sep(x))
+    other = seeded_state_dict(sep.xumx_model.table.shapes, seed=99)
+    sep.xumx_model.load_state_dict(other, strict=True)
+    sep.xumx_model.eval()
+    e2 = sep(x).clone()                                     # rebuilds (and frees) the handle the old graph captured
+    g2 = sep.forward_graphed(x).clone()
+    assert torch.equal(e2, g2) and not torch.equal(g1, g2)
+    assert len(sep._graphs) == 1
+    for blk in sep.xumx_model.sliced_umx:                   # Wiener on: another pipeline, another graph
+        blk.realtime = False
+    e3 = sep(x).clone()
+    g3 = sep.forward_graphed(x).clone()
+    assert torch.equal(e3, g3) and not torch.equal(g3, g2)
+    sep.xumx_model.set_precision("bf16x6")
+    g4 = sep.forward_graphed(x).clone()
+    assert torch.equal(g4, sep(x))
+    c = copy.deepcopy(sep.xumx_model)                       # device handles are not shared with the copy
+    assert c._handles == {} and sep.xumx_model._handles
+
+
+@pytest.mark.parametrize("name,wiener", [("offline_phasemix", False), ("offline_wiener", True)])
+def test_full_size_track_matches_the_oracle(seps, oracle_plan, seeded_sd, name, wiener):
+    """BASELINE configs[1] / [2] at FULL size: the 10,584,000-sample track of bench.py (4 chunks of 2,621,440
+    samples stacked along the batch axis -- B = 4, S = 292, the exact bench shape -- plus the 98,240-sample tail on
+    the side stream; with Wiener-EM: 18 windows in block 69, per-chunk window maxima) against the CPU oracle's
+    literal chunk loop (phase.py:43-59 at 85,264 frames, norbert/__init__.py:257).  ~1-2 minutes of host CPU
+    per configuration.  Bar: 1e-4 RMS / 1e-3 max-abs (BASELINE.json)."""
+    import os
+    from oracle import separator as osep
+    n = 10_584_000
+    sep = seps[name]
+    sep.chunk_size = 2621440
+    x = synth_audio(n, seed=20260101)
+    est = sep(x.cuda()).cpu()
+    torch.cuda.synchronize()
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(old, min(32, os.cpu_count() or 1)))
+    try:
+        ref = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=wiener)
+    finally:
+        torch.set_num_threads(old)
+    assert est.shape == ref.shape == (4, 1, 2, n)
+    worst_rms = worst_max = 0.0
+    for c0 in range(0, n, 2621440):            # per chunk: a failure names the chunk (stacked pass vs tail)
+        d = (est[..., c0:c0 + 2621440] - ref[..., c0:c0 + 2621440]).double()
+        rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+        assert rms < RMS_TOL and mx < MAX_TOL, (name, c0, rms, mx)
+        worst_rms, worst_max = max(worst_rms, rms), max(worst_max, mx)
+    print(f"full-size {name}: rms {worst_rms:.2e} max {worst_max:.2e}")

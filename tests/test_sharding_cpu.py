@@ -8,8 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from xumx_slicq_amd.sharding import (WorkItem, assign_lpt, assign_tracks_lpt, chunk_items, demix_sharded,
-                                     demix_tracks)
+from xumx_slicq_amd.sharding import (ShardedDemixer, ShardPlan, WorkItem, assign_lpt, assign_tracks_lpt, chunk_items,
+                                     demix_sharded, demix_tracks)
 
 
 def fake_separate(x):
@@ -50,6 +50,58 @@ def test_track_assignment_is_a_balanced_partition():
     assert assign_tracks_lpt([10, 10, 10, 10], 4) == [[0], [1], [2], [3]]   # bench shape: one track per rank
 
 
+class FakeSeparator:
+    """CPU stand-in with the Separator.demix_into contract (items stacked along the batch axis, stems placed
+    through a row-offset table): what ShardedDemixer drives on the GPU."""
+    chunk_size = 600
+
+    def demix_into(self, audio, out, row_offsets, group=1):
+        assert group == 1 and row_offsets.shape == (4, audio.shape[0], 2) and row_offsets.dtype == torch.int64
+        flat, n = out.view(-1), audio.shape[-1]
+        for i in range(audio.shape[0]):
+            est = fake_separate(audio[i:i + 1])                 # (4, 1, 2, n): item-local, as chunks are
+            for tg in range(4):
+                for c in range(2):
+                    o = int(row_offsets[tg, i, c])
+                    flat[o:o + n] = est[tg, 0, c]
+
+
+def _sequential(tracks, cs=600):
+    return {t: torch.cat([fake_separate(x[..., s:s + cs]) for s in range(0, x.shape[-1], cs)], dim=-1)
+            for t, x in enumerate(tracks)}
+
+
+def test_shard_plan_rounds_cover_every_item_once():
+    lengths = [2500, 700, 1301, 64, 600, 1800]
+    for world in (1, 2, 3):
+        for stack in (1, 2, 4):
+            plan = ShardPlan(lengths, 600, world, stack=stack)
+            seen = [p.item for rnd in plan.rounds for per_rank in rnd for p in per_rank]
+            assert sorted(seen, key=lambda i: (i.track, i.chunk)) == chunk_items(lengths, 600)
+            for k, rnd in enumerate(plan.rounds):
+                for r, placed in enumerate(rnd):
+                    assert len(placed) <= stack
+                    end = 0
+                    for p in placed:                          # packed back to back, inside the round's width
+                        assert p.offset == end
+                        end += 8 * p.item.length
+                    assert end <= plan.width[k]
+                    # passes: equal lengths only, every item exactly once
+                    ps = plan.passes(k, r)
+                    assert sorted(id(p) for g in ps for p in g) == sorted(id(p) for p in placed)
+                    assert all(len({p.item.length for p in g}) == 1 for g in ps)
+            assert plan.imbalance() >= 1.0
+
+
+def test_sharded_demixer_single_process_places_every_chunk():
+    g = torch.Generator().manual_seed(1)
+    tracks = [torch.randn(1, 2, n, generator=g) for n in (2500, 700, 1301, 64)]
+    get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+    out = ShardedDemixer(FakeSeparator(), [x.shape[-1] for x in tracks], get, torch.device("cpu"), stack=3).run()
+    ref = _sequential(tracks)
+    assert all(torch.equal(out[t], ref[t]) for t in ref)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,7 +124,22 @@ def _worker(rank, world, port, q):
         ok_tracks = sorted(own) == sorted(mine_t) and all(torch.equal(own[t], whole[t]) for t in own)
         allg = demix_tracks(fake_separate, tracks, gather=True)
         ok_tracks = ok_tracks and sorted(allg) == [0, 1, 2, 3] and all(torch.equal(allg[t], whole[t]) for t in allg)
-        res = (rank, ok, ok_part and ok_tracks)
+        # stacked rounds + one all-gather per round + placement (what bench.py --gpus N runs)
+        get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+        lens = [x.shape[-1] for x in tracks]
+        dmx = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2)
+        ok_dmx = True
+        for _ in range(2):                                       # buffers are reused across steps
+            got = dmx.run()
+            ok_dmx = ok_dmx and all(torch.equal(got[t], ref[t]) for t in ref)
+        own = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, gather=False).run()
+        mine2 = [p.item for rnd in dmx.plan.rounds for p in rnd[rank]]
+        ok_dmx = ok_dmx and sorted(mine2, key=lambda i: (i.track, i.chunk)) == sorted(mine, key=lambda i: (i.track, i.chunk))
+        ok_dmx = ok_dmx and all(torch.equal(own[i.track][..., i.start:i.start + i.length],
+                                            ref[i.track][..., i.start:i.start + i.length]) for i in mine2)
+        theirs = [p.item for rnd in dmx.plan.rounds for r2 in range(world) if r2 != rank for p in rnd[r2]]
+        ok_dmx = ok_dmx and all(float(own[i.track][..., i.start:i.start + i.length].abs().max()) == 0.0 for i in theirs)
+        res = (rank, ok, ok_part and ok_tracks and ok_dmx)
     finally:
         q.put(res)
         dist.destroy_process_group()

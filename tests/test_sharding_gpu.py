@@ -1,0 +1,117 @@
+"""The sharded chunk-batch path (BASELINE configs[3]) with the REAL Separator on the GPU: stacked passes over
+work items of different tracks, stems placed through row offsets, and -- with two ranks sharing the one GPU of
+the test box over gloo (RCCL refuses two ranks on one device) -- the all-gather + placement, all compared
+bitwise with the single-process ``Separator.forward`` of every track."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CS = 100_000                       # chunk size of these tests: S = 13 slices per full chunk
+LENGTHS = (250_000, 130_000, 100_000, 9_500, 300_000, 5_000)
+
+
+def _tracks(dev):
+    from xumx_slicq_amd.synth import synth_audio
+    return [synth_audio(n, seed=31 + t).to(dev) for t, n in enumerate(LENGTHS)]
+
+
+def _reference(sep, tracks):
+    """The reference's literal chunk loop (separator.py:147-231), one chunk per pass."""
+    sep.batch_chunks = False
+    try:
+        return {t: sep(x).clone() for t, x in enumerate(tracks)}
+    finally:
+        sep.batch_chunks = True
+
+
+@pytest.mark.parametrize("wiener", [False, True])
+def test_stacked_items_of_different_tracks_equal_the_chunk_loop(wiener):
+    from xumx_slicq_amd.separator import seeded_separator
+    from xumx_slicq_amd.sharding import ShardedDemixer
+    dev = torch.device("cuda", 0)
+    sep = seeded_separator(realtime=False, wiener=wiener, device=dev, chunk_size=CS)
+    tracks = _tracks(dev)
+    ref = _reference(sep, tracks)
+    get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+    for stack in (1, 3):
+        dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=stack)
+        for _ in range(2):
+            out = dmx.run()
+            torch.cuda.synchronize()
+            for t in ref:
+                assert out[t].shape == ref[t].shape
+                assert torch.equal(out[t], ref[t]), (wiener, stack, t, float((out[t] - ref[t]).abs().max()))
+
+
+def test_demix_into_rejects_bad_arguments():
+    from xumx_slicq_amd.separator import seeded_separator
+    dev = torch.device("cuda", 0)
+    sep = seeded_separator(realtime=False, wiener=False, device=dev, chunk_size=CS)
+    out = torch.zeros(8 * 20_000, device=dev)
+    offs = (torch.arange(8, device=dev) * 20_000).view(4, 1, 2)
+    with pytest.raises(ValueError):
+        sep.demix_into(torch.zeros(1, 2, CS + 1, device=dev), out, offs)
+    with pytest.raises(ValueError):
+        sep.demix_into(torch.zeros(1, 2, 20_000, device=dev), out, offs.view(8))
+    sep.demix_into(torch.zeros(1, 2, 20_000, device=dev), out, offs)       # the valid call
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = (rank, "not run")
+    try:
+        from xumx_slicq_amd.separator import seeded_separator
+        from xumx_slicq_amd.sharding import ShardedDemixer
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        msgs = []
+        for wiener in (False, True):
+            sep = seeded_separator(realtime=False, wiener=wiener, device=dev, chunk_size=CS)
+            tracks = _tracks(dev)
+            ref = _reference(sep, tracks)
+            get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+            dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=2)
+            assert dmx.world == world and dmx.gather
+            for step in range(2):
+                out = dmx.run()
+                torch.cuda.synchronize()
+                for t in ref:
+                    if not torch.equal(out[t], ref[t]):
+                        msgs.append(f"wiener={wiener} step={step} track={t} differs by {float((out[t] - ref[t]).abs().max()):.3e}")
+            own = ShardedDemixer(sep, LENGTHS, get, dev, stack=2, gather=False).run()
+            torch.cuda.synchronize()
+            for rnd in dmx.plan.rounds:
+                for p in rnd[rank]:
+                    i = p.item
+                    if not torch.equal(own[i.track][..., i.start:i.start + i.length], ref[i.track][..., i.start:i.start + i.length]):
+                        msgs.append(f"wiener={wiener} no-gather item {i} differs")
+        res = (rank, "ok" if not msgs else "; ".join(msgs[:4]))
+    except Exception as e:          # reported through the queue: a dead worker would only time the test out
+        res = (rank, f"{type(e).__name__}: {e}")
+    finally:
+        q.put(res)
+        dist.destroy_process_group()
+
+
+def test_two_ranks_all_gather_and_place_bitwise():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res == [(0, "ok"), (1, "ok")], res

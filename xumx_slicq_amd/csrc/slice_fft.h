@@ -232,13 +232,30 @@ __global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x,
     }
 }
 
-// ---- inverse: seg[row] = L * irfft_L( sum over covering bands of the synthesis spectra ) ------------
+// ---- inverse: seg = L * irfft_L( sum over covering bands of the synthesis spectra ), overlap-added -----
+// Overlap-add fused in (nsgt/unslicing.py:6-69, no synthesis window): slice s holds samples (2s-2)h .. (2s+2)h,
+// every output sample is the sum of exactly two neighbouring slices -- one even, one odd.  The launch with
+// parity 0 transforms the even slices and STORES them (together they cover every sample once); the launch
+// with parity 1 transforms the odd slices and ADDS them (load, add, store: each sample belongs to one odd
+// slice, so no atomics and a fixed order: even + odd, bitwise the same sum as any other order of two terms).
+// The L-sample segments never go to HBM.  Samples past the last even slice (S even, tail of the last odd
+// slice) have no partner and are stored by the odd launch.  row_off: element offset of packed channel bc in y
+// (the caller's final tensor: the hard concat of separator.py:231 by placement), nullptr = bc * length.
+struct OlaArgs {
+    float* y;
+    const int64_t* row_off;
+    int S, h, parity;
+    int64_t length;
+};
+
 __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
-                                                      const FftTables T, float* __restrict__ seg) {
+                                                      const FftTables T, const OlaArgs O) {
     __shared__ float2 Z[FFT_N + 1];        // bins 0..N while gathering, then the complex sequence
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
-    const int row = blockIdx.x;
+    const int nsl = (O.S + 1 - O.parity) >> 1;              // slices of this parity per channel
+    const int bc = blockIdx.x / nsl, s = 2 * (blockIdx.x - bc * nsl) + O.parity;
+    const int row = bc * O.S + s;
     if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
     for (int k = tid; k <= FFT_N; k += 256) Z[k] = make_float2(0.f, 0.f);
     __syncthreads();
@@ -307,9 +324,43 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
     }
     __syncthreads();
     if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1>(Z, T.w1, w2s, tid);
-    float2* out = reinterpret_cast<float2*>(seg + (int64_t)row * FFT_L);
-    if (!(XSQ_ABLATE & 128))
-        for (int nn = tid; nn < FFT_N; nn += 256) out[nn] = Z[fft_pos(nn)];
+    if (XSQ_ABLATE & 128) return;
+    // samples 2nn, 2nn+1 of the segment = Re / Im of sequence element nn; output index i = (2s-2)h + 2nn
+    float* const yr = O.y + (O.row_off ? O.row_off[bc] : (int64_t)bc * O.length);
+    const int64_t i0 = (int64_t)(2 * s - 2) * O.h;
+    // the second half of the last slice has no partner: plain store even in the adding launch
+    const bool add_lo = O.parity != 0, add_hi = O.parity != 0 && s + 1 < O.S;
+    const bool al8 = ((reinterpret_cast<uintptr_t>(yr + i0)) & 7) == 0;       // workgroup-uniform (h may be odd: i0 too)
+    constexpr int NIT = (FFT_N + 255) / 256;
+    if (al8 && i0 >= 0 && i0 + FFT_L <= O.length) {
+        // interior slice, 8-byte aligned: all loads of the partner sums first, then all stores
+        float2* const y2 = reinterpret_cast<float2*>(yr + i0);
+        float2 prev[NIT];
+        if (O.parity) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int nn = tid + 256 * it;
+                prev[it] = (nn < FFT_N && (2 * nn < 2 * O.h ? add_lo : add_hi)) ? y2[nn] : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int nn = tid + 256 * it;
+            if (nn >= FFT_N) break;
+            float2 v = Z[fft_pos(nn)];
+            if (O.parity) { v.x += prev[it].x; v.y += prev[it].y; }
+            y2[nn] = v;
+        }
+        return;
+    }
+    // edge slices (first / last of a channel) and odd row offsets: per-sample bounds, 4-byte accesses
+    for (int nn = tid; nn < FFT_N; nn += 256) {
+        const float2 v = Z[fft_pos(nn)];
+        const bool add = 2 * nn < 2 * O.h ? add_lo : add_hi;     // 2h is even: both samples of nn lie in the same half
+        const int64_t ia = i0 + 2 * nn, ib = ia + 1;
+        if (ia >= 0 && ia < O.length) yr[ia] = add ? yr[ia] + v.x : v.x;
+        if (ib >= 0 && ib < O.length) yr[ib] = add ? yr[ib] + v.y : v.y;
+    }
 }
 
 }  // namespace xsq

@@ -684,6 +684,7 @@ size_t xsq_slicqt_inverse_workspace(xsq_plan* P, int BC, int S) {
     const size_t rows = (size_t)BC * S;
     FftPlan f;
     if (!lds_fft(P) && get_fft(P, 1, (int)rows, &f)) return 0;
+    if (lds_fft(P)) return al(rows * P->sumFT * 8) + 256;        // Z only: spectra and segments stay in LDS
     return al(rows * P->sumFT * 8) + al(rows * P->nbins * 8) + al(rows * P->L * 4) + al(f.work_bytes) + 256;
 }
 
@@ -722,8 +723,8 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     if (rc) return rc;
     char* w = (char*)ws;
     float* Z = (float*)w;    w += al((size_t)rows * P->sumFT * 8);
-    float2* fr = (float2*)w; w += al((size_t)rows * P->nbins * 8);
-    float* seg = (float*)w;  w += al((size_t)rows * P->L * 4);
+    float2* fr = (float2*)w; if (!lds_fft(P)) w += al((size_t)rows * P->nbins * 8);
+    float* seg = (float*)w;  if (!lds_fft(P)) w += al((size_t)rows * P->L * 4);
     void* fwork = w;
     if ((size_t)(w - (char*)ws) + f.work_bytes > ws_bytes) {
         set_error("xsq_slicqt_inverse: workspace too small (%zu needed, %zu given)",
@@ -747,11 +748,18 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     hipLaunchKernelGGL((grouped_gemm_kernel<BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     if (lds_fft(P)) {
-        XSQ_PROF("slice_irfft", stream);
+        // inverse slice FFT with the overlap-add fused in: even slices store, odd slices add (slice_fft.h)
+        XSQ_PROF("slice_irfft_ola", stream);
         GatherSched G;
         G.tgt = P->d_tgt; G.row_len = (int)P->sumFT;
         for (int i = 0; i < 5; ++i) G.begin[i] = P->phase_begin[i];
-        hipLaunchKernelGGL(k_slice_irfft, dim3(rows), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), seg);
+        for (int parity = 0; parity < 2; ++parity) {
+            const int nsl = (S + 1 - parity) / 2;
+            OlaArgs O{y, row_offsets, S, P->h, parity, length};
+            hipLaunchKernelGGL(k_slice_irfft, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O);
+        }
+        XSQ_HIP(hipGetLastError());
+        return XSQ_OK;
     } else {
         { XSQ_PROF("spectrum_gather", stream);
         hipLaunchKernelGGL(k_spectrum_gather, dim3((P->nbins + 255) / 256, rows), dim3(256), 0, stream, Z,

@@ -762,11 +762,31 @@ int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32
     return XSQ_OK;
 }
 
+static float* train_pool(xsq_train* Tr, int what) {
+    return what == 0 ? Tr->d_params : what == 1 ? Tr->d_grads : what == 2 ? Tr->d_m : Tr->d_v;
+}
+
 int xsq_train_read(xsq_train* Tr, int what, float* host_out) {
-    XSQ_REQUIRE(Tr && host_out && what >= 0 && what <= 1, "xsq_train_read: bad argument");
+    XSQ_REQUIRE(Tr && host_out && what >= 0 && what <= 3, "xsq_train_read: bad argument (what = 0..3)");
     XSQ_HIP(hipDeviceSynchronize());
-    XSQ_HIP(hipMemcpy(host_out, what == 0 ? Tr->d_params : Tr->d_grads, (size_t)Tr->nparams * 4, hipMemcpyDeviceToHost));
+    XSQ_HIP(hipMemcpy(host_out, train_pool(Tr, what), (size_t)Tr->nparams * 4, hipMemcpyDeviceToHost));
     return XSQ_OK;
+}
+
+// Restores a pool from the host (resuming from a checkpoint: parameters + both AdamW moments).  Gradients are
+// an output of the step and cannot be written.
+int xsq_train_write(xsq_train* Tr, int what, const float* host_in) {
+    XSQ_REQUIRE(Tr && host_in && (what == 0 || what == 2 || what == 3), "xsq_train_write: bad argument (what = 0, 2 or 3)");
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpy(train_pool(Tr, what), host_in, (size_t)Tr->nparams * 4, hipMemcpyHostToDevice));
+    return XSQ_OK;
+}
+
+// AdamW step counter (bias correction 1 - beta^step); set >= 0 to restore it, -1 to only read.  Returns the counter.
+int64_t xsq_train_step_count(xsq_train* Tr, int64_t set) {
+    if (!Tr) return XSQ_ERR_ARG;
+    if (set >= 0) Tr->step = set;
+    return Tr->step;
 }
 
 // workspace (floats): xin | z1 a1 g1 | z2 a2 g2 | z3 a3 g3 | masks gM | Y gY [Y0] | bn stats | mean scale | loss

@@ -83,10 +83,82 @@ class _SlicedUnmixCDAE(nn.Module):
             p.grad = None
         self.eval()
 
+    # -- the reference's per-block call, sliced_umx[i](Xblock, abs(Xblock)) (model.py:76-80, 213-271) ------
+    def _block_model(self, device: torch.device):
+        """A one-block xsq_model of this block's parameters, rebuilt when any of them changed."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        sd = self.state_dict()
+        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        cached = self.__dict__.setdefault("_block_handles", {}).get(idx)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if cached is not None:
+            _lib.lib.xsq_model_destroy(cached[1])
+        params = torch.cat([v.detach().to("cpu", torch.float32).reshape(-1) for k, v in sd.items()
+                            if not k.endswith("num_batches_tracked")]).numpy()
+        F_ = np.asarray([self.nb_f_bins], dtype=np.int32)
+        T_ = np.asarray([self.nb_t_bins], dtype=np.int32)
+        out = C.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib.xsq_model_create(C.byref(out), 1, F_.ctypes.data, T_.ctypes.data,
+                                                 1 if self.causal else 0, params.ctypes.data, params.size),
+                       "xsq_model_create")
+        self._block_handles[idx] = (key, out)
+        return out
+
+    def __del__(self):
+        try:
+            for _, h in self.__dict__.get("_block_handles", {}).values():
+                _lib.lib.xsq_model_destroy(h)
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_block_handles", None)
+        st.pop("_block_ws", None)
+        return st
+
     def forward(self, xcomplex: Tensor, x: Tensor):
-        raise NotImplementedError(
-            "blocks are not run one by one on the HIP path: call Unmix.forward, which runs every block "
-            "and target in grouped launches")
+        """(B, 2, F, S, T, 2), (B, 2, F, S, T) -> (estimates (4, B, 2, F, S, T, 2), masks (4, B, 2, F, S, T)),
+        model.py:213-271.  ``x`` is ``abs_of_real_complex(xcomplex)`` in every caller of the reference
+        (model.py:74-76); the kernel forms the magnitude from ``xcomplex`` itself, ``x`` only has its shape
+        checked and is never modified (the reference whitens it in place).  One launch set for the four targets
+        of this block; ``Unmix.forward`` runs all 70 blocks in one."""
+        from .phase import wiener_em_arena
+        if self.training:
+            raise _lib.XsqError("the HIP CDAE is the inference path (BatchNorm folded); call .eval()/.freeze()")
+        F_, T_ = self.nb_f_bins, self.nb_t_bins
+        if xcomplex.dim() != 6 or tuple(xcomplex.shape[1:3]) != (2, F_) or tuple(xcomplex.shape[4:]) != (T_, 2):
+            raise ValueError(f"expected xcomplex (B, 2, {F_}, S, {T_}, 2); got {tuple(xcomplex.shape)}")
+        if tuple(x.shape) != tuple(xcomplex.shape[:-1]):
+            raise ValueError(f"x must be the magnitude of xcomplex, shape {tuple(xcomplex.shape[:-1])}; got {tuple(x.shape)}")
+        if xcomplex.device.type != "cuda":
+            raise _lib.XsqError(f"the CDAE runs on a ROCm device only (got '{xcomplex.device}'); there is no CPU fallback")
+        if not self.mask:
+            raise _lib.XsqError("the HIP CDAE applies the multiplicative skip connection (mask=True, the reference's default)")
+        B = xcomplex.shape[0]
+        S = xcomplex.shape[3]
+        dev = xcomplex.device
+        X = xcomplex.contiguous().float().view(-1)
+        h = self._block_model(dev)
+        table = BlockTable([(F_, T_)])
+        with torch.cuda.device(dev):
+            Y = torch.empty(4, B, 2, F_, S, T_, 2, dtype=torch.float32, device=dev)
+            masks = torch.empty(4, B, 2, F_, S, T_, dtype=torch.float32, device=dev)
+            nbytes = _lib.lib.xsq_cdae_workspace(h, B, S)
+            if nbytes == 0:
+                raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            wss = self.__dict__.setdefault("_block_ws", {})
+            ws = wss.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = wss[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib.xsq_cdae_forward(h, X.data_ptr(), B, S, Y.data_ptr(), masks.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
+            if not self.realtime:
+                wiener_em_arena(table, X, Y.view(-1), B, S)
+        return Y, masks
 
 
 class Unmix(nn.Module):
@@ -138,8 +210,24 @@ class Unmix(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def train(self, mode: bool = True):
-        self.refresh()
+        if bool(mode) != bool(self.training):     # an idempotent .eval() must not force a 60 MB repack + handle rebuild
+            self.refresh()
         return super().train(mode)
+
+    def __deepcopy__(self, memo):
+        """Copies share nothing with the original on the device side: the ctypes handles and workspaces are
+        dropped (a copied raw handle would be freed twice) and rebuilt on the copy's first forward."""
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k in ("_handles", "_ws") else copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_handles"], st["_ws"] = {}, {}
+        return st
 
     def packed_parameters(self) -> np.ndarray:
         """fp32 tensors of the state_dict in key order, num_batches_tracked left out
@@ -169,7 +257,8 @@ class Unmix(nn.Module):
             _lib.check(_lib.lib.xsq_model_create(
                 C.byref(out), len(self.table), self._F.ctypes.data, self._T.ctypes.data,
                 1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
-        _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
+            # inside the device guard: bf16 modes allocate and launch on the CURRENT device
+            _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
         self._handles[idx] = (ver, out)
         return out
 
@@ -179,8 +268,9 @@ class Unmix(nn.Module):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision {precision!r} not in {sorted(_PRECISIONS)}")
         self.precision = precision
-        for (_ver, h) in self._handles.values():
-            _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
+        for idx, (_ver, h) in self._handles.items():
+            with torch.cuda.device(idx):       # the split-weight pool is allocated / converted on the model's device
+                _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
 
     def __del__(self):
         try:

@@ -71,13 +71,31 @@ class Separator(nn.Module):
         self.xumx_model.freeze()
         self.eval()
 
+    def _graph_key(self, audio_big: Tensor):
+        """Everything a captured forward depends on besides the input values: shape and device, the chunking
+        switches, the packed-parameter version of the model (captured kernels hold raw pointers into the
+        xsq_model handle), the arithmetic mode and the post-filter / fusion switches read per call."""
+        m = self.xumx_model
+        return (tuple(audio_big.shape), audio_big.device.index, self.chunk_size, getattr(m, "precision", "fp32"),
+                bool(getattr(self, "overlap_tail", True)), bool(getattr(self, "batch_chunks", True)),
+                int(getattr(self, "max_stack", 8)), int(getattr(self, "pass_streams", 1)),
+                m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused())
+
+    def drop_graphs(self):
+        """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
+        self.__dict__.pop("_graphs", None)
+
     def forward_graphed(self, audio_big: Tensor) -> Tensor:
         """``forward`` replayed from a HIP graph captured per input shape (launch-bound shapes: the
         2.2 s tail chunk or streaming-sized inputs spend more time between launches than inside them).
-        The result tensor is owned by the graph and overwritten by the next call of the same shape."""
-        key = (tuple(audio_big.shape), audio_big.device.index, self.chunk_size, getattr(self.xumx_model, "precision", "fp32"),
-               bool(getattr(self, "overlap_tail", True)))
+        The result tensor is owned by the graph and overwritten by the next call of the same shape.
+        Graphs captured against an older parameter version / post-filter setting are dropped before the
+        model handle they point into is rebuilt (``Unmix._model`` frees it)."""
+        key = self._graph_key(audio_big)
         cache = self.__dict__.setdefault("_graphs", {})
+        ver = key[8:]
+        for k in [k for k in cache if k[1] == key[1] and k[8:] != ver]:
+            del cache[k]                              # stale: would replay against freed device memory
         entry = cache.get(key)
         if entry is None:
             static_in = audio_big.clone()
@@ -101,6 +119,46 @@ class Separator(nn.Module):
         graph.replay()
         return static_out
 
+    def _fused(self) -> bool:
+        """Mix-phase models: the CDAE writes the masks only and the inverse transform forms mask * X while it
+        loads (same products, same order: bitwise equal to decoding the materialised estimates)."""
+        return bool(getattr(self, "fuse_phasemix", os.environ.get("XSQ_FUSE_PHASEMIX", "1") != "0")
+                    and all(bool(b.realtime) for b in self.xumx_model.sliced_umx))
+
+    def _decode_into(self, out: Tensor, Xc, length: int, offsets: Tensor, group: int = 0):
+        """CDAE + post-filter + inverse transform of the coefficient list ``Xc`` (batch B); packed channel
+        (target, b, c) is written to out.view(-1)[offsets[target, b, c] : +length]."""
+        eng = self.insgt.nsgt.nsgt
+        offs = offsets.reshape(-1).contiguous()
+        if self._fused():
+            masks, X, B, S = self.xumx_model.masks_arena(Xc)
+            eng.backward_masked(masks, X, 8 * B, 2 * B, S, length, out, offs)
+            return
+        Ylist = self.xumx_model(Xc, wiener_batch_group=group)
+        arena, lead, S = eng.table.as_arena(list(Ylist))
+        eng.backward(arena, offs.numel(), S, length, out=out, row_offsets=offs)
+
+    @torch.no_grad()
+    def demix_into(self, audio: Tensor, out: Tensor, row_offsets: Tensor, group: int = 1):
+        """One pass over ``audio`` (k * group, 2, n): k independent work items of n <= chunk_size samples each
+        (chunks of any tracks -- no state crosses the reference's chunk loop, separator.py:153-229), ``group``
+        = nb_samples of an item.  The stems of packed channel (target, item*group + b, c) land at
+        out.view(-1)[row_offsets[target, item*group + b, c] : + n] -- the hard concat of separator.py:231 by
+        placement.  The Wiener window maximum keeps its per-item scope (quirk A13) through ``group``.
+        Building block of ``sharding.ShardedDemixer``; ``forward`` is the single-track case."""
+        if audio.dim() != 3 or audio.shape[1] != 2:
+            raise ValueError(f"audio must be (items * nb_samples, 2, n); got {tuple(audio.shape)}")
+        n = audio.shape[-1]
+        if n > self.chunk_size:
+            raise ValueError(f"work items are at most chunk_size = {self.chunk_size} samples (got {n})")
+        if tuple(row_offsets.shape) != (4, audio.shape[0], 2) or row_offsets.dtype != torch.int64:
+            raise ValueError(f"row_offsets must be int64 (4, {audio.shape[0]}, 2); got {tuple(row_offsets.shape)}")
+        min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
+        if n < min_samples:
+            audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n), device=audio.device,
+                                                  dtype=audio.dtype)], dim=-1)
+        self._decode_into(out, self.nsgt(audio), n, row_offsets, group=group)
+
     @torch.no_grad()
     def forward(self, audio_big: Tensor) -> Tensor:
         """(nb_samples, 2, N) fp32 on a ROCm device -> (4, nb_samples, 2, N).  separator.py:133-232:
@@ -112,7 +170,6 @@ class Separator(nn.Module):
         launches.  ``batch_chunks = False`` restores the literal loop."""
         nb, N, cs = audio_big.shape[0], audio_big.shape[-1], self.chunk_size
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
-        eng = self.insgt.nsgt.nsgt
         dev = audio_big.device
         # every chunk's stems are written straight into their place of the result (the hard concat
         # of separator.py:231 without a copy): packed channel (target, [chunk,] b, c) -> out row
@@ -120,19 +177,8 @@ class Separator(nn.Module):
         rows = (torch.arange(4, device=dev).view(4, 1, 1, 1) * nb + torch.arange(nb, device=dev).view(1, 1, nb, 1)) * 2 \
             + torch.arange(2, device=dev).view(1, 1, 1, 2)                       # (4, 1, nb, 2) row of `out`
 
-        # mix-phase models: the CDAE writes the masks only and the inverse transform forms mask * X while it
-        # loads (same products, same order: bitwise equal to decoding the materialised estimates)
-        fused = getattr(self, "fuse_phasemix", os.environ.get("XSQ_FUSE_PHASEMIX", "1") != "0") and all(bool(b.realtime) for b in self.xumx_model.sliced_umx)
-
         def decode(Xc, length, offsets, group=0):
-            offs = offsets.reshape(-1).contiguous()
-            if fused:
-                masks, X, B, S = self.xumx_model.masks_arena(Xc)
-                eng.backward_masked(masks, X, 8 * B, 2 * B, S, length, out, offs)
-                return
-            Ylist = self.xumx_model(Xc, wiener_batch_group=group)
-            arena, lead, S = eng.table.as_arena(list(Ylist))
-            eng.backward(arena, offs.numel(), S, length, out=out, row_offsets=offs)
+            self._decode_into(out, Xc, length, offsets, group)
 
         full = N // cs if getattr(self, "batch_chunks", True) else 0
         start0 = 0

@@ -15,6 +15,12 @@ independent work items.  Two levels, one process per GPU:
   with the ``nccl`` backend), issued ``async_op=True`` per round so it overlaps the next
   round's kernels.  Chunks are never merged into one Wiener batch across tracks' statistics
   (the window maximum spans the batch dimension).
+* ``ShardedDemixer`` (BASELINE configs[3], what ``bench.py --gpus N`` runs for N > 1): the same
+  (track, chunk) items, but a rank runs its full-size chunks STACKED along the batch axis through
+  ``Separator.demix_into`` (the pass shape of the single-GPU headline), the kernels write the stems
+  straight into a packed per-round send buffer, one ``all_gather_into_tensor`` per round runs
+  beside the next round's kernels, and a placement step copies every item into its track's
+  ``(4, nb_samples, 2, N_t)`` tensor -- the final waveform concat of separator.py:231.
 """
 from __future__ import annotations
 
@@ -138,3 +144,179 @@ def demix_sharded(separate_chunk: Callable[[Tensor], Tensor], tracks: Sequence[T
                 it = queues[r][k]
                 out[it.track][..., it.start:it.start + it.length] = recv[4 * r:4 * r + 4, ..., :it.length]
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: a set of tracks as one chunk batch over the ranks, stems all-gathered
+# --------------------------------------------------------------------------------------------------
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_gather_stems(recv: Tensor, send: Tensor, group=None, async_op: bool = True):
+    """``dist.all_gather_into_tensor`` (RCCL over xGMI with the ``nccl`` backend: device buffers, asynchronous on
+    the backend's stream).  With the ``gloo`` backend -- CPU tests, and two ranks sharing the one GPU of a test
+    box, which RCCL refuses -- device tensors are staged through the host (functional path only)."""
+    if send.device.type == "cuda" and dist.get_backend(group) == "gloo":
+        h_send = send.cpu()
+        h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv, h_send, group=group)
+        recv.copy_(h_recv)
+        return _Done()
+    return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+
+
+@dataclass(frozen=True)
+class PlacedItem:
+    item: WorkItem
+    offset: int          # float offset of the item's packed stems (4, nb, 2, length) in its rank's round buffer
+
+
+class ShardPlan:
+    """Deterministic schedule, identical on every rank: LPT assignment of the (track, chunk) items, each
+    rank's queue cut into rounds of ``stack`` items (longest first, so the full-size chunks of a round form
+    one stacked pass and the short tails come last), and per round the packed send layout.
+
+    Round k of rank r packs its items back to back as (4, nb, 2, length_i) row blocks; the round's buffer
+    width is the largest packed size over the ranks (ranks with less send padding that nobody reads)."""
+
+    def __init__(self, track_lengths: Sequence[int], chunk_size: int, world_size: int, nb_samples: int = 1,
+                 stack: int = 4):
+        self.lengths = [int(n) for n in track_lengths]
+        self.chunk_size, self.world, self.nb, self.stack = int(chunk_size), int(world_size), int(nb_samples), int(stack)
+        self.queues = assign_lpt(chunk_items(self.lengths, self.chunk_size), self.world)
+        nrounds = max((len(q) + self.stack - 1) // self.stack for q in self.queues) if self.queues else 0
+        self.rounds: List[List[List[PlacedItem]]] = []      # [round][rank] -> placed items
+        self.width: List[int] = []                          # floats per rank in round k
+        for k in range(nrounds):
+            per_rank, width = [], 0
+            for q in self.queues:
+                off, placed = 0, []
+                for it in q[k * self.stack:(k + 1) * self.stack]:
+                    placed.append(PlacedItem(it, off))
+                    off += 8 * self.nb * it.length
+                per_rank.append(placed)
+                width = max(width, off)
+            self.rounds.append(per_rank)
+            self.width.append((width + 63) // 64 * 64)      # 256-byte granules
+        self.audio_seconds = sum(self.lengths)
+
+    def passes(self, k: int, rank: int) -> List[List[PlacedItem]]:
+        """Items of round k on ``rank`` grouped into passes: equal-length items share a stacked pass."""
+        groups: Dict[int, List[PlacedItem]] = {}
+        for p in self.rounds[k][rank]:
+            groups.setdefault(p.item.length, []).append(p)
+        return [groups[n] for n in sorted(groups, reverse=True)]
+
+    def imbalance(self) -> float:
+        """max rank load / mean rank load (1.0 = perfectly balanced)."""
+        loads = [sum(i.length for i in q) for q in self.queues]
+        return max(loads) * len(loads) / max(1, sum(loads))
+
+
+class ShardedDemixer:
+    """Demixes a fixed set of tracks as one chunk batch over the process group.
+
+    ``separator``: a ``Separator`` (``demix_into`` is the compute step).  ``get_chunk(item)`` returns the
+    (nb_samples, 2, item.length) audio of a work item, resident on this rank's device (a rank only ever asks
+    for its own items).  All buffers (send / receive rounds, the per-track result tensors) are allocated once;
+    ``run()`` may be called repeatedly (the bench's steps) and returns {track: (4, nb_samples, 2, N_t)}.
+
+    gather=True  : every rank ends up holding every track (RCCL all-gather of the stems, then placement).
+    gather=False : the kernels write this rank's items straight into the result tensors; chunks computed by
+                   other ranks stay zero (no data-path collective)."""
+
+    def __init__(self, separator, track_lengths: Sequence[int], get_chunk: Callable[[WorkItem], Tensor],
+                 device: torch.device, group: Optional[dist.ProcessGroup] = None, gather: bool = True,
+                 nb_samples: int = 1, stack: int = 4, only_rank: Optional[int] = None):
+        self.sep, self.get_chunk, self.dev, self.group, self.gather = separator, get_chunk, torch.device(device), group, gather
+        live = dist.is_initialized() and only_rank is None
+        self.world = dist.get_world_size(group) if live else 1
+        self.rank = dist.get_rank(group) if live else 0
+        self.plan = ShardPlan(track_lengths, separator.chunk_size, self.world, nb_samples, stack)
+        if self.world == 1:
+            self.gather = False
+        nb, dt = self.plan.nb, torch.float32
+        lens = self.plan.lengths
+        # one flat allocation for all tracks: the kernels address it through element offsets
+        self.track_off = [0]
+        for n in lens:
+            self.track_off.append(self.track_off[-1] + 8 * nb * n)
+        self.flat = torch.zeros(self.track_off[-1], dtype=dt, device=self.dev)
+        self.out = {t: self.flat[self.track_off[t]:self.track_off[t + 1]].view(4, nb, 2, lens[t]) for t in range(len(lens))}
+        if self.gather:
+            self.send = [torch.zeros(w, dtype=dt, device=self.dev) for w in self.plan.width]
+            self.recv = [torch.empty(self.world * w, dtype=dt, device=self.dev) for w in self.plan.width]
+        self._offs = {}       # (round, pass) -> (audio builder inputs, row-offset tensor)
+        self._place_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+
+    # element offsets of packed channel (target, item*nb + b, c) for one pass
+    def _row_offsets(self, k: int, pi: int, placed: Sequence[PlacedItem]) -> Tensor:
+        key = (k, pi)
+        t = self._offs.get(key)
+        if t is None:
+            nb = self.plan.nb
+            rows = torch.empty(4, len(placed) * nb, 2, dtype=torch.int64)
+            for i, p in enumerate(placed):
+                it = p.item
+                for tg in range(4):
+                    for b in range(nb):
+                        for c in range(2):
+                            r = (tg * nb + b) * 2 + c
+                            if self.gather:       # packed (4, nb, 2, length) block of the round buffer
+                                rows[tg, i * nb + b, c] = p.offset + r * it.length
+                            else:                 # final position inside the track's (4, nb, 2, N_t)
+                                rows[tg, i * nb + b, c] = self.track_off[it.track] + r * self.plan.lengths[it.track] + it.start
+            t = self._offs[key] = rows.to(self.dev)
+        return t
+
+    def _compute_round(self, k: int):
+        target = self.send[k] if self.gather else self.flat
+        for pi, placed in enumerate(self.plan.passes(k, self.rank)):
+            audio = [self.get_chunk(p.item) for p in placed]
+            audio = audio[0] if len(audio) == 1 else torch.cat(audio, dim=0)
+            self.sep.demix_into(audio, target, self._row_offsets(k, pi, placed), group=self.plan.nb)
+
+    def _place_round(self, k: int):
+        """recv[k] (rank-major packed blocks) -> the per-track tensors: the hard concat by placement."""
+        nb, w = self.plan.nb, self.plan.width[k]
+        for r in range(self.world):
+            for p in self.plan.rounds[k][r]:
+                it = p.item
+                src = self.recv[k][r * w + p.offset: r * w + p.offset + 8 * nb * it.length].view(4, nb, 2, it.length)
+                self.out[it.track][..., it.start:it.start + it.length].copy_(src)
+
+    @torch.no_grad()
+    def run(self) -> Dict[int, Tensor]:
+        nrounds = len(self.plan.rounds)
+        if not self.gather:
+            for k in range(nrounds):
+                self._compute_round(k)
+            return self.out
+        cuda = self.dev.type == "cuda"
+        main = torch.cuda.current_stream(self.dev) if cuda else None
+        pending = []
+        for k in range(nrounds):
+            self._compute_round(k)
+            # async: the collective waits for this round's kernels on the backend's own stream and runs beside
+            # the next round's kernels; the placement of the round before is queued behind its collective on a
+            # side stream, so the host never blocks here with RCCL
+            work = all_gather_stems(self.recv[k], self.send[k], group=self.group, async_op=True)
+            pending.append((k, work))
+            if len(pending) > 1:
+                self._finish(*pending.pop(0))
+        while pending:
+            self._finish(*pending.pop(0))
+        if cuda:
+            main.wait_stream(self._place_stream)
+        return self.out
+
+    def _finish(self, k: int, work):
+        if self._place_stream is None:
+            work.wait()
+            self._place_round(k)
+            return
+        with torch.cuda.stream(self._place_stream):
+            work.wait()              # NCCL/RCCL: a stream-level wait of the place stream on the collective
+            self._place_round(k)

@@ -119,12 +119,50 @@ class Trainer:
         return OrderedDict((k, v) for k, v in self._read(1).items()
                            if not k.endswith(("running_mean", "running_var")))
 
+    def _write(self, what: int, tensors: Dict[str, Tensor]):
+        buf = np.empty(self.nparams, dtype=np.float32)
+        o = 0
+        for k, shp in self._spec:
+            n = int(np.prod(shp)) if shp else 1
+            v = tensors[k]
+            if tuple(v.shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(v.shape)} does not match {tuple(shp)}")
+            buf[o:o + n] = v.detach().to("cpu", torch.float32).reshape(-1).numpy()
+            o += n
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.xsq_train_write(self._h, what, buf.ctypes.data), "xsq_train_write")
+
+    def optimizer_state_dict(self) -> dict:
+        """What ``optimizer.state_dict()`` holds in the reference's checkpoints (training.py:419-430): the AdamW
+        step counter and both moments, keyed like the parameters (running statistics carry zeros)."""
+        step = int(_lib.lib.xsq_train_step_count(self._h, -1))
+        return {"step": step, "exp_avg": self._read(2), "exp_avg_sq": self._read(3),
+                "lr": self.lr, "weight_decay": self.weight_decay}
+
+    def load_optimizer_state_dict(self, state: dict):
+        """Resume: restores the moments and the step counter, so bias correction continues where it stopped."""
+        self._write(2, state["exp_avg"])
+        self._write(3, state["exp_avg_sq"])
+        _lib.lib.xsq_train_step_count(self._h, int(state["step"]))
+        self.steps = int(state["step"])
+        self._synced = self.steps
+        self.lr = float(state.get("lr", self.lr))
+        self.weight_decay = float(state.get("weight_decay", self.weight_decay))
+
+    def load_state_dict(self, sd: Dict[str, Tensor]):
+        """Parameters + running statistics from a (reference-layout) state_dict."""
+        self._write(0, sd)
+
     def sync_to(self, unmix: Unmix) -> Unmix:
+        """Hands the trained tensors to ``unmix``; ``num_batches_tracked`` advances by the steps taken SINCE
+        THE LAST sync (calling this once per epoch must not count earlier epochs again)."""
         sd = unmix.state_dict()
         for k, v in self.state_dict().items():
             sd[k] = v
+        fresh = self.steps - getattr(self, "_synced", 0)
         for k in sd:
             if k.endswith("num_batches_tracked"):
-                sd[k] = sd[k] + self.steps
+                sd[k] = sd[k] + fresh
         unmix.load_state_dict(sd, strict=True)
+        self._synced = self.steps
         return unmix

@@ -98,6 +98,21 @@ class SliCQEngine:
         except Exception:
             pass
 
+    def __deepcopy__(self, memo):
+        """The device plan handles and workspaces stay with the original (a copied raw handle would be
+        destroyed twice); the copy creates its own on first use."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k in ("_handles", "_ws") else copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_handles"], st["_ws"] = {}, {}
+        return st
+
     # -- transforms --------------------------------------------------------------
     def forward(self, x: Tensor):
         """x (*lead, n) fp32 on a ROCm device -> (arena, lead, S)."""
