@@ -120,24 +120,24 @@ _PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2O
               "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
               "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4<inverse>"],
               "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
-              "slice_irfft_ola": ["k_slice_irfft_ola"],
+              "slice_irfft_ola": ["k_slice_irfft"],
               "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"],
               "wiener_stats": ["k_wiener_stats"], "wiener_apply": ["k_wiener_apply"]}
 
 
 def pmc_traffic(kernel, tag=None):
-    """HBM bytes per STEP of `kernel` (all its launches of one 240 s track) from the committed rocprofv3 PMC
-    passes of this same command (tools/collect_profiles.sh -> tools/summarize_profiles.py; FETCH_SIZE doubled
-    for gfx950 as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is; both are KB per dispatch, averaged over
-    the launches of a step) and the launch count it was averaged over.  None when no profile of the current
-    kernels is committed."""
+    """(HBM bytes per STEP of `kernel` -- all its launches of one 240 s track --, launches per step) from the
+    committed rocprofv3 PMC passes of this same command (tools/collect_profiles.sh -> tools/summarize_profiles.py;
+    FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes, WRITE_SIZE as is; both are KB per dispatch
+    averaged over the profiled launches; the profiled run holds `steps_profiled` steps).  None when no profile
+    of the current kernels is committed."""
     import csv
     import glob
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv"))
                    if (tag is None) == ("wiener" not in os.path.basename(f)))
     if not files or kernel not in _PMC_NAMES:
         return None
-    total, launches = 0.0, 0
+    total, launches, steps = 0.0, 0, 2
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
             if row["Kernel"] in _PMC_NAMES[kernel]:
@@ -145,9 +145,10 @@ def pmc_traffic(kernel, tag=None):
                     n = int(float(row["launches"]))
                     total += n * (2.0 * float(row["fetch_KB_mean_raw"]) + float(row["write_KB_mean_raw"])) * 1024
                     launches += n
+                    steps = int(float(row.get("steps_profiled") or 2))     # tools/collect_profiles.sh: --steps 1 --warmup 1
                 except (KeyError, ValueError):
                     return None
-    return (int(total), launches) if launches else None
+    return (int(total / steps), launches / steps) if launches else None
 
 
 def cpu_baseline(threads):

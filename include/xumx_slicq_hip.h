@@ -70,6 +70,12 @@ int xsq_plan_set_fft_backend(xsq_plan* plan, int backend);
  * frequency stage fused into the operand staging, 4x fewer MFMA flops); 0 = all bands on the
  * dense grouped GEMM.                                                                      */
 int xsq_plan_set_band_radix4(xsq_plan* plan, int on);
+/* inverse transform, bands with Lg < 64 (167 of the 263 Bark-262 bands): 0 (default) = on the dense grouped GEMM;
+ * 1 = synthesised inside the inverse slice-FFT kernel straight from the coefficients (radix-4 stage + 4..15-point
+ * codelets, no Z round trip, no dense DFT-matrix GEMM) -- an experiment that measured 0.03-0.05 ms SLOWER per 240 s
+ * track (the kernel is bound by its chain of memory / LDS round trips) and is kept as an A/B switch.  Ignored
+ * when the plan is not eligible (rocFFT backend, other band lengths).                                       */
+int xsq_plan_set_short_inline(xsq_plan* plan, int on);
 /* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
 int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);
 /* complex coefficients per channel-slice (sum_b F_b*T_b) */

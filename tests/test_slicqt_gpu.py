@@ -144,3 +144,38 @@ def test_radix4_band_kernel_matches_dense_gemm(fb, oracle_plan):
     finally:
         eng.set_fft_backend(0)
     assert float((y_roc - y_dense).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("n,lead", [(70000, (1, 2)), (9031, (4, 1, 2)), (30000, (2, 2))])
+def test_short_bands_in_kernel_equal_the_dense_gemm_path(fb, n, lead):
+    """Inverse transform A/B: bands with Lg < 64 synthesised inside the slice-FFT kernel (radix-4 stage + 4..15-point
+    codelets; an opt-in experiment) against the dense DFT-matrix GEMM with its workspace round trip (default);
+    even/odd slice counts, odd and even output row offsets (the fused overlap-add takes 8-byte stores only on
+    aligned rows)."""
+    base, enc, dec = fb
+    eng = base.nsgt
+    x = synth_audio(n, seed=77 + n, nb_samples=int(np.prod(lead)) // 2).cuda().view(*lead, n)
+    rng = torch.Generator(device="cuda").manual_seed(n)
+    P = [c + 0.1 * torch.randn(c.shape, generator=rng, device="cuda") for c in enc(x)]
+    try:
+        eng.set_short_inline(False)
+        ref = dec(P, n).clone()
+        eng.set_short_inline(True)
+        got = dec(P, n).clone()
+        # odd length and an odd row offset: the 4-byte path of the fused overlap-add
+        ref_o = dec(P, n - 1).clone()
+        arena, ld, S = eng.table.as_arena(list(P))
+        BC = int(np.prod(ld))
+        out = torch.full((BC * (n + 3) + 1,), float("nan"), device="cuda")
+        offs = (torch.arange(BC, device="cuda") * (n + 3) + 1).to(torch.int64)
+        eng.backward(arena, BC, S, n - 1, out=out, row_offsets=offs)
+    finally:
+        eng.set_short_inline(False)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (*lead, n)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-6 * max(1.0, scale), float((got - ref).abs().max())
+    placed = torch.stack([out[1 + r * (n + 3): 1 + r * (n + 3) + n - 1] for r in range(BC)]).view(*lead, n - 1)
+    assert torch.equal(placed, ref_o)
+    # nothing outside the rows was touched
+    assert bool(torch.isnan(out[0])) and bool(torch.isnan(out[1 + n - 1: 1 + n + 3]).all())

@@ -3,10 +3,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/xumx_slicq_amd/csrc
 for v in ${VARIANTS:-0 1 2 4 6 8 14 15}; do
-  for f in slicqt cdae wiener prof loss train; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DXSQ_ABLATE=$v -c $f.hip -o /tmp/ab_$f.o 2>/dev/null
-  done
-  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 /tmp/ab_slicqt.o /tmp/ab_cdae.o /tmp/ab_wiener.o /tmp/ab_prof.o /tmp/ab_loss.o /tmp/ab_train.o -o /tmp/libab_$v.so -L/opt/rocm/lib -lrocfft
+  # same flags as the product library (csrc/Makefile), plus the ablation switch; objects outside the tree
+  make -s -j4 OBJDIR=/tmp/ab_$v OUT=/tmp/libab_$v.so EXTRA=-DXSQ_ABLATE=$v 2>/dev/null
   echo "== ablate=$v"
   XSQ_LIB=/tmp/libab_$v.so python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/tmp/ab_err.txt > /tmp/ab_out.json || tail -5 /tmp/ab_err.txt
   python3 -c "

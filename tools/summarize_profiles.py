@@ -62,6 +62,7 @@ for name, corr in (("fetch", 2.0), ("write", 1.0)):
     g[f"{name}_MB_largest_launch"] = g[f"{name}_KB_max_raw"] * corr / 1024.0
     rows.append(g)
 t = rows[0].join(rows[1], lsuffix="", rsuffix="_w")
+t["steps_profiled"] = int(os.environ.get("XSQ_PROFILED_STEPS", "2"))     # collect_profiles.sh: --steps 1 --warmup 1
 t.round(3).to_csv(f"{dst}/{tag}_hbm_traffic.csv")
 for f in ("trace_bench.json", "pmc_sq_bench.json"):
     try:

@@ -773,6 +773,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     //   1 bf16x3 generic engine with 256-row tiles      2 ... with 32-value K-steps      4 no slab kernels at all
     //   8 no slab kernels on the fp32 path              64 fp32 slab kernels padded to 64 columns (MODE 0)
     //   128 generic fp32 engine padded to 64 columns    256 layer 4 with 32/64-column tiles only
+    //   512 fp32 slab kernels request the next slab a whole df ahead (28 VGPRs held across the MFMA slots, spilled: r01)
     static const int variant = getenv("XSQ_CDAE_VARIANT") ? atoi(getenv("XSQ_CDAE_VARIANT")) : 0;
     const int mt23 = bf3 && (variant & 1) ? 2 : L23_MT;
     const bool xw = !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && layer <= 3 && !(variant & 128);   // fp32 inference: no column padding
@@ -784,8 +785,11 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);      // its own event name: one kernel, one name
 #define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
         const bool exw = !(variant & 64);      // fp32: exact-width columns (MODE 3) unless switched back to MODE 0
-        if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else if (exw) XSQ_SLAB(false, 3); else XSQ_SLAB(false, 0); }
-        else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
+#define XSQ_SLAB_LATE(TR_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, 3, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
+        const bool late = !(variant & 512);      // fp32 exact-width kernel: next slab fetched in its own slot (no registers held across the MFMA slots: no scratch)
+        if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else if (exw && late) XSQ_SLAB_LATE(false); else if (exw) XSQ_SLAB(false, 3); else XSQ_SLAB(false, 0); }
+        else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw && late) XSQ_SLAB_LATE(true); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
+#undef XSQ_SLAB_LATE
 #undef XSQ_SLAB
         return XSQ_OK;
     }

@@ -48,7 +48,12 @@ constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored cha
 //              tools/probe/mfma4x4.hip -- but measured ~7x slower than the whole rest of the kernel.)
 // MODE 2 (bf16x6): plain fp32 operands, fp32 slab plane; the A fragment is cut into its three bf16 pieces when
 //              it is read (gemm_tile_bf6.h), the B tile holds the three pieces of the weights; six bf16 MFMAs
-template <bool TRANSPOSED, int MODE>
+// LATE: the next df's slab is fetched in the slot that writes it (slot 7, no MFMAs: two load -> store halves whose
+//       registers are dead fragment registers) instead of being requested a whole df ahead and held in 28 VGPRs
+//       across the MFMA slots -- under the 128-VGPR cap of two workgroups per CU those registers were spilled
+//       (96-104 B of scratch per lane, 2.4 GB of HBM traffic per launch against 1.0 GB of activations, r01).  The
+//       round trip is exposed to this workgroup only; the other three waves of the SIMD keep the matrix pipe busy.
+template <bool TRANSPOSED, int MODE, bool LATE = false>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
     constexpr bool BF3 = MODE == 1, BF6 = MODE == 2, EXW = MODE == 3;
     constexpr bool F32T = MODE == 0 || MODE == 3;                // fp32 B tile / fp32 slab plane
@@ -101,10 +106,10 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     constexpr int NLD = (SLAB_POS * (CS / 4) + 511) / 512;           // float4 loads per thread and slab (7)
     float4 sa[NLD];
 
-    auto load_slab = [&](int df) {
+    auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
         const int total = (nrows + 3 * SLAB_MAXSEG) * (CS / 4);
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
+        for (int q = q0; q < q1; ++q) {
             const int e = tid + 512 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < total) {
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
             sa[q] = v;
         }
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](int q0 = 0, int q1 = NLD) {
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
+        for (int q = q0; q < q1; ++q) {
             const int e = tid + 512 * q;
             if (!BF3) {
                 if (e < SLAB_POS * (CS / 4)) *reinterpret_cast<float4*>(&slabF[4 * e]) = sa[q];
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     store_b(0, 0);
     load_b(1, 0, 1);
     load_b(0, 0, 2);
-    if (kf > 1) load_slab(1);
+    if (kf > 1 && !LATE) load_slab(1);
     __syncthreads();
     for (int df = 0; df < kf; ++df) {
         const bool more = df + 1 < kf;
@@ -298,9 +303,14 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                         }
                     }
                 }
-            } else if (more) {
-                store_slab();                  // slot 7: every wave has passed the barrier behind the slab's last reader
-                if (df + 2 < kf) load_slab(df + 2);
+            } else if (more) {                 // slot 7: every wave has passed the barrier behind the slab's last reader
+                if constexpr (LATE) {
+                    load_slab(df + 1, 0, 4); store_slab(0, 4);
+                    load_slab(df + 1, 4, NLD); store_slab(4, NLD);
+                } else {
+                    store_slab();
+                    if (df + 2 < kf) load_slab(df + 2);
+                }
             }
             // K-step of slot s1 = ks + 1 -> tile s1 & 1 (read last in slot ks - 1); its register set is then refilled
             // with the K-step of slot s3 = ks + 3

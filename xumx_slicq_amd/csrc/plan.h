@@ -45,6 +45,14 @@ struct xsq_plan {
     float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)
     int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap
     int phase_begin[5] = {0, 0, 0, 0, 0};
+    // short bands (Lg < 64) synthesised inside k_slice_irfft (slice_fft.h: ShortSched); valid when short_n1 > 0
+    int short_inline = 0;           // 0 (default, faster as measured): short bands on the dense GEMM + Z round trip (band_synthesis_gemm)
+    void *d_s_item1 = nullptr, *d_s_tw1 = nullptr;
+    int *d_s_item2 = nullptr, *d_s_tgt = nullptr;
+    float* d_s_wd = nullptr;
+    int short_n1 = 0, short_n2 = 0, short_nent = 0, short_sc0 = 0;
+    int short_begin[5] = {0, 0, 0, 0, 0};
+    int phase_long[4] = {0, 0, 0, 0};   // first entry of each gather phase that belongs to a band NOT handled in-kernel
     float* d_tw = nullptr;          // (L) slice window
     float* d_Wf = nullptr;          // per-band analysis matrices  (window, sign, 1/Lg folded in)
     float* d_Wi = nullptr;          // per-band synthesis matrices (dual window, Lg, sign, 1/L folded in)

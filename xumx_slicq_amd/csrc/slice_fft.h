@@ -46,10 +46,16 @@ __device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {   // a * conj(b)
 }
 
 // X[k] = sum_n x[n] exp(SIGN * 2 pi i n k / R), results handed to emit(k, X[k]) as they are produced.
-template <int R, int SIGN, class Emit>
+// PARTS = 2 splits the OUTPUTS between two callers that hold the same inputs (two wave groups of a 512-thread
+// workgroup): PART 0 emits k = 0 and the pairs k = 1 .. KSPLIT, PART 1 the pairs KSPLIT + 1 .. H (odd R only).
+template <int R, int SIGN, int PART = 0, int PARTS = 1, class Emit>
 __device__ __forceinline__ void dft_small(const float2 (&x)[R], Emit&& emit) {
     constexpr int H = (R - 1) / 2;
     constexpr bool EVEN = (R % 2) == 0;
+    static_assert(PARTS == 1 || !EVEN, "split outputs: odd radix only");
+    constexpr int KSPLIT = (H + 1) / 2;
+    constexpr int K_LO = PARTS == 1 ? 1 : (PART == 0 ? 1 : KSPLIT + 1);
+    constexpr int K_HI = PARTS == 1 ? H : (PART == 0 ? KSPLIT : H);
     float2 a[H], b[H];
     float2 s0 = x[0];
     static_for<1, H + 1>([&](auto nc) {
@@ -59,8 +65,8 @@ __device__ __forceinline__ void dft_small(const float2 (&x)[R], Emit&& emit) {
         s0 = c_add(s0, a[n - 1]);
     });
     if constexpr (EVEN) s0 = c_add(s0, x[R / 2]);
-    emit(0, s0);
-    static_for<1, H + 1>([&](auto kc) {
+    if constexpr (PART == 0) emit(0, s0);
+    static_for<K_LO, K_HI + 1>([&](auto kc) {
         constexpr int k = kc;
         float2 P = x[0];
         if constexpr (EVEN) P = (k & 1) ? c_sub(P, x[R / 2]) : c_add(P, x[R / 2]);
@@ -113,18 +119,52 @@ struct FftTables {
 struct GatherSched {
     const int* tgt;        // (sumLg) target bin of each entry, -1 when outside [0, N]
     int begin[5];          // entry range of phase p is [begin[p], begin[p+1])
+    int lo[4];             // first entry of phase p that is gathered from Z (= begin[p] unless the short bands run in-kernel)
     int row_len;           // entries per row (sum of band lengths)
 };
+
+// Short bands (Lg = 4m < 64) synthesised INSIDE k_slice_irfft, straight from the coefficient arena (or from
+// mask * mix): for them the dense DFT-matrix GEMM (band_synthesis_gemm) moved 8 Lg^2 flops and a Z round trip per
+// band and row for what is a 16..60-point FFT.  Here: one radix-4 decimation-in-frequency stage while the
+// coefficients are loaded (one lane per (band, t1): the four quarters x[t1 + a m] are contiguous runs), the four
+// m-point DFTs per band from compile-time-twiddle codelets (dft_small<4..15>, one lane per (band, residue), in
+// place in an LDS scratch area), and a 4-phase accumulation into the spectrum bins (bands of one phase are
+// disjoint: plain read-modify-write, fixed order, bitwise reproducible) with the dual window applied on the way.
+struct ShortItem1 {        // one (band, t1) butterfly
+    int cum, F, f, Lg, t1, sc;    // block offset (complex per channel-slice), block rows, row, band length, t1, scratch offset of the band
+};
+struct ShortSched {
+    const ShortItem1* item1;   // n1 butterflies, band-major
+    const float2* tw1;         // 3 per butterfly: w^(r t1), r = 1..3, w = exp(-2 pi i / Lg)
+    const int* item2;          // n2 m-point DFTs sorted by m: (scratch offset of (band, r)) << 4 | m
+    const int* stgt;           // nent: spectrum bin of scratch entry e (phase-major), -1 outside [0, N]
+    const float* swd;          // nent: dual window * Lg * sign / L of that entry
+    int n1, n2, nent, sc0;     // sc0: first spectrum slot used as scratch (above every short band's bins)
+    int begin[5];              // scratch entry range of phase p
+};
+struct ShortIn {           // per call
+    const float* coef;     // coefficient arena (BC channels), or the mix arena (BCx channels) when mask != nullptr
+    const float* mask;     // optional real mask arena (BC channels)
+    int BC, BCx;
+};
+
+template <int R>
+__device__ __forceinline__ void short_dft(float2* base) {      // in place: X[k] = sum_n x[n] exp(-2 pi i n k / R)
+    float2 v[R];
+#pragma unroll
+    for (int n = 0; n < R; ++n) v[n] = base[n];
+    dft_small<R, -1>(v, [&](int k, float2 X) { base[k] = X; });
+}
 
 // Steps 2 and 3 of the complex FFT, in place on Z.  The step-1 twiddles W_N^(m*k1) are applied
 // here on the load side, where the 14 table reads of a butterfly are independent loads issued
 // together (inside step 1 each one sat behind a 43-point butterfly).  w2s = step-2 twiddles in LDS.
 // SIGN = +1 uses the conjugate twiddles.
-template <int SIGN>
+template <int SIGN, int NT>
 __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restrict__ w1, const float2* w2s, int tid) {
-    // 645 butterflies over 256 threads = 3 rounds; the 14 step-1 twiddles of round i + 1 are requested before
+    // 645 butterflies over NT threads = 3 (2) rounds; the 14 step-1 twiddles of round i + 1 are requested before
     // round i computes (they come from L2: one exposed round trip per round otherwise)
-    constexpr int NB = FFT_R1 * FFT_R3, ROUNDS = (NB + 255) / 256;
+    constexpr int NB = FFT_R1 * FFT_R3, ROUNDS = (NB + NT - 1) / NT;
     float2 w[2][FFT_R2];
     auto load_w = [&](int set, int bf) {
         const int bfc = bf < NB ? bf : NB - 1;
@@ -136,8 +176,8 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
     load_w(0, tid);
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int bf = tid + 256 * r;
-        if (r + 1 < ROUNDS) load_w((r + 1) & 1, bf + 256);
+        const int bf = tid + NT * r;
+        if (r + 1 < ROUNDS) load_w((r + 1) & 1, bf + NT);
         if (bf < NB) {
             const int k1 = bf / FFT_R3, n3 = bf - k1 * FFT_R3;
             float2* base = Z + k1 * FFT_M1 + n3;
@@ -153,7 +193,7 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
         }
     }
     __syncthreads();
-    for (int bf = tid; bf < FFT_R1 * FFT_R2; bf += 256) {
+    for (int bf = tid; bf < FFT_R1 * FFT_R2; bf += NT) {
         float2* base = Z + bf * FFT_R3;
         float2 v[FFT_R3];
 #pragma unroll
@@ -164,9 +204,15 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
 }
 
 // ---- forward: U[row, 0..N] = rfft_L( tw * xpad[(2s-2)h : (2s+2)h] ) --------------------------------
-__global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
-                                                     const FftTables T, float2* __restrict__ U,
-                                                     int S, int64_t n, int h) {
+// NT = 256: one lane per 43-point butterfly (210 of 256 lanes), 2 workgroups of 4 waves per CU.
+// NT = 512: the OUTPUTS of every 43-point butterfly are split between wave group 0 (lanes 0..255) and wave group 1
+//           (lanes 256..511), both holding the column's 43 inputs: the longest serial stage of the transform is
+//           halved, steps 2 / 3 take 2 rounds instead of 3, and a CU holds 16 waves instead of 8 -- the kernel is
+//           bound by dependent LDS / memory round trips, not by issue slots (27 % VALU utilisation measured).
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
+                                                              const FftTables T, float2* __restrict__ U,
+                                                              int S, int64_t n, int h) {
     __shared__ float2 Z[FFT_N];
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
@@ -175,8 +221,8 @@ __global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x,
     const float* xr = x + (int64_t)bc * n;
     if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
     const int64_t i0 = (int64_t)(2 * s - 2) * h;
-    if (tid < FFT_M1) {
-        const int m = tid;
+    const int part = tid >> 8, m = tid & 255;            // wave-uniform part
+    if (m < FFT_M1) {
         float2 v[FFT_R1];
         // Straight-line loads: with a predicate around every sample the compiler emitted 86 load -> wait
         // round trips in sequence (57 us per row, measured); here every load is unconditional and the 129 of a
@@ -203,23 +249,26 @@ __global__ __launch_bounds__(256) void k_slice_rfft(const float* __restrict__ x,
                 v[n1].y = (i + 1 >= 0 && i + 1 < n) ? w.y * xb : 0.f;
             }
         }
-        dft_small<FFT_R1, -1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+        auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
+        if constexpr (NT == 256) dft_small<FFT_R1, -1>(v, put);
+        else if (part == 0) dft_small<FFT_R1, -1, 0, 2>(v, put);
+        else dft_small<FFT_R1, -1, 1, 2>(v, put);
     }
     __syncthreads();
-    fft_steps_2_3<-1>(Z, T.w1, w2s, tid);
+    fft_steps_2_3<-1, NT>(Z, T.w1, w2s, tid);
     // real post-processing: U[k] = E + G, U[N-k] = conj(E - G), E = (Z[k] + conj Z[N-k])/2,
     // G = -i/2 * W_L^k * (Z[k] - conj Z[N-k])
     float2* Ur = U + (int64_t)row * (FFT_N + 1);
-    // the 18 W_L^k of this lane are requested together, ahead of the loop: a table load inside the loop body
+    // the W_L^k of this lane are requested together, ahead of the loop: a table load inside the loop body
     // (waited for in every iteration, and on this target a wait for a load also waits for the stores issued
     // before it) made the loop one memory round trip per iteration
-    constexpr int NPP = (FFT_N / 2 + 256) / 256;           // 18 iterations cover k = 0 .. N/2
+    constexpr int NPP = (FFT_N / 2 + NT) / NT;             // iterations that cover k = 0 .. N/2
     float2 wlr[NPP];
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) { const int k = tid + 256 * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
+    for (int i = 0; i < NPP; ++i) { const int k = tid + NT * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-        const int k = tid + 256 * i;
+        const int k = tid + NT * i;
         if (k > FFT_N / 2) break;
         const float2 zk = Z[fft_pos(k)];
         const float2 zn = Z[fft_pos(k == 0 ? 0 : FFT_N - k)];
@@ -248,8 +297,11 @@ struct OlaArgs {
     int64_t length;
 };
 
-__global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
-                                                      const FftTables T, const OlaArgs O) {
+
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
+                                                      const FftTables T, const OlaArgs O, const ShortSched SS,
+                                                      const ShortIn SI) {
     __shared__ float2 Z[FFT_N + 1];        // bins 0..N while gathering, then the complex sequence
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
@@ -257,54 +309,167 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
     const int bc = blockIdx.x / nsl, s = 2 * (blockIdx.x - bc * nsl) + O.parity;
     const int row = bc * O.S + s;
     if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
-    for (int k = tid; k <= FFT_N; k += 256) Z[k] = make_float2(0.f, 0.f);
-    __syncthreads();
-    // gather-sum of the band spectra, one phase of mutually disjoint bands at a time
+    // Gather registers of the long bands: two phases per memory round trip, all loads of a pair of phases issued
+    // (unconditionally: clamped entry index, validity kept in k) before any is consumed.
+    constexpr int UN = (4864 + NT - 1) / NT;     // covers a whole phase of the Bark-262 plan in one chunk
     const float2* zr = Zrow + (int64_t)row * G.row_len;
-    // Two phases per memory round trip: all loads of phases (0,1), then (2,3), are issued before any
-    // is consumed (they are independent -- ~19 entries per lane and phase); the accumulation itself
-    // stays phase by phase with a barrier in between, because neighbouring phases overlap in bins.
-    constexpr int UN = 19;                 // ceil(4864 / 256): covers a whole phase of the Bark-262 plan
+    float2 z[2][UN];
+    int k[2][UN];
+    auto gather_load = [&](int pp, int off) {
 #pragma unroll
-    for (int pp = 0; pp < ((XSQ_ABLATE & 16) ? 0 : 4); pp += 2) {
-        const int lo0 = G.begin[pp], hi0 = G.begin[pp + 1], hi1 = G.begin[pp + 2];
-        const int span = (hi0 - lo0) > (hi1 - hi0) ? (hi0 - lo0) : (hi1 - hi0);
-        for (int off = tid; off < span; off += 256 * UN) {
-            float2 z[2][UN];
-            int k[2][UN];
+        for (int h = 0; h < 2; ++h) {
+            const int e0 = G.lo[pp + h], e1 = G.begin[pp + h + 1];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e0 = h ? hi0 : lo0, e1 = h ? hi1 : hi0;
+            for (int u = 0; u < UN; ++u) {
+                const int ee = e0 + off + NT * u;
+                const int ec = ee < e1 ? ee : (e1 > e0 ? e1 - 1 : 0);
+                const int kk = G.tgt[ec];
+                k[h][u] = ee < e1 ? kk : -1;
+                z[h][u] = zr[ec];
+            }
+        }
+    };
+    auto gather_accum = [&]() {
 #pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int ee = e0 + off + 256 * u;
-                    k[h][u] = -1;
-                    z[h][u] = make_float2(0.f, 0.f);
-                    if (ee < e1) { k[h][u] = G.tgt[ee]; z[h][u] = zr[ee]; }
+        for (int h = 0; h < 2; ++h) {
+            // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
+            float2 acc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc[u] = Z[k[h][u] >= 0 ? k[h][u] : 0];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (k[h][u] >= 0) Z[k[h][u]] = make_float2(acc[u].x + z[h][u].x, acc[u].y + z[h][u].y);
+            __syncthreads();
+        }
+    };
+    const bool do_gather = !(XSQ_ABLATE & 16);
+    if (SS.n1 > 0) {
+        // ---- short bands in-kernel (see ShortSched) ------------------------------------------------------
+        constexpr int U1 = (1280 + NT - 1) / NT, U2 = (768 + NT - 1) / NT, UG = (1280 + NT - 1) / NT;   // 1280 butterflies, 768 small DFTs, 1280 entries per phase
+        float2* const scr = Z + SS.sc0;
+        const bool masked = SI.mask != nullptr;
+        const int64_t BCS = (int64_t)SI.BC * O.S, BCSx = (int64_t)SI.BCx * O.S;
+        const int bcx = masked ? bc % SI.BCx : bc;
+        const float2* const c2 = reinterpret_cast<const float2*>(SI.coef);
+        float2 xv[U1][4], tw[U1][3];
+        float mk[U1][4];
+        int sc1[U1], m1[U1];
+#pragma unroll
+        for (int u = 0; u < U1; ++u) {               // all loads first (unconditional, clamped item index)
+            const int i = tid + NT * u;
+            const int ii = i < SS.n1 ? i : SS.n1 - 1;
+            const ShortItem1 it = SS.item1[ii];
+            const int m = it.Lg >> 2;
+            sc1[u] = i < SS.n1 ? it.sc + it.t1 : -1;
+            m1[u] = m;
+            const int64_t xi = (masked ? BCSx : BCS) * it.cum + (((int64_t)bcx * it.F + it.f) * O.S + s) * it.Lg + it.t1;
+            const int64_t mi = BCS * it.cum + (((int64_t)bc * it.F + it.f) * O.S + s) * it.Lg + it.t1;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                xv[u][a] = c2[xi + a * m];
+                mk[u][a] = masked ? SI.mask[mi + a * m] : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tw[u][r] = SS.tw1[3 * ii + r];
+        }
+        // the long bands' first pair of phases travels in the same memory round trip as the short bands' inputs
+        if (do_gather) gather_load(0, tid);
+        // spectrum slots outside the scratch area start at zero (the scratch area is written in full below)
+        for (int k = tid; k <= FFT_N; k += NT)
+            if (k < SS.sc0 || k >= SS.sc0 + SS.nent) Z[k] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U1; ++u) {
+            if (sc1[u] < 0) continue;
+            float2 x[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) x[a] = masked ? make_float2(xv[u][a].x * mk[u][a], xv[u][a].y * mk[u][a]) : xv[u][a];
+            const float2 s0 = c_add(x[0], x[2]), s1 = c_add(x[1], x[3]);
+            const float2 d0 = c_sub(x[0], x[2]), d1 = c_sub(x[1], x[3]);
+            const float2 y1 = make_float2(d0.x + d1.y, d0.y - d1.x);      // d0 - i d1
+            const float2 y3 = make_float2(d0.x - d1.y, d0.y + d1.x);      // d0 + i d1
+            float2* o = scr + sc1[u];
+            o[0] = c_add(s0, s1);
+            o[m1[u]] = c_mul(y1, tw[u][0]);
+            o[2 * m1[u]] = c_mul(c_sub(s0, s1), tw[u][1]);
+            o[3 * m1[u]] = c_mul(y3, tw[u][2]);
+        }
+        // gather tables of the four phases, requested before the small DFTs run
+        int gk[4][UG];
+        float gw[4][UG];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int e = SS.begin[ph] + tid + NT * u;
+                const bool ok = e < SS.begin[ph + 1];
+                gk[ph][u] = ok ? SS.stgt[e] : -1;
+                gw[ph][u] = ok ? SS.swd[e] : 0.f;
+            }
+        int code2[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = tid + NT * u; code2[u] = i < SS.n2 ? SS.item2[i] : 0; }
+        __syncthreads();
+#pragma unroll 1                                   // one copy of the twelve codelets (instruction cache)
+        for (int u = 0; u < U2; ++u) {
+            float2* base = scr + (code2[u] >> 4);
+            switch (code2[u] & 15) {               // items are sorted by m: a wave sees one or two cases
+                case 4: short_dft<4>(base); break;
+                case 5: short_dft<5>(base); break;
+                case 6: short_dft<6>(base); break;
+                case 7: short_dft<7>(base); break;
+                case 8: short_dft<8>(base); break;
+                case 9: short_dft<9>(base); break;
+                case 10: short_dft<10>(base); break;
+                case 11: short_dft<11>(base); break;
+                case 12: short_dft<12>(base); break;
+                case 13: short_dft<13>(base); break;
+                case 14: short_dft<14>(base); break;
+                case 15: short_dft<15>(base); break;
+                default: break;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int e = SS.begin[ph] + tid + NT * u;
+                if (gk[ph][u] >= 0) {
+                    const float2 v = scr[e];
+                    float2 acc = Z[gk[ph][u]];
+                    acc.x += v.x * gw[ph][u];
+                    acc.y += v.y * gw[ph][u];
+                    Z[gk[ph][u]] = acc;
                 }
             }
+            __syncthreads();
+        }
+        for (int e = tid; e < SS.nent; e += NT) scr[e] = make_float2(0.f, 0.f);
+    } else {
+        if (do_gather) gather_load(0, tid);
+        for (int k = tid; k <= FFT_N; k += NT) Z[k] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // gather-sum of the band spectra, one phase of mutually disjoint bands at a time; the accumulation stays
+    // phase by phase with a barrier in between, because neighbouring phases overlap in bins
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
-                float2 acc[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) acc[u] = Z[k[h][u] >= 0 ? k[h][u] : 0];
-#pragma unroll
-                for (int u = 0; u < UN; ++u)
-                    if (k[h][u] >= 0) Z[k[h][u]] = make_float2(acc[u].x + z[h][u].x, acc[u].y + z[h][u].y);
-                __syncthreads();
-            }
+    for (int pp = 0; pp < (do_gather ? 4 : 0); pp += 2) {
+        const int s0 = G.begin[pp + 1] - G.lo[pp], s1 = G.begin[pp + 2] - G.lo[pp + 1];
+        const int span = s0 > s1 ? s0 : s1;             // workgroup-uniform
+        for (int off = 0; off < span; off += NT * UN) {
+            if (off > 0 || pp > 0) gather_load(pp, off + tid);      // (the first chunk of phases 0 / 1 is already in flight)
+            gather_accum();
         }
     }
     // real pre-processing in place: Zin[k] = E + i O, Zin[N-k] = conj(E) + i conj(O),
     // E = U[k] + conj U[N-k], O = (U[k] - conj U[N-k]) * conj(W_L^k)   (no 1/2: output = L * irfft)
-    constexpr int NPP = (FFT_N / 2 + 256) / 256;           // 18 iterations; table values requested together (see k_slice_rfft)
+    constexpr int NPP = (FFT_N / 2 + NT) / NT;             // table values requested together (see k_slice_rfft)
     float2 wlr[NPP];
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) { const int k = tid + 256 * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
+    for (int i = 0; i < NPP; ++i) { const int k = tid + NT * i; wlr[i] = T.wl[k <= FFT_N / 2 ? k : FFT_N / 2]; }
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-        const int k = tid + 256 * i;
+        const int k = tid + NT * i;
         if (k > FFT_N / 2) break;
         float2 uk = Z[k], un = Z[FFT_N - k];
         if (k == 0) { uk.y = 0.f; un.y = 0.f; }   // irfft ignores Im of DC / Nyquist (nsigtf.py:103)
@@ -315,15 +480,25 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
         if (k != 0) Z[FFT_N - k] = make_float2(E.x + O.y, O.x - E.y);
     }
     __syncthreads();
-    if (tid < FFT_M1 && !(XSQ_ABLATE & 32)) {
-        const int m = tid;
+    {   // 43-point butterflies, in place: every lane reads its column first; with NT = 512 the outputs are split between
+        // the two wave groups, which both hold the column (barrier between the reads and the writes of the pair)
+        const int part = tid >> 8, m = tid & 255;
+        const bool on = m < FFT_M1 && !(XSQ_ABLATE & 32);
         float2 v[FFT_R1];
+        if (on) {
 #pragma unroll
-        for (int n1 = 0; n1 < FFT_R1; ++n1) v[n1] = Z[n1 * FFT_M1 + m];
-        dft_small<FFT_R1, +1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+            for (int n1 = 0; n1 < FFT_R1; ++n1) v[n1] = Z[n1 * FFT_M1 + m];
+        }
+        if constexpr (NT != 256) __syncthreads();
+        if (on) {
+            auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
+            if constexpr (NT == 256) dft_small<FFT_R1, +1>(v, put);
+            else if (part == 0) dft_small<FFT_R1, +1, 0, 2>(v, put);
+            else dft_small<FFT_R1, +1, 1, 2>(v, put);
+        }
     }
     __syncthreads();
-    if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1>(Z, T.w1, w2s, tid);
+    if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1, NT>(Z, T.w1, w2s, tid);
     if (XSQ_ABLATE & 128) return;
     // samples 2nn, 2nn+1 of the segment = Re / Im of sequence element nn; output index i = (2s-2)h + 2nn
     float* const yr = O.y + (O.row_off ? O.row_off[bc] : (int64_t)bc * O.length);
@@ -331,7 +506,7 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
     // the second half of the last slice has no partner: plain store even in the adding launch
     const bool add_lo = O.parity != 0, add_hi = O.parity != 0 && s + 1 < O.S;
     const bool al8 = ((reinterpret_cast<uintptr_t>(yr + i0)) & 7) == 0;       // workgroup-uniform (h may be odd: i0 too)
-    constexpr int NIT = (FFT_N + 255) / 256;
+    constexpr int NIT = (FFT_N + NT - 1) / NT;
     if (al8 && i0 >= 0 && i0 + FFT_L <= O.length) {
         // interior slice, 8-byte aligned: all loads of the partner sums first, then all stores
         float2* const y2 = reinterpret_cast<float2*>(yr + i0);
@@ -339,13 +514,13 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
         if (O.parity) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int nn = tid + 256 * it;
+                const int nn = tid + NT * it;
                 prev[it] = (nn < FFT_N && (2 * nn < 2 * O.h ? add_lo : add_hi)) ? y2[nn] : make_float2(0.f, 0.f);
             }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int nn = tid + 256 * it;
+            const int nn = tid + NT * it;
             if (nn >= FFT_N) break;
             float2 v = Z[fft_pos(nn)];
             if (O.parity) { v.x += prev[it].x; v.y += prev[it].y; }
@@ -354,7 +529,7 @@ __global__ __launch_bounds__(256) void k_slice_irfft(const float2* __restrict__ 
         return;
     }
     // edge slices (first / last of a channel) and odd row offsets: per-sample bounds, 4-byte accesses
-    for (int nn = tid; nn < FFT_N; nn += 256) {
+    for (int nn = tid; nn < FFT_N; nn += NT) {
         const float2 v = Z[fft_pos(nn)];
         const bool add = 2 * nn < 2 * O.h ? add_lo : add_hi;     // 2h is even: both samples of nn lie in the same half
         const int64_t ia = i0 + 2 * nn, ib = ia + 1;

@@ -11,9 +11,11 @@
 //   fr[bc,s,k]    = sum over bands covering bin k of Z[bc,j,s,k-bin0_j]   k_spectrum_gather (HBM stream)
 //   seg[bc,s,:]   = L * irfft_L(fr[bc,s,:])  (unnormalised c2r; the 1/L sits in Wi)   rocFFT
 //   y[bc,i]       = seg[bc,s0,i-(2s0-2)h] + seg[bc,s0+1,i-2h*s0],  s0 = i/(2h)        k_overlap_add
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/xumx_slicq_hip.h"
@@ -335,6 +337,25 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
+#ifndef XSQ_FFT_NT_FWD
+#define XSQ_FFT_NT_FWD 256
+#endif
+#ifndef XSQ_FFT_NT_INV
+#define XSQ_FFT_NT_INV 512
+#endif
+
+// threads per row of the slice FFT kernels (slice_fft.h): XSQ_FFT_THREADS = "fwd,inv" of 256 / 512 overrides the
+// defaults (diagnostic A/B switch; same results bit for bit)
+static int fft_threads(int inverse) {
+    static int u[2] = {-1, -1};
+    if (u[0] < 0) {
+        int f = XSQ_FFT_NT_FWD, i = XSQ_FFT_NT_INV;
+        if (const char* e = getenv("XSQ_FFT_THREADS")) { if (sscanf(e, "%d,%d", &f, &i) < 2) i = f; }
+        u[0] = f == 512 ? 512 : 256; u[1] = i == 512 ? 512 : 256;
+    }
+    return u[inverse ? 1 : 0];
+}
+
 static inline bool lds_fft(const xsq_plan* P) { return P->fft_backend == 0 && P->L == FFT_L && P->d_tgt != nullptr; }
 static inline FftTables fft_tables(const xsq_plan* P) {
     return FftTables{P->d_T, P->d_T + FFT_R1 * FFT_M1, P->d_T + FFT_R1 * FFT_M1 + FFT_R2 * FFT_R3};
@@ -569,6 +590,94 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
     }
     XSQ_HIP(hipMalloc(&P->d_tw, (size_t)L * sizeof(float)));
     XSQ_HIP(hipMemcpy(P->d_tw, tw, (size_t)L * sizeof(float), hipMemcpyHostToDevice));
+    // ---- short bands inside k_slice_irfft (slice_fft.h: ShortSched) ----------------------------------------
+    // eligible: the LDS slice FFT is in use, every band the radix-4 kernel does not take has Lg = 4m with
+    // 4 <= m <= 15 and lies below the scratch area, and the scratch area fits above it
+    if (P->d_tgt != nullptr && P->nbands4 > 0 && !P->bands4_small.empty()) {
+        bool ok = true;
+        int nent = 0, maxbin = 0;
+        for (int j : P->bands4_small) {
+            const BandDev& b = P->bands[j];
+            if (b.Lg % 4 != 0 || b.Lg < 16 || b.Lg > 60) ok = false;
+            nent += b.Lg;
+            maxbin = std::max(maxbin, b.bin0 + b.Lg);
+        }
+        const int sc0 = 4096;
+        if (maxbin >= sc0 || sc0 + nent > FFT_N + 1) ok = false;
+        if (ok) {
+            std::vector<ShortItem1> item1;
+            std::vector<float2> tw1;
+            std::vector<std::pair<int, int>> item2;     // (m, code)
+            std::vector<int> stgt((size_t)nent, -1);
+            std::vector<float> swd((size_t)nent, 0.f);
+            int sc = 0;
+            for (int ph = 0; ph < 4; ++ph) {
+                P->short_begin[ph] = sc;
+                for (int j : P->bands4_small) {
+                    if (j % 4 != ph) continue;
+                    const BandDev& b = P->bands[j];
+                    const int n = b.Lg, m = n / 4;
+                    const double sign = ((c[j] / 2) % 2 == 0) ? 1.0 : -1.0;
+                    for (int t1 = 0; t1 < m; ++t1) {
+                        item1.push_back(ShortItem1{(int)b.cum, b.F, b.f, n, t1, sc});
+                        for (int r = 1; r <= 3; ++r) {
+                            const int e = (r * t1) % n;
+                            tw1.push_back(make_float2((float)std::cos(PI2 * e / n), (float)(-std::sin(PI2 * e / n))));
+                        }
+                    }
+                    for (int r = 0; r < 4; ++r) {
+                        item2.push_back({m, ((sc + r * m) << 4) | m});
+                        for (int k = 0; k < m; ++k) {
+                            const int q = 4 * k + r;
+                            const int bin = b.bin0 + (q + n / 2) % n;
+                            stgt[sc + r * m + k] = (bin >= 0 && bin <= L / 2) ? bin : -1;
+                            swd[sc + r * m + k] = (float)(gd[g_off[j] + q] * n * sign / L);
+                        }
+                    }
+                    sc += n;
+                }
+            }
+            P->short_begin[4] = sc;
+            std::stable_sort(item2.begin(), item2.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+            std::vector<int> codes;
+            for (auto& it : item2) codes.push_back(it.second);
+            // the gather of the long bands starts behind the short ones of each phase (bands of a phase are in band order)
+            for (int ph = 0; ph < 4; ++ph) {
+                int lo = P->phase_begin[ph + 1];
+                for (int j = ph; j < nbands; j += 4) {
+                    bool is_short = false;
+                    for (int js : P->bands4_small) is_short = is_short || js == j;
+                    if (!is_short) { lo = P->bands[j].ent; break; }
+                }
+                P->phase_long[ph] = lo;
+                // every short band of the phase must precede every long one, or the split gather would skip entries
+                for (int j = ph; j < nbands; j += 4) {
+                    bool is_short = false;
+                    for (int js : P->bands4_small) is_short = is_short || js == j;
+                    if (is_short && P->bands[j].ent >= lo) ok = false;
+                }
+            }
+            if (ok && item1.size() <= 1280 && codes.size() <= 768 && sc <= nent) {
+                bool fits = true;
+                for (int ph = 0; ph < 4; ++ph) fits = fits && (P->short_begin[ph + 1] - P->short_begin[ph] <= 1280);
+                if (fits) {
+#define UPV(dst, vec, T)                                                                          \
+    do {                                                                                          \
+        XSQ_HIP(hipMalloc((void**)&(dst), (vec).size() * sizeof(T)));                             \
+        XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); \
+    } while (0)
+                    UPV(P->d_s_item1, item1, ShortItem1);
+                    UPV(P->d_s_tw1, tw1, float2);
+                    UPV(P->d_s_item2, codes, int);
+                    UPV(P->d_s_tgt, stgt, int);
+                    UPV(P->d_s_wd, swd, float);
+#undef UPV
+                    P->short_n1 = (int)item1.size(); P->short_n2 = (int)codes.size();
+                    P->short_nent = nent; P->short_sc0 = sc0;
+                }
+            }
+        }
+    }
     return XSQ_OK;
 }
 
@@ -582,6 +691,7 @@ int xsq_plan_destroy(xsq_plan* P) {
     (void)hipFree(P->d_bands4); (void)hipFree(P->d_pool4f); (void)hipFree(P->d_pool4i);
     (void)hipFree(P->d_T); (void)hipFree(P->d_tgt); (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
     (void)hipFree(P->d_cov_ptr); (void)hipFree(P->d_cov_band);
+    (void)hipFree(P->d_s_item1); (void)hipFree(P->d_s_tw1); (void)hipFree(P->d_s_item2); (void)hipFree(P->d_s_tgt); (void)hipFree(P->d_s_wd);
     delete P;
     return XSQ_OK;
 }
@@ -591,6 +701,12 @@ int xsq_plan_num_blocks(const xsq_plan* P) { return P ? P->nblocks : XSQ_ERR_ARG
 int xsq_plan_set_band_radix4(xsq_plan* P, int on) {
     XSQ_REQUIRE(P, "xsq_plan_set_band_radix4: null plan");
     P->band_radix4 = on ? 1 : 0;
+    return XSQ_OK;
+}
+
+int xsq_plan_set_short_inline(xsq_plan* P, int on) {
+    XSQ_REQUIRE(P, "xsq_plan_set_short_inline: null plan");
+    P->short_inline = on ? 1 : 0;
     return XSQ_OK;
 }
 
@@ -651,7 +767,8 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
     }
     if (lds_fft(P)) {
         XSQ_PROF("slice_rfft", stream);
-        hipLaunchKernelGGL(k_slice_rfft, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
+        if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
+        else hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
     } else {
         { XSQ_PROF("slice_window", stream);
         hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
@@ -744,7 +861,9 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         XSQ_PROF("band_synthesis_dft4", stream);
         hipLaunchKernelGGL(band_dft4_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
-    if (tt.ntiles) { XSQ_PROF("band_synthesis_gemm", stream);
+    // short bands: inside k_slice_irfft when the plan allows it, else dense GEMM + Z round trip
+    const bool inl = lds_fft(P) && P->band_radix4 && P->short_inline && P->short_n1 > 0;
+    if (tt.ntiles && !inl) { XSQ_PROF("band_synthesis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandInvOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
                        tt.d_tiles, tt.ntiles); }
     if (lds_fft(P)) {
@@ -753,10 +872,21 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         GatherSched G;
         G.tgt = P->d_tgt; G.row_len = (int)P->sumFT;
         for (int i = 0; i < 5; ++i) G.begin[i] = P->phase_begin[i];
+        for (int i = 0; i < 4; ++i) G.lo[i] = inl ? P->phase_long[i] : P->phase_begin[i];
+        ShortSched SS;
+        memset(&SS, 0, sizeof(SS));
+        if (inl) {
+            SS.item1 = (const ShortItem1*)P->d_s_item1; SS.tw1 = (const float2*)P->d_s_tw1; SS.item2 = P->d_s_item2;
+            SS.stgt = P->d_s_tgt; SS.swd = P->d_s_wd;
+            SS.n1 = P->short_n1; SS.n2 = P->short_n2; SS.nent = P->short_nent; SS.sc0 = P->short_sc0;
+            for (int i = 0; i < 5; ++i) SS.begin[i] = P->short_begin[i];
+        }
+        const ShortIn SI{coef, mask, BC, mask ? BCx : BC};
         for (int parity = 0; parity < 2; ++parity) {
             const int nsl = (S + 1 - parity) / 2;
             OlaArgs O{y, row_offsets, S, P->h, parity, length};
-            hipLaunchKernelGGL(k_slice_irfft, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O);
+            if (fft_threads(1) == 512) hipLaunchKernelGGL(k_slice_irfft<512>, dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else hipLaunchKernelGGL(k_slice_irfft<256>, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
         }
         XSQ_HIP(hipGetLastError());
         return XSQ_OK;

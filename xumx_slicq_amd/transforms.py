@@ -43,6 +43,11 @@ class SliCQEngine:
         self._handles = {}
         self._ws = {}
         self._fft_backend = 0
+        import os
+        # measured (r02c-e): synthesising the short bands inside the inverse slice FFT kernel is 0.03-0.05 ms SLOWER per
+        # 240 s track than the dense GEMM + workspace round trip it replaces (the kernel is bound by its serial chain of
+        # memory / LDS round trips, and the in-kernel stage adds three) -> off by default; XSQ_SHORT_INLINE=1 / set_short_inline
+        self._short_inline = os.environ.get("XSQ_SHORT_INLINE", "0") != "0"
 
     def set_fft_backend(self, backend: int):
         """0 = hand-written LDS slice FFT when the plan allows it (default), 1 = rocFFT."""
@@ -55,6 +60,13 @@ class SliCQEngine:
         self._band_radix4 = bool(on)
         for h in self._handles.values():
             _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(self._band_radix4)), "xsq_plan_set_band_radix4")
+
+    def set_short_inline(self, on: bool):
+        """False (default): bands with Lg < 64 on the dense GEMM with a round trip through the workspace; True: the inverse
+        transform synthesises them inside the slice-FFT kernel (A/B switch, same results to fp32 rounding; measured slower)."""
+        self._short_inline = bool(on)
+        for h in self._handles.values():
+            _lib.check(_lib.lib.xsq_plan_set_short_inline(h, int(self._short_inline)), "xsq_plan_set_short_inline")
 
     # -- handle management ---------------------------------------------------
     def handle(self, device: torch.device):
@@ -75,6 +87,8 @@ class SliCQEngine:
             _lib.check(_lib.lib.xsq_plan_set_fft_backend(h, self._fft_backend), "xsq_plan_set_fft_backend")
             _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(getattr(self, "_band_radix4", True))),
                        "xsq_plan_set_band_radix4")
+            _lib.check(_lib.lib.xsq_plan_set_short_inline(h, int(getattr(self, "_short_inline", False))),
+                       "xsq_plan_set_short_inline")
             self._handles[idx] = h
         return h
 
