@@ -91,6 +91,14 @@ int xsq_plan_num_slices(const xsq_plan* plan, int64_t n);
 size_t xsq_slicqt_forward_workspace(xsq_plan* plan, int BC, int64_t n);   /* 0 on error */
 int xsq_slicqt_forward(xsq_plan* plan, const float* x, int BC, int64_t n, float* coef,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same transform, with the CDAE's whitened input written beside the coefficients by the analysis kernels'
+ * epilogues: xin[i] = (|coef[i]| + mean[band]) * scale[band] (model.py:238-242; Unmix.forward's abs_of_real_complex,
+ * model.py:74-76), real arena layout for BC channels -- normally the head of the xsq_cdae_forward workspace, with
+ * mean / scale / split from xsq_model_whitening; xsq_cdae_forward_xin(..., xin_ready = 1) then skips its magnitude
+ * pass (one kernel and a second read of the 87 MB mix arena less per chunk).  xin == NULL: plain forward.     */
+int xsq_slicqt_forward_xin(xsq_plan* plan, const float* x, int BC, int64_t n, float* coef, float* xin,
+                           const float* mean, const float* scale, int split,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- inverse sliCQT -----------------------------------------------------------
  * Replaces INSGT_SL.forward (transforms.py:154-178) -> NSGT_sliced.backward
@@ -153,6 +161,12 @@ size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 o
  *          (one float per coefficient) -- Unmix.forward(return_masks=True)             */
 int xsq_cdae_forward(xsq_model* model, const float* X, int B, int S, float* Y, float* masks,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* xin_ready != 0: the head of `workspace` (2 B S sum(F T) floats) already holds the whitened magnitude, written by
+ * xsq_slicqt_forward_xin with this model's tables (xsq_model_whitening: device pointers to input_mean / input_scale
+ * per band and the operand format of the current precision mode).                                            */
+int xsq_cdae_forward_xin(xsq_model* model, const float* X, int B, int S, float* Y, float* masks,
+                         void* workspace, size_t workspace_bytes, void* stream, int xin_ready);
+int xsq_model_whitening(xsq_model* model, const float** mean, const float** scale, int* split);
 
 /* ---- post-filters on the arena ---------------------------------------------------
  * Both take an explicit block table (nblocks, F[], T[]) so that they also serve the

@@ -533,3 +533,25 @@ def test_full_size_track_matches_the_oracle(seps, oracle_plan, seeded_sd, name, 
         assert rms < RMS_TOL and mx < MAX_TOL, (name, c0, rms, mx)
         worst_rms, worst_max = max(worst_rms, rms), max(worst_max, mx)
     print(f"full-size {name}: rms {worst_rms:.2e} max {worst_max:.2e}")
+
+
+@pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener", "realtime"])
+def test_whitening_fused_into_the_analysis_epilogues_is_bitwise_equal(seps, name):
+    """Separator's default: the forward transform writes (|X| + mean) * scale straight into the CDAE workspace
+    (xsq_slicqt_forward_xin) and the model skips its magnitude pass -- same bits as the two-pass path, in fp32 and
+    in the split-bf16 operand format."""
+    sep = seps[name]
+    sep.chunk_size = 60000
+    x = synth_audio(60000 * 2 + 23456, seed=91, nb_samples=2).cuda()
+    try:
+        for prec in ("fp32", "bf16x3"):
+            sep.xumx_model.set_precision(prec)
+            sep.fuse_whiten = False
+            a = sep(x).clone()
+            sep.fuse_whiten = True
+            b = sep(x).clone()
+            assert torch.equal(a, b), (name, prec, float((a - b).abs().max()))
+    finally:
+        sep.fuse_whiten = True
+        sep.chunk_size = 2621440
+        sep.xumx_model.set_precision("fp32")

@@ -53,6 +53,7 @@ _SIGS = {
     "xsq_plan_num_slices": (C.c_int, [_vp, C.c_int64]),
     "xsq_slicqt_forward_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int64]),
     "xsq_slicqt_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_slicqt_forward_xin": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -63,6 +64,8 @@ _SIGS = {
     "xsq_model_set_precision": (C.c_int, [_vp, C.c_int]),
     "xsq_cdae_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_cdae_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_cdae_forward_xin": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_int]),
+    "xsq_model_whitening": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
     "xsq_phasemix": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "xsq_wiener_workspace": (C.c_size_t, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "xsq_loss_workspace": (C.c_size_t, [C.c_int, _vp, _vp, C.c_int, C.c_int]),

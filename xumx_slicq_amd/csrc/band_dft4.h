@@ -21,13 +21,14 @@
 #pragma once
 #include "common.h"
 #include "gemm_tile.h"
+#include "gemm_tile_bf3.h"
 
 namespace xsq {
 
 struct Band4Dev {
     int Lg, m, bin0, f, F, ent;
     int ldd;            // row length of the transposed DFT_m matrix: round_up(2m, 16)
-    int pad;
+    int jband;          // band index inside the plan (= row of the model's input_mean / input_scale tables)
     int64_t cum;        // arena offset of the band's block (complex per channel-slice)
     int64_t d_off;      // float offset of Dt[n = (k, re/im)][kk = (t1, re/im)] inside the direction's pool
     int64_t tw_off;     // float offset of the twiddles w^(r t1), r = 1..3: [3][round_up(m, 8)] complex
@@ -46,6 +47,13 @@ struct Band4Args {
     // with BCx channels, coefficient channel bc reads mix channel bc % BCx.
     const float* mask;
     int BCx;
+    // FWD, optional: the CDAE's whitened magnitude (|coef| + mean[band]) * scale[band] (model.py:238-242) written beside
+    // the coefficients, same arena layout, real -- the separate magnitude pass then never runs.  split = 1: stored in
+    // the split-bf16 operand format (gemm_tile_bf3.h).
+    float* xin;
+    const float* mean;
+    const float* scale;
+    int split;
 };
 
 constexpr int D4_BM = 64, D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
@@ -56,73 +64,43 @@ constexpr int D4_BM = 64, D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 
 #ifndef XSQ_D4_WPE
 #define XSQ_D4_WPE __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
-// PERSIST = false: one tile per workgroup (blockIdx -> tile through the XCD remap), as launched by hardware.
-// PERSIST = true : one workgroup walks a CONTIGUOUS range of the tile table (ranges of equal estimated work from the
-//   host, `chunks`); the first operand loads of the NEXT tile are issued before the epilogue of the current one, so
-//   the ~3 us of memory latency in front of every tile's first K-step -- a third of a tile whose K loop has 2..10 steps
-//   -- run under the LDS transpose and the stores of its predecessor.  Neighbouring tiles share their band (twiddle
-//   table, DFT matrix) and, on the masked path, the mix rows.
-template <bool FWD, bool PERSIST = false>
-__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles,
-                                                                    const int* __restrict__ chunks) {
+template <bool FWD>
+__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4_BM + 64) * D4_LD];
     __shared__ __attribute__((aligned(16))) float2 twl[3 * D4_MPAD];      // w^(r t1), r = 1..3, of this tile's band
     float* const As0 = lds;                               // [buf][r][row][20]
     float* const Bs0 = lds + 2 * 4 * D4_BM * D4_LD;       // [buf][col][20]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s_row = tid >> 2, s_kq = tid & 3;           // staging assignment: row s_row, complex pair 2*s_kq, 2*s_kq+1 of the K-step
-    const int lrow = lane & 31, lk = lane >> 5;
-    const int e_c4 = tid & 63;                            // epilogue: float4 slot of an output row (complex outputs 2*c4, 2*c4+1)
-    const int M = a.BC * a.S;
+    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const bool wide = t.narrow == 0;
+    const Band4Dev& bd = a.bands[t.group];
+    const int m_ = bd.m, Lg = bd.Lg, K = 2 * m_, M = a.BC * a.S;
     const int64_t BCS = (int64_t)a.BC * a.S;
+
+    // ---- staging assignment: row s_row, complex pair 2*s_kq, 2*s_kq+1 of the K-step -------------
+    const int s_row = tid >> 2, s_kq = tid & 3;
+    const int row = t.m0 + s_row;
+    const bool row_ok = row < M;
+    const int rowc = row_ok ? row : M - 1;             // rows past M load row M-1 (any valid memory) and are zeroed below
+    const int bc = rowc / a.S, s = rowc - bc * a.S;
+    // 32-bit element offsets from the (uniform) arena pointers: the arenas hold < 2^31 floats (checked by the
+    // host) and two lane-varying 64-bit pointers would not fit under the 3-workgroups-per-CU register cap
     const float* const xbase = a.src;
     const float* const mbase = a.mask;
     const bool masked = !FWD && a.mask != nullptr;
-
-    int ti, tend;
-    if (PERSIST) {
-        // consecutive chunks on one XCD (blocks b and b + 8 share one): neighbours share matrices and mix rows in its L2
-        const int G = gridDim.x, c = (G % 8 == 0) ? (blockIdx.x & 7) * (G / 8) + (blockIdx.x >> 3) : blockIdx.x;
-        ti = chunks[c]; tend = chunks[c + 1];
-        if (ti >= tend) return;
-    } else {
-        ti = xcd_remap(blockIdx.x, ntiles); tend = ti + 1;
+    int xoff, moff = 0;
+    if (FWD) xoff = rowc * 2 * a.nbins;
+    else if (!masked) xoff = (int)(2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg));
+    else {
+        moff = (int)(BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
+        xoff = (int)(2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + s) * Lg));
     }
-
-    // ---- per-tile state of the tile whose operands are being LOADED (set by setup) ---------------------------
-    TileDev t;
-    int m_, Lg, K, mpad, band;
-    bool wide, row_ok, b_on;
-    int xoff, moff;
-    const float *win, *bp;
-    const float2* tw;
-    int bin0 = 0;
-    auto setup = [&](int tix) {
-        t = tiles[tix];
-        band = t.group;
-        const Band4Dev& bd = a.bands[band];
-        wide = t.narrow == 0;
-        m_ = bd.m; Lg = bd.Lg; K = 2 * m_; bin0 = bd.bin0;
-        const int row = t.m0 + s_row;
-        row_ok = row < M;
-        const int rowc = row_ok ? row : M - 1;             // rows past M load row M-1 (any valid memory) and are zeroed below
-        const int bc = rowc / a.S, s = rowc - bc * a.S;
-        // 32-bit element offsets from the (uniform) arena pointers: the arenas hold < 2^31 floats (checked by the
-        // host) and two lane-varying 64-bit pointers would not fit under the 3-workgroups-per-CU register cap
-        moff = 0;
-        if (FWD) xoff = rowc * 2 * a.nbins;
-        else if (!masked) xoff = (int)(2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg));
-        else {
-            moff = (int)(BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + s) * Lg);
-            xoff = (int)(2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + s) * Lg));
-        }
-        win = a.pool + bd.win_off;
-        mpad = (m_ + 7) & ~7;
-        tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
-        bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
-        b_on = wide || s_row < 32;
-    };
+    const float* win = a.pool + bd.win_off;
+    const int mpad = (m_ + 7) & ~7;
+    const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
+    const float* bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
+    const bool b_on = wide || s_row < 32;
 
     // Operand staging.  load_set only ISSUES loads -- unconditionally, from clamped addresses, nothing consumed --
     // so that the K-step's ~9 loads per lane are in flight together while the previous step's MFMAs run; every
@@ -138,7 +116,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     int g_t1 = 0;          // t1 of the staged pair (twiddles are read from LDS in store_set)
 
     auto fwd_idx = [&](int tt, int q4, float& cj) {        // spectrum bin of window index tt + q4*m, Hermitian reflection
-        int idx = bin0 + tt + ((q4 + 2) & 3) * m_;
+        int idx = bd.bin0 + tt + ((q4 + 2) & 3) * m_;
         cj = 1.f;
         if (idx < 0) { idx = -idx; cj = -1.f; }
         else if (idx > a.L / 2) { idx = a.L - idx; cj = -1.f; }
@@ -228,140 +206,121 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
         *reinterpret_cast<float4*>(Bs0 + buf * 64 * D4_LD + s_row * D4_LD + 4 * s_kq) = gb;
     };
 
-    // ---- first tile: operands, epilogue constants and twiddle table requested together ------------------------
-    // epilogue constants of a lane (synthesis: its two dual-window values) travel with the tile's first operand loads
-    float p_w0 = 1.f, p_w1 = 1.f;
-    auto load_w = [&]() {
-        const int q = 4 * (t.n0 >> 1) + 2 * e_c4;
-        const int qc = q + 1 < Lg ? q : 0;               // clamped: unconditional loads
-        p_w0 = 1.f; p_w1 = 1.f;
-        if (!FWD) { p_w0 = win[qc]; p_w1 = win[qc + 1]; }
-    };
-    setup(ti);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    // epilogue constants of this lane (synthesis: the two dual-window values), requested here with the first
+    // operand loads and the twiddle table -- one memory round trip for the prologue instead of three, none in the epilogue
+    const int e_c4 = tid & 63;                   // float4 slot of an output row: complex outputs 2*c4, 2*c4+1
+    const int e_q = 4 * (t.n0 >> 1) + 2 * e_c4;
+    const bool e_on = e_c4 < (wide ? 64 : 32) && e_q < Lg;
+    float e_w0 = 1.f, e_w1 = 1.f;
     load_set(0);
-    load_w();
-    int tw_band = -1;                  // band whose twiddles are in twl
-    for (;;) {
-        // state of the tile being COMPUTED (the loader state above moves on to the next tile before the epilogue)
-        const TileDev ct = t;
-        const bool c_wide = wide;
-        const int c_m = m_, c_Lg = Lg, c_K = K, c_band = band;
-        // epilogue constants of this lane (synthesis: the two dual-window values)
-        const int e_q = 4 * (ct.n0 >> 1) + 2 * e_c4;
-        const bool e_on = e_c4 < (c_wide ? 64 : 32) && e_q < c_Lg;
-        const float e_w0 = p_w0, e_w1 = p_w1;
-        if (tw_band != c_band) {       // workgroup-uniform
-            for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the barrier below
-            tw_band = c_band;
+    if (!FWD && e_on) { e_w0 = win[e_q]; e_w1 = win[e_q + 1]; }
+    float w_mu = 0.f, w_sc = 1.f;                // whitening constants of this tile's band (uniform)
+    if (FWD && a.xin) { w_mu = a.mean[bd.jband]; w_sc = a.scale[bd.jband]; }
+    for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the barrier below
+    __syncthreads();             // twiddle table complete
+    store_set(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const bool more = k0 + 16 < K;
+        if (more) load_set(k0 + 16);
+        const float* As = As0 + (cur * 4 + wave) * D4_BM * D4_LD;     // this wave's residue
+        const float* Bs = Bs0 + cur * 64 * D4_LD;
+        float av[2][8], bv[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 lo = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk]);
+            const float4 hi = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk + 4]);
+            av[i][0] = lo.x; av[i][1] = lo.y; av[i][2] = lo.z; av[i][3] = lo.w;
+            av[i][4] = hi.x; av[i][5] = hi.y; av[i][6] = hi.z; av[i][7] = hi.w;
         }
-        __syncthreads();             // twiddle table complete; the previous tile's epilogue has left the staging buffers
-        store_set(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !wide) break;
+            const float4 lo = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk]);
+            const float4 hi = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk + 4]);
+            bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;
+            bv[j][4] = hi.x; bv[j][5] = hi.y; bv[j][6] = hi.z; bv[j][7] = hi.w;
+        }
+        if (wide) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (XSQ_D4_ABL & 1) { acc[i][j][kk] += av[i][kk] * bv[j][kk]; continue; }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[0][kk], acc[i][0], 0, 0, 0);
+        }
+        if (more) store_set(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
+    }
 
-        f32x16 acc[2][2];
+    // ---- epilogue: wave = residue r, lane column n -> (k = n/2, re/im), output index q = 4k + r.
+    // The four waves hold interleaved parts of every output row, so the tile is transposed through
+    // LDS (32 rows x 256 floats at a time, row stride 260) and written as 16-byte stores of two
+    // consecutive complex outputs per lane -- full 128-byte lines instead of 4-byte scatters.
+    if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][9] == 1.2345e-30f) __builtin_trap(); return; }
+    constexpr int TLD = 260;
+    float* const Tt = lds;                       // reuses the staging buffers (33,280 B needed)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !wide) break;
+            const int col = 8 * ((j * 32 + lrow) >> 1) + 2 * wave + (lrow & 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        int cur = 0;
-        for (int k0 = 0; k0 < c_K; k0 += 16) {
-            const bool more = k0 + 16 < c_K;
-            if (more) load_set(k0 + 16);
-            const float* As = As0 + (cur * 4 + wave) * D4_BM * D4_LD;     // this wave's residue
-            const float* Bs = Bs0 + cur * 64 * D4_LD;
-            float av[2][8], bv[2][8];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 lo = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk]);
-                const float4 hi = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk + 4]);
-                av[i][0] = lo.x; av[i][1] = lo.y; av[i][2] = lo.z; av[i][3] = lo.w;
-                av[i][4] = hi.x; av[i][5] = hi.y; av[i][6] = hi.z; av[i][7] = hi.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j == 1 && !c_wide) break;
-                const float4 lo = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk]);
-                const float4 hi = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk + 4]);
-                bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;
-                bv[j][4] = hi.x; bv[j][5] = hi.y; bv[j][6] = hi.z; bv[j][7] = hi.w;
-            }
-            if (c_wide) {
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (XSQ_D4_ABL & 1) { acc[i][j][kk] += av[i][kk] * bv[j][kk]; continue; }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
-                        }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[0][kk], acc[i][0], 0, 0, 0);
-            }
-            if (more) store_set(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
+            for (int r = 0; r < 16; ++r) Tt[(acc_row(r) + 4 * lk) * TLD + col] = acc[i][j][r];
         }
-
-        // ---- the next tile's first operand loads go out now: they land under the epilogue below ------------------
-        const bool next = PERSIST && ti + 1 < tend;
-        if (next) { setup(ti + 1); load_set(0); load_w(); }
-
-        // ---- epilogue: wave = residue r, lane column n -> (k = n/2, re/im), output index q = 4k + r.
-        // The four waves hold interleaved parts of every output row, so the tile is transposed through
-        // LDS (32 rows x 256 floats at a time, row stride 260) and written as 16-byte stores of two
-        // consecutive complex outputs per lane -- full 128-byte lines instead of 4-byte scatters.
-        if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][9] == 1.2345e-30f) __builtin_trap(); }
-        else {
-            constexpr int TLD = 260;
-            float* const Tt = lds;                       // reuses the staging buffers (33,280 B needed)
-            const Band4Dev& cbd = a.bands[c_band];
+        __syncthreads();
+        const int c4 = e_c4, q = e_q;
+        if (e_on) {
+            const float w0 = e_w0, w1 = e_w1;
+            int pos = q;
+            if (!FWD) {
+                pos = q + 2 * m_;                // spectrum position p = (q + Lg/2) mod Lg
+                if (pos >= Lg) pos -= Lg;
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i) __syncthreads();                  // (i = 0: the K loop ended on a barrier)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j == 1 && !c_wide) break;
-                    const int col = 8 * ((j * 32 + lrow) >> 1) + 2 * wave + (lrow & 1);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Tt[(acc_row(r) + 4 * lk) * TLD + col] = acc[i][j][r];
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 6) + 4 * it;
+                const int mrow = t.m0 + i * 32 + rl;
+                if (mrow >= M) break;
+                float4 v = *reinterpret_cast<const float4*>(&Tt[rl * TLD + 4 * c4]);
+                v.x *= w0; v.y *= w0; v.z *= w1; v.w *= w1;
+                float* d;
+                if (!FWD && a.row_len) {
+                    d = a.dst + 2 * ((int64_t)mrow * a.row_len + bd.ent + pos);
+                } else {
+                    const int rb = mrow / a.S, rs = mrow - rb * a.S;
+                    d = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg + pos);
                 }
-                __syncthreads();
-                const int c4 = e_c4, q = e_q;
-                if (e_on) {
-                    const float w0 = e_w0, w1 = e_w1;
-                    int pos = q;
-                    if (!FWD) {
-                        pos = q + 2 * c_m;                // spectrum position p = (q + Lg/2) mod Lg
-                        if (pos >= c_Lg) pos -= c_Lg;
-                    }
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int rl = (tid >> 6) + 4 * it;
-                        const int mrow = ct.m0 + i * 32 + rl;
-                        if (mrow >= M) break;
-                        float4 v = *reinterpret_cast<const float4*>(&Tt[rl * TLD + 4 * c4]);
-                        v.x *= w0; v.y *= w0; v.z *= w1; v.w *= w1;
-                        float* d;
-                        if (!FWD && a.row_len) {
-                            d = a.dst + 2 * ((int64_t)mrow * a.row_len + cbd.ent + pos);
-                        } else {
-                            const int rb = mrow / a.S, rs = mrow - rb * a.S;
-                            d = a.dst + 2 * (BCS * cbd.cum + (((int64_t)rb * cbd.F + cbd.f) * a.S + rs) * c_Lg + pos);
-                        }
-                        if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
-                    }
+                if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
+                if (FWD && a.xin) {
+                    float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
+                    if (a.split) bf3_words2(o.x, o.y, o.x, o.y);
+                    *reinterpret_cast<float2*>(a.xin + ((d - a.dst) >> 1)) = o;
                 }
             }
         }
-        if (!next) break;
-        ++ti;
     }
 }
 

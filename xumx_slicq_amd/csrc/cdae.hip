@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void k_magnitude_whiten(const float4* __restri
     const float mu = mean[b.cumF + f], sc = scale[b.cumF + f];
     const float4 z0 = X[2 * q], z1 = X[2 * q + 1];
     float4 o;
-    o.x = (sqrtf(z0.x * z0.x + z0.y * z0.y) + mu) * sc;
-    o.y = (sqrtf(z0.z * z0.z + z0.w * z0.w) + mu) * sc;
-    o.z = (sqrtf(z1.x * z1.x + z1.y * z1.y) + mu) * sc;
-    o.w = (sqrtf(z1.z * z1.z + z1.w * z1.w) + mu) * sc;
+    o.x = whiten_mag(z0.x, z0.y, mu, sc);
+    o.y = whiten_mag(z0.z, z0.w, mu, sc);
+    o.z = whiten_mag(z1.x, z1.y, mu, sc);
+    o.w = whiten_mag(z1.z, z1.w, mu, sc);
     if (split) { bf3_words2(o.x, o.y, o.x, o.y); bf3_words2(o.z, o.w, o.z, o.w); }
     xin[q] = o;
 }
@@ -134,15 +134,19 @@ __device__ __forceinline__ void relu_shift_epilogue(const CdaeGroup& g, int row0
 
 // the same for the exact-width column layout of the fp32 engines (gemm_tile.h XW = 1, cdae_slab.h MODE 3):
 // columns 0..31 in the 32x32 accumulator, 32..47 in two 16x16 blocks, 48..47+nv as half-wave partial sums
+// Wide stores: the wave's 32 x 52 output block is one contiguous 6,656-byte span of the channels-last activation, but
+// the accumulator layout gives a lane one COLUMN of it (25 four-byte stores per lane, each behind its own 64-bit
+// address and row predicate: 0.2 ms of layer 1's 0.68, measured with the epilogue ablated).  The block goes through a
+// per-wave LDS image (the staging buffers are dead once the K loop has passed its last barrier) and leaves as seven
+// 16-byte stores per lane, lanes consecutive: whole 1 KB wave-instructions.
+constexpr int XW_TILE = 32 * CS;          // floats of one wave's image
 __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int rowb, int lane, const f32x16& a0,
-                                                       const f32x4 (&a16)[2], float (&av)[4], int nv) {
+                                                       const f32x4 (&a16)[2], float (&av)[4], int nv, float* img) {
     const int lrow = lane & 31, lk = lane >> 5, q16 = lane >> 4;
     {
         const float sh = g.shift[lrow];
-        float* d0 = g.out + (int64_t)(rowb + 4 * lk) * CS + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (rowb + 4 * lk + acc_row(r) < g.M) d0[acc_row(r) * CS] = fmaxf(a0[r] + sh, 0.f);
+        for (int r = 0; r < 16; ++r) img[(acc_row(r) + 4 * lk) * CS + lrow] = fmaxf(a0[r] + sh, 0.f);
     }
     {
         const int col = 32 + (lane & 15);
@@ -150,20 +154,24 @@ __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int r
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rowb + 16 * rb + 4 * q16 + r;
-                if (row < g.M) g.out[(int64_t)row * CS + col] = fmaxf(a16[rb][r] + sh, 0.f);
-            }
+            for (int r = 0; r < 4; ++r) img[(16 * rb + 4 * q16 + r) * CS + col] = fmaxf(a16[rb][r] + sh, 0.f);
     }
     {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) av[cc] = cc < nv ? av[cc] + __shfl_xor(av[cc], 32) : 0.f;
-        const int row = rowb + lrow;
-        if (lk == 0 && row < g.M) {
+        if (lk == 0) {
             const float4 sh = *reinterpret_cast<const float4*>(g.shift + 48);
-            *reinterpret_cast<float4*>(g.out + (int64_t)row * CS + 48) =
+            *reinterpret_cast<float4*>(img + lrow * CS + 48) =
                 make_float4(fmaxf(av[0] + sh.x, 0.f), fmaxf(av[1] + sh.y, 0.f), fmaxf(av[2] + sh.z, 0.f), fmaxf(av[3] + sh.w, 0.f));
         }
+    }
+    __builtin_amdgcn_wave_barrier();          // same wave, LDS operations complete in order: no workgroup barrier needed
+    const int nvalid = (g.M - rowb < 32 ? g.M - rowb : 32) * (CS / 4);       // float4 slots of the rows that exist
+    float* out = g.out + (int64_t)rowb * CS;
+#pragma unroll
+    for (int i = 0; i < (XW_TILE / 4 + 63) / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < nvalid) *reinterpret_cast<float4*>(out + 4 * e) = *reinterpret_cast<const float4*>(img + 4 * e);
     }
 }
 
@@ -217,8 +225,8 @@ struct CdaeL1Op {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
     static constexpr int NV = H1 - 48;        // real output channels past 47
-    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
-        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4], float* img) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV, img);
     }
 };
 
@@ -257,8 +265,8 @@ struct CdaeL2Op {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
     static constexpr int NV = H2 - 48;        // real output channels past 47
-    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
-        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4], float* img) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV, img);
     }
 };
 
@@ -300,8 +308,8 @@ struct CdaeL3Op {
         relu_shift_epilogue(g, row0, n, a0, a1, a.raw != 0, a.split != 0);
     }
     static constexpr int NV = H1 - 48;        // real output channels past 47
-    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4]) const {
-        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV);
+    __device__ void epilogue_xw(const Group& g, int rowb, int lane, const f32x16& a0, const f32x4 (&a16)[2], float (&av)[4], float* img) const {
+        relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV, img);
     }
 };
 
@@ -820,8 +828,19 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 
 extern "C" {
 
+int xsq_model_whitening(xsq_model* Mo, const float** mean, const float** scale, int* split) {
+    XSQ_REQUIRE(Mo && mean && scale && split, "xsq_model_whitening: null argument");
+    *mean = Mo->d_mean; *scale = Mo->d_scale; *split = Mo->precision == 1 ? 1 : 0;
+    return XSQ_OK;
+}
+
 int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, float* masks, void* ws,
                      size_t ws_bytes, void* stream_) {
+    return xsq_cdae_forward_xin(Mo, X, Bn, S, Y, masks, ws, ws_bytes, stream_, 0);
+}
+
+int xsq_cdae_forward_xin(xsq_model* Mo, const float* X, int Bn, int S, float* Y, float* masks, void* ws,
+                         size_t ws_bytes, void* stream_, int xin_ready) {
     XSQ_REQUIRE(Mo && X && (Y || masks) && ws, "xsq_cdae_forward: null argument");
     XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_cdae_forward: Bn=%d S=%d (the conv stack needs >= 3 slices)", Bn, S);
     XSQ_REQUIRE(ws_bytes >= xsq_cdae_workspace(Mo, Bn, S), "xsq_cdae_forward: workspace too small");
@@ -833,7 +852,7 @@ int xsq_cdae_forward(xsq_model* Mo, const float* X, int Bn, int S, float* Y, flo
     float* act3 = (float*)w; w += al((size_t)CS * Bn * T1 * 4 * Mo->sumF1 * 4);
     float* act2 = (float*)w;
     const int split = Mo->precision == 1 ? 1 : 0;
-    cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream, split);
+    if (!xin_ready) cdae_launch_magnitude(Mo, X, xin, Mo->d_mean, Mo->d_scale, Bn, S, stream, split);
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0, nullptr, nullptr};
     a.split = split;
     a.poolB = split ? Mo->d_pool_split : nullptr;

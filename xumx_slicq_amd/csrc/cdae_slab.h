@@ -325,35 +325,10 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
 
     if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
     if constexpr (EXW) {
-        const int rowb = t.m0 + wave * 32;
-        {   // columns 0..31
-            const float sh = g.shift[lrow];
-            float* d0 = g.out + (int64_t)(rowb + 4 * lk) * CS + lrow;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (rowb + 4 * lk + acc_row(r) < g.M) d0[acc_row(r) * CS] = fmaxf(acc0[r] + sh, 0.f);
-        }
-        {   // columns 32..47: C[4 q + r][l & 15] of each 16-row block
-            const int col = 32 + (lane & 15);
-            const float sh = g.shift[col];
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rowb + 16 * rb + 4 * q16 + r;
-                    if (row < g.M) g.out[(int64_t)row * CS + col] = fmaxf(acc16[rb][r] + sh, 0.f);
-                }
-        }
-        {   // columns 48..51: the two half-waves hold the partial sums over their 8 k-values of every chunk
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) accv[cc] += __shfl_xor(accv[cc], 32);
-            const int row = rowb + lrow;
-            if (lk == 0 && row < g.M) {
-                const float4 sh = *reinterpret_cast<const float4*>(g.shift + 48);
-                *reinterpret_cast<float4*>(g.out + (int64_t)row * CS + 48) =
-                    make_float4(fmaxf(accv[0] + sh.x, 0.f), fmaxf(accv[1] + sh.y, 0.f), fmaxf(accv[2] + sh.z, 0.f), fmaxf(accv[3] + sh.w, 0.f));
-            }
-        }
+        // (the slot loop ended on a barrier: the slab planes are free; each wave transposes its 32 x 52 block through
+        //  6.6 KB of them and stores it as whole 16-byte lanes -- relu_shift_epilogue_xw, cdae.hip)
+        static_assert(8 * 32 * CS * 4 <= 2 * PLANE * 2, "epilogue images do not fit the slab planes");
+        relu_shift_epilogue_xw(g, t.m0 + wave * 32, lane, acc0, acc16, accv, NV, slabF + wave * 32 * CS);
         return;
     }
     relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, BF3);

@@ -42,6 +42,12 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 static __device__ float4 g_zero16;       // zero-initialised, never written
 __device__ __forceinline__ const float* zero16() { return reinterpret_cast<const float*>(&g_zero16); }
 
+// Whitened magnitude of one coefficient, (|c| + mean) * scale (model.py:238-242), spelled once so that the separate
+// magnitude pass (cdae.hip) and the fused analysis epilogues (band_dft4.h, slicqt.hip) round identically.
+__device__ __forceinline__ float whiten_mag(float re, float im, float mu, float sc) {
+    return (sqrtf(fmaf(re, re, im * im)) + mu) * sc;
+}
+
 struct TileDev;
 // tiles of one group: 128-row x 64-column tiles, plus a 32-column tile when the N tail is <= 32
 template <class Vec>

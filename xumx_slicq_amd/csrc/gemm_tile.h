@@ -70,6 +70,7 @@ template <class Op, int MT = 1, int XW = 0>
 __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
                                                             int ntiles) {
     static_assert(XW == 0 || MT == 1, "exact-width columns: MT = 1 only");
+    static_assert(XW != 1 || 4 * 32 * 52 <= 2 * (GEMM_BM + GEMM_BN) * GEMM_LD, "XW = 1 epilogue image does not fit the staging buffers");
     constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
     constexpr int RA = BM / 64;     // A rows staged per thread
 
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         return;
     }
     if constexpr (XW == 1) {
-        if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv); return; }
+        // (the K loop ended on a barrier: the staging buffers are free, each wave takes 32 x 52 floats of them)
+        if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv, lds + wave * 32 * 52); return; }
     }
     if constexpr (XW == 2) {
         if (kind >= 2) op.epilogue16(g, t.m0 + wave * 32, lane, t.n0 + (kind == 3 ? 32 : 0), acc16);

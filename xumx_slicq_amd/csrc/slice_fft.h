@@ -222,37 +222,74 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
     if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
     const int64_t i0 = (int64_t)(2 * s - 2) * h;
     const int part = tid >> 8, m = tid & 255;            // wave-uniform part
-    if (m < FFT_M1) {
-        float2 v[FFT_R1];
-        // Straight-line loads: with a predicate around every sample the compiler emitted 86 load -> wait
-        // round trips in sequence (57 us per row, measured); here every load is unconditional and the 129 of a
-        // thread are in flight together.  Slices inside the signal (all but the first two and last three of a
-        // channel) take 8-byte loads; edge slices clamp the index and select afterwards.
-        const float2* tw2 = reinterpret_cast<const float2*>(tw);
-        if (i0 >= 0 && i0 + FFT_L <= n) {            // workgroup-uniform
+    const float2* tw2 = reinterpret_cast<const float2*>(tw);
+    if constexpr (NT == 256) {
+        if (m < FFT_M1) {
+            float2 v[FFT_R1];
+            // Straight-line loads: with a predicate around every sample the compiler emitted 86 load -> wait
+            // round trips in sequence (57 us per row, measured); here every load is unconditional and the 129 of a
+            // thread are in flight together.  Slices inside the signal (all but the first two and last three of a
+            // channel) take 8-byte loads; edge slices clamp the index and select afterwards.
+            if (i0 >= 0 && i0 + FFT_L <= n) {            // workgroup-uniform
 #pragma unroll
-            for (int n1 = 0; n1 < FFT_R1; ++n1) {
-                const int p2 = n1 * FFT_M1 + m;
-                const float2 w = tw2[p2];
-                const float xa = xr[i0 + 2 * p2], xb = xr[i0 + 2 * p2 + 1];
-                v[n1] = make_float2(w.x * xa, w.y * xb);
+                for (int n1 = 0; n1 < FFT_R1; ++n1) {
+                    const int p2 = n1 * FFT_M1 + m;
+                    const float2 w = tw2[p2];
+                    const float xa = xr[i0 + 2 * p2], xb = xr[i0 + 2 * p2 + 1];
+                    v[n1] = make_float2(w.x * xa, w.y * xb);
+                }
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < FFT_R1; ++n1) {
+                    const int p2 = n1 * FFT_M1 + m;
+                    const int64_t i = i0 + 2 * p2;
+                    const float2 w = tw2[p2];
+                    const int64_t ia = i < 0 ? 0 : (i >= n ? n - 1 : i), ib = i + 1 < 0 ? 0 : (i + 1 >= n ? n - 1 : i + 1);
+                    const float xa = xr[ia], xb = xr[ib];
+                    v[n1].x = (i >= 0 && i < n) ? w.x * xa : 0.f;
+                    v[n1].y = (i + 1 >= 0 && i + 1 < n) ? w.y * xb : 0.f;
+                }
             }
-        } else {
+            dft_small<FFT_R1, -1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+        }
+    } else {
+        // 512 threads: the windowed samples go through LDS once (every lane 18 consecutive-lane pairs, all loads in
+        // flight together), then both wave groups read the columns they share from there
+        constexpr int NLD = (FFT_N + NT - 1) / NT;
+        float2 xv[NLD], wv[NLD];
+        const bool inner = i0 >= 0 && i0 + FFT_L <= n;      // workgroup-uniform
 #pragma unroll
-            for (int n1 = 0; n1 < FFT_R1; ++n1) {
-                const int p2 = n1 * FFT_M1 + m;
-                const int64_t i = i0 + 2 * p2;
-                const float2 w = tw2[p2];
+        for (int it = 0; it < NLD; ++it) {
+            const int p2 = tid + NT * it;
+            const int pc = p2 < FFT_N ? p2 : FFT_N - 1;
+            wv[it] = tw2[pc];
+            const int64_t i = i0 + 2 * pc;
+            if (inner) { xv[it].x = xr[i]; xv[it].y = xr[i + 1]; }
+            else {
                 const int64_t ia = i < 0 ? 0 : (i >= n ? n - 1 : i), ib = i + 1 < 0 ? 0 : (i + 1 >= n ? n - 1 : i + 1);
                 const float xa = xr[ia], xb = xr[ib];
-                v[n1].x = (i >= 0 && i < n) ? w.x * xa : 0.f;
-                v[n1].y = (i + 1 >= 0 && i + 1 < n) ? w.y * xb : 0.f;
+                xv[it].x = (i >= 0 && i < n) ? xa : 0.f;
+                xv[it].y = (i + 1 >= 0 && i + 1 < n) ? xb : 0.f;
             }
         }
-        auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
-        if constexpr (NT == 256) dft_small<FFT_R1, -1>(v, put);
-        else if (part == 0) dft_small<FFT_R1, -1, 0, 2>(v, put);
-        else dft_small<FFT_R1, -1, 1, 2>(v, put);
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int p2 = tid + NT * it;
+            if (p2 < FFT_N) Z[p2] = make_float2(wv[it].x * xv[it].x, wv[it].y * xv[it].y);
+        }
+        __syncthreads();
+        const bool on = m < FFT_M1;
+        float2 v[FFT_R1];
+        if (on) {
+#pragma unroll
+            for (int n1 = 0; n1 < FFT_R1; ++n1) v[n1] = Z[n1 * FFT_M1 + m];
+        }
+        __syncthreads();
+        if (on) {
+            auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
+            if (part == 0) dft_small<FFT_R1, -1, 0, 2>(v, put);
+            else dft_small<FFT_R1, -1, 1, 2>(v, put);
+        }
     }
     __syncthreads();
     fft_steps_2_3<-1, NT>(Z, T.w1, w2s, tid);

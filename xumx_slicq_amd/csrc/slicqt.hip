@@ -101,6 +101,7 @@ struct BandGroup {
     int Lg, bin0, f, F;
     int64_t base;  // float offset of (bc=0, f, s=0) of this band in the arena
     int64_t cum;   // complex coefficients per channel-slice before this band's block
+    int j;         // band index inside the plan
 };
 
 // coef = U_window x Wf
@@ -114,6 +115,10 @@ struct BandFwdOp {
     const BandDev* bands;
     const float* W;
     int BC, S, nbins, L;
+    float* xin;            // optional whitened magnitude beside the coefficients (see Band4Args)
+    const float* mean;
+    const float* scale;
+    int split;
 
     __device__ Group group(int j) const {
         const BandDev b = bands[j];
@@ -122,6 +127,7 @@ struct BandFwdOp {
         g.Lg = b.Lg; g.bin0 = b.bin0; g.f = b.f; g.F = b.F;
         g.base = 2 * ((int64_t)BC * S * b.cum + (int64_t)b.f * S * b.Lg);
         g.cum = b.cum;
+        g.j = j;
         return g;
     }
     __device__ RowA row_a(const Group& g, int m) const {
@@ -152,6 +158,15 @@ struct BandFwdOp {
             float* d = coef + g.base + ((int64_t)bc * g.F * S + s) * (2 * g.Lg) + n;
             if (c0) d[0] = a0[r];
             if (c1) d[32] = a1[r];
+            if (xin) {       // uniform.  Column n = 2t + (re/im): the even lane of a pair forms |c| and stores it
+                const float o0 = __shfl_xor(a0[r], 1), o1 = __shfl_xor(a1[r], 1);
+                if (!(n & 1)) {
+                    const float mu = mean[g.j], sc = scale[g.j];
+                    float* x = xin + ((d - coef) >> 1);
+                    if (c0) { float v = whiten_mag(a0[r], o0, mu, sc); if (split) v = bf3_word(v); x[0] = v; }
+                    if (c1) { float v = whiten_mag(a1[r], o1, mu, sc); if (split) v = bf3_word(v); x[16] = v; }
+                }
+            }
         }
     }
 };
@@ -263,18 +278,11 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
 // (sample, channel, slice)); their tiles are made neighbours so the mix is fetched once per XCD.  When share is not a
 // multiple of the tile height the last tile of a copy runs into the next copy's first rows and recomputes them
 // (same values, written twice).
-static int get_dft4_chunks(xsq_plan* P, int rows, int share, const std::vector<TileDev>* host_tiles, int nchunks, int** out);
-constexpr int D4_CHUNKS = 768;      // persistent launch: 3 resident workgroups on each of the 256 CUs
-
-static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0, int** chunks = nullptr) {
+static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) {
     std::lock_guard<std::mutex> lk(P->mu);
     auto key = std::make_tuple(1, rows, share);
     auto it = P->tiles.find(key);
-    if (it != P->tiles.end()) {
-        *out = it->second;
-        if (chunks) return get_dft4_chunks(P, rows, share, nullptr, D4_CHUNKS, chunks);      // built together with the tiles
-        return XSQ_OK;
-    }
+    if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
     std::vector<TileDev> t;
     const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
     for (int i = P->nbands4 - 1; i >= 0; --i) {
@@ -288,44 +296,6 @@ static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0, 
     if (rc) return rc;
     P->tiles[key] = tt;
     *out = tt;
-    int* ch = nullptr;
-    rc = get_dft4_chunks(P, rows, share, &t, D4_CHUNKS, &ch);
-    if (rc) return rc;
-    if (chunks) *chunks = ch;
-    return XSQ_OK;
-}
-
-// Persistent launch of the radix-4 band kernel: the tile table cut into `nchunks` contiguous ranges of equal
-// estimated work (a tile costs its K-steps -- 0.6 each for a 32-column tile -- plus ~3 K-steps of fixed overhead).
-static int get_dft4_chunks(xsq_plan* P, int rows, int share, const std::vector<TileDev>* host_tiles, int nchunks, int** out) {
-    auto key = std::make_tuple(3, rows, share);
-    auto it = P->tiles.find(key);
-    if (it != P->tiles.end()) { *out = (int*)it->second.d_tiles; return XSQ_OK; }
-    const std::vector<TileDev>& t = *host_tiles;
-    std::vector<double> cost(t.size());
-    double total = 0;
-    for (size_t i = 0; i < t.size(); ++i) {
-        const int ks = (2 * P->bands4_m[t[i].group] + 15) / 16;
-        cost[i] = 3.0 + ks * (t[i].narrow ? 0.6 : 1.0);
-        total += cost[i];
-    }
-    std::vector<int> ch(nchunks + 1, (int)t.size());
-    double acc = 0;
-    int c = 0;
-    ch[0] = 0;
-    for (size_t i = 0; i < t.size(); ++i) {
-        // tile i starts chunk c+1 once the running cost passes the (c+1)-th share
-        while (c + 1 < nchunks && acc >= total * (c + 1) / nchunks) ch[++c] = (int)i;
-        acc += cost[i];
-    }
-    while (c + 1 <= nchunks) ch[++c] = (int)t.size();
-    int* d = nullptr;
-    XSQ_HIP(hipMalloc(&d, ch.size() * sizeof(int)));
-    XSQ_HIP(hipMemcpy(d, ch.data(), ch.size() * sizeof(int), hipMemcpyHostToDevice));
-    TileTable tt;
-    tt.d_tiles = (TileDev*)d; tt.ntiles = nchunks;
-    P->tiles[key] = tt;
-    *out = d;
     return XSQ_OK;
 }
 
@@ -382,11 +352,8 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
-#ifndef XSQ_D4_PERSIST_DEFAULT
-#define XSQ_D4_PERSIST_DEFAULT 0
-#endif
 #ifndef XSQ_FFT_NT_FWD
-#define XSQ_FFT_NT_FWD 256
+#define XSQ_FFT_NT_FWD 512
 #endif
 #ifndef XSQ_FFT_NT_INV
 #define XSQ_FFT_NT_INV 512
@@ -402,14 +369,6 @@ static int fft_threads(int inverse) {
         u[0] = f == 512 ? 512 : 256; u[1] = i == 512 ? 512 : 256;
     }
     return u[inverse ? 1 : 0];
-}
-
-// XSQ_D4_PERSIST=0/1: the radix-4 band kernel one tile per workgroup, or persistent over contiguous tile ranges with
-// cross-tile operand prefetch (band_dft4.h); diagnostic A/B switch, same results bit for bit
-static bool d4_persistent() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("XSQ_D4_PERSIST"); v = e ? atoi(e) != 0 : XSQ_D4_PERSIST_DEFAULT; }
-    return v != 0;
 }
 
 static inline bool lds_fft(const xsq_plan* P) { return P->fft_backend == 0 && P->L == FFT_L && P->d_tgt != nullptr; }
@@ -590,7 +549,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
             const int n = b.Lg, m = n / 4;
             Band4Dev d;
             memset(&d, 0, sizeof(d));
-            d.Lg = n; d.m = m; d.bin0 = b.bin0; d.f = b.f; d.F = b.F; d.ent = b.ent; d.cum = b.cum;
+            d.Lg = n; d.m = m; d.bin0 = b.bin0; d.f = b.f; d.F = b.F; d.ent = b.ent; d.cum = b.cum; d.jband = j;
             d.ldd = (int)round_up(2 * m, 16);
             if (!doff.count(m)) {       // Dt[n' = (k, ro)][kk = (t1, ri)] of exp(-+2 pi i k t1 / m)
                 const int64_t o = alloc2((size_t)round_up(2 * m, 64) * d.ldd);
@@ -802,7 +761,14 @@ size_t xsq_slicqt_forward_workspace(xsq_plan* P, int BC, int64_t n) {
 
 int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* coef, void* ws,
                        size_t ws_bytes, void* stream_) {
+    return xsq_slicqt_forward_xin(P, x, BC, n, coef, nullptr, nullptr, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float* coef, float* xin, const float* mean,
+                           const float* scale, int split, void* ws, size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(P && x && coef && ws, "xsq_slicqt_forward: null argument");
+    XSQ_REQUIRE(!xin || (mean && scale), "xsq_slicqt_forward_xin: xin needs the mean / scale tables");
+    XSQ_REQUIRE(!xin || (P->band_radix4 && P->nbands4), "xsq_slicqt_forward_xin: needs the radix-4 band path");
     XSQ_REQUIRE(BC > 0 && n > 0, "xsq_slicqt_forward: BC=%d n=%lld", BC, (long long)n);
     hipStream_t stream = (hipStream_t)stream_;
     const int S = xsq_plan_num_slices(P, n);
@@ -835,18 +801,14 @@ int xsq_slicqt_forward(xsq_plan* P, const float* x, int BC, int64_t n, float* co
     TileTable tt;
     rc = get_band_tiles(P, rows, &tt);
     if (rc) return rc;
-    BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L};
+    BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L, xin, mean, scale, split};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
-        int* ch4 = nullptr;
-        rc = get_dft4_tiles(P, rows, &t4, 0, &ch4);
+        rc = get_dft4_tiles(P, rows, &t4);
         if (rc) return rc;
-        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0};
+        Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0, xin, mean, scale, split};
         XSQ_PROF("band_analysis_dft4", stream);
-        if (d4_persistent() && t4.ntiles >= 4 * D4_CHUNKS)
-            hipLaunchKernelGGL((band_dft4_kernel<true, true>), dim3(D4_CHUNKS), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles, ch4);
-        else
-            hipLaunchKernelGGL((band_dft4_kernel<true, false>), dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles, nullptr);
+        hipLaunchKernelGGL(band_dft4_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
     if (tt.ntiles) { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
@@ -914,16 +876,12 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
-        int* ch4 = nullptr;
-        rc = get_dft4_tiles(P, rows, &t4, mask ? BCx * S : 0, &ch4);
+        rc = get_dft4_tiles(P, rows, &t4, mask ? BCx * S : 0);
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
-                     lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
+                     lds_fft(P) ? (int)P->sumFT : 0, mask, BCx, nullptr, nullptr, nullptr, 0};
         XSQ_PROF("band_synthesis_dft4", stream);
-        if (d4_persistent() && t4.ntiles >= 4 * D4_CHUNKS)
-            hipLaunchKernelGGL((band_dft4_kernel<false, true>), dim3(D4_CHUNKS), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles, ch4);
-        else
-            hipLaunchKernelGGL((band_dft4_kernel<false, false>), dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles, nullptr);
+        hipLaunchKernelGGL(band_dft4_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
     // short bands: inside k_slice_irfft when the plan allows it, else dense GEMM + Z round trip
     const bool inl = lds_fft(P) && P->band_radix4 && P->short_inline && P->short_n1 > 0;

@@ -290,7 +290,21 @@ class Unmix(nn.Module):
         return ws
 
     # -- forward -----------------------------------------------------------------------
-    def masks_arena(self, Xcomplex: List[Tensor]):
+    def whitening_target(self, device: torch.device, B: int, S: int):
+        """(workspace, mean pointer, scale pointer, split flag): where the forward transform may write the whitened
+        magnitude of a (B, 2, ...) input with S slices (``SliCQEngine.forward(x, whiten=...)``) so that the next
+        ``masks_arena`` / ``forward`` call on the same stream runs with ``xin_ready=True`` and skips its magnitude pass."""
+        h = self._model(device)
+        with torch.cuda.device(device):
+            nbytes = _lib.lib.xsq_cdae_workspace(h, B, S)
+            if nbytes == 0:
+                raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
+            ws = self._workspace(device, nbytes)
+        mean, scale, split = C.c_void_p(), C.c_void_p(), C.c_int()
+        _lib.check(_lib.lib.xsq_model_whitening(h, C.byref(mean), C.byref(scale), C.byref(split)), "xsq_model_whitening")
+        return ws, mean.value, scale.value, split.value
+
+    def masks_arena(self, Xcomplex: List[Tensor], xin_ready: bool = False):
         """Mix-phase models only: (masks, X, B, S) with ``masks`` the real arena (4, B, 2, ...) of sigmoid
         masks and ``X`` the mix arena -- the estimate Y = masks * X is left to the consumer
         (``SliCQEngine.backward_masked`` forms it while it loads; Separator.forward uses this)."""
@@ -308,11 +322,12 @@ class Unmix(nn.Module):
             if nbytes == 0:
                 raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
             ws = self._workspace(dev, nbytes)
-            _lib.check(_lib.lib.xsq_cdae_forward(h, X.data_ptr(), B, S, None, masks.data_ptr(),
-                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
+            _lib.check(_lib.lib.xsq_cdae_forward_xin(h, X.data_ptr(), B, S, None, masks.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(), int(bool(xin_ready))),
+                       "xsq_cdae_forward")
         return masks, X, B, S
 
-    def forward(self, Xcomplex: List[Tensor], return_masks=False, wiener_batch_group: int = 0):
+    def forward(self, Xcomplex: List[Tensor], return_masks=False, wiener_batch_group: int = 0, xin_ready: bool = False):
         """list over blocks of (B, 2, F_b, S, T_b, 2) -> list of (4, B, 2, F_b, S, T_b, 2)
         [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82.  ``wiener_batch_group`` (extension):
         runs of that many batch items share the Wiener window maximum (0 = the whole batch, the
@@ -336,9 +351,9 @@ class Unmix(nn.Module):
             if nbytes == 0:
                 raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
             ws = self._workspace(dev, nbytes)
-            _lib.check(_lib.lib.xsq_cdae_forward(
+            _lib.check(_lib.lib.xsq_cdae_forward_xin(
                 h, X.data_ptr(), B, S, Y.data_ptr(), masks.data_ptr() if return_masks else None,
-                ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "xsq_cdae_forward")
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr(), int(bool(xin_ready))), "xsq_cdae_forward")
             if not phasemix:
                 wiener_em_arena(self.table, X, Y, B, S, batch_group=wiener_batch_group)
         Ylist = self.table.views(Y, (4, B, 2), S)

@@ -79,7 +79,8 @@ class Separator(nn.Module):
         return (tuple(audio_big.shape), audio_big.device.index, self.chunk_size, getattr(m, "precision", "fp32"),
                 bool(getattr(self, "overlap_tail", True)), bool(getattr(self, "batch_chunks", True)),
                 int(getattr(self, "max_stack", 8)), int(getattr(self, "pass_streams", 1)),
-                m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused())
+                m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused(),
+                bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")))
 
     def drop_graphs(self):
         """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
@@ -125,16 +126,31 @@ class Separator(nn.Module):
         return bool(getattr(self, "fuse_phasemix", os.environ.get("XSQ_FUSE_PHASEMIX", "1") != "0")
                     and all(bool(b.realtime) for b in self.xumx_model.sliced_umx))
 
-    def _decode_into(self, out: Tensor, Xc, length: int, offsets: Tensor, group: int = 0):
+    def _encode(self, audio: Tensor):
+        """Forward transform of (B, 2, n) audio -> (coefficient list, xin_ready).  By default the analysis kernels also
+        write the CDAE's whitened magnitude straight into the model's workspace (xsq_slicqt_forward_xin; same values as
+        the separate magnitude pass, which is then skipped); ``fuse_whiten = False`` / XSQ_FUSE_WHITEN=0 restores it."""
+        if not getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0") or audio.dim() != 3 or audio.shape[1] != 2 \
+                or audio.device.type != "cuda":
+            return self.nsgt(audio), False
+        eng = self.nsgt.nsgt.nsgt
+        if not getattr(eng, "_band_radix4", True):
+            return self.nsgt(audio), False
+        S = eng.plan.num_slices(audio.shape[-1])
+        ws, mean, scale, split = self.xumx_model.whitening_target(audio.device, audio.shape[0], S)
+        arena, lead, S = eng.forward(audio, whiten=(ws.data_ptr(), mean, scale, split))
+        return eng.table.views(arena, lead, S), True
+
+    def _decode_into(self, out: Tensor, Xc, length: int, offsets: Tensor, group: int = 0, xin_ready: bool = False):
         """CDAE + post-filter + inverse transform of the coefficient list ``Xc`` (batch B); packed channel
         (target, b, c) is written to out.view(-1)[offsets[target, b, c] : +length]."""
         eng = self.insgt.nsgt.nsgt
         offs = offsets.reshape(-1).contiguous()
         if self._fused():
-            masks, X, B, S = self.xumx_model.masks_arena(Xc)
+            masks, X, B, S = self.xumx_model.masks_arena(Xc, xin_ready=xin_ready)
             eng.backward_masked(masks, X, 8 * B, 2 * B, S, length, out, offs)
             return
-        Ylist = self.xumx_model(Xc, wiener_batch_group=group)
+        Ylist = self.xumx_model(Xc, wiener_batch_group=group, xin_ready=xin_ready)
         arena, lead, S = eng.table.as_arena(list(Ylist))
         eng.backward(arena, offs.numel(), S, length, out=out, row_offsets=offs)
 
@@ -157,7 +173,8 @@ class Separator(nn.Module):
         if n < min_samples:
             audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n), device=audio.device,
                                                   dtype=audio.dtype)], dim=-1)
-        self._decode_into(out, self.nsgt(audio), n, row_offsets, group=group)
+        Xc, ready = self._encode(audio)
+        self._decode_into(out, Xc, n, row_offsets, group=group, xin_ready=ready)
 
     @torch.no_grad()
     def forward(self, audio_big: Tensor) -> Tensor:
@@ -177,8 +194,9 @@ class Separator(nn.Module):
         rows = (torch.arange(4, device=dev).view(4, 1, 1, 1) * nb + torch.arange(nb, device=dev).view(1, 1, nb, 1)) * 2 \
             + torch.arange(2, device=dev).view(1, 1, 1, 2)                       # (4, 1, nb, 2) row of `out`
 
-        def decode(Xc, length, offsets, group=0):
-            self._decode_into(out, Xc, length, offsets, group)
+        def decode(audio, length, offsets, group=0):
+            Xc, ready = self._encode(audio)
+            self._decode_into(out, Xc, length, offsets, group, xin_ready=ready)
 
         full = N // cs if getattr(self, "batch_chunks", True) else 0
         start0 = 0
@@ -198,7 +216,7 @@ class Separator(nn.Module):
                 if n_samples < min_samples:
                     audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n_samples),
                                                           device=dev, dtype=audio.dtype)], dim=-1)
-                decode(self.nsgt(audio), n_samples, rows * N + start)
+                decode(audio, n_samples, rows * N + start)
 
         if not stacked:
             rest(0)
@@ -228,7 +246,7 @@ class Separator(nn.Module):
             with torch.cuda.stream(st):
                 a = audio_big[..., s0:s0 + k * cs].reshape(nb, 2, k, cs).permute(2, 0, 1, 3).reshape(k * nb, 2, cs)
                 offs = rows * N + s0 + torch.arange(k, device=dev).view(1, k, 1, 1) * cs   # (4, k, nb, 2)
-                decode(self.nsgt(a), cs, offs, group=nb)                         # batch = (chunk, b)
+                decode(a, cs, offs, group=nb)                                    # batch = (chunk, b)
         for st in used:
             main.wait_stream(st)
         if not overlap_tail:

@@ -128,8 +128,10 @@ class SliCQEngine:
         return st
 
     # -- transforms --------------------------------------------------------------
-    def forward(self, x: Tensor):
-        """x (*lead, n) fp32 on a ROCm device -> (arena, lead, S)."""
+    def forward(self, x: Tensor, whiten=None):
+        """x (*lead, n) fp32 on a ROCm device -> (arena, lead, S).  ``whiten`` = (xin device pointer, mean pointer,
+        scale pointer, split flag) from ``Unmix.whitening_target``: the analysis kernels also write the CDAE's
+        whitened magnitude there (xsq_slicqt_forward_xin)."""
         if x.dtype != torch.float32:
             x = x.float()
         lead = tuple(x.shape[:-1])
@@ -144,8 +146,14 @@ class SliCQEngine:
             if nbytes == 0:
                 raise _lib.XsqError("xsq_slicqt_forward_workspace: " + _lib.last_error())
             ws = self.workspace(x.device, nbytes)
-            _lib.check(_lib.lib.xsq_slicqt_forward(h, xb.data_ptr(), BC, n, arena.data_ptr(), ws.data_ptr(),
-                                                   ws.numel(), _lib.stream_ptr()), "xsq_slicqt_forward")
+            if whiten is None:
+                _lib.check(_lib.lib.xsq_slicqt_forward(h, xb.data_ptr(), BC, n, arena.data_ptr(), ws.data_ptr(),
+                                                       ws.numel(), _lib.stream_ptr()), "xsq_slicqt_forward")
+            else:
+                xin, mean, scale, split = whiten
+                _lib.check(_lib.lib.xsq_slicqt_forward_xin(h, xb.data_ptr(), BC, n, arena.data_ptr(), xin, mean, scale,
+                                                           int(split), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                           "xsq_slicqt_forward_xin")
         return arena, lead, S
 
     def backward(self, arena: Tensor, BC: int, S: int, length: int, out: Tensor = None,
