@@ -206,23 +206,33 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
         *reinterpret_cast<float4*>(Bs0 + buf * 64 * D4_LD + s_row * D4_LD + 4 * s_kq) = gb;
     };
 
-    f32x16 acc[2][2];
+    // ---- MFMA section: wave w owns rows 16 w .. 16 w + 15 of the tile for ALL FOUR residues (v_mfma_f32_16x16x4_f32,
+    // lane = row l & 15 / column l & 15, k quad l >> 4; MFMA j of a 16-k chunk takes k = 4 (l >> 4) + j, so a fragment is
+    // one 16-byte LDS read).  A lane pair (columns 2k', 2k'+1 = Re, Im) then holds outputs q = 4k .. 4k + 3 of its rows
+    // across the four residue accumulators: one DPP exchange per pair gives each lane two consecutive complex outputs
+    // -- a 16-byte store -- with no LDS transpose and no barrier in the epilogue.  (The first version gave every wave
+    // one residue of 64 rows, v_mfma_f32_32x32x2_f32: the waves then held interleaved parts of every output row and
+    // the tile went through LDS twice behind four barriers.)
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t acc[4][4];                           // [residue][16-column block]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int cb = 0; cb < 4; ++cb) acc[r][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int lrow = lane & 31, lk = lane >> 5;
-    // epilogue constants of this lane (synthesis: the two dual-window values), requested here with the first
-    // operand loads and the twiddle table -- one memory round trip for the prologue instead of three, none in the epilogue
-    const int e_c4 = tid & 63;                   // float4 slot of an output row: complex outputs 2*c4, 2*c4+1
-    const int e_q = 4 * (t.n0 >> 1) + 2 * e_c4;
-    const bool e_on = e_c4 < (wide ? 64 : 32) && e_q < Lg;
-    float e_w0 = 1.f, e_w1 = 1.f;
+    const int l16 = lane & 15, kq = lane >> 4;
+    // epilogue constants: this lane's outputs are q = 4 (k0 + 8 cb + k') + 2 (l & 1) + {0, 1}, k' = (l & 15) >> 1
+    const int e_k = (t.n0 >> 1) + (l16 >> 1);    // + 8 cb
+    const int e_odd = lane & 1;
+    float e_w[4][2];
     load_set(0);
-    if (!FWD && e_on) { e_w0 = win[e_q]; e_w1 = win[e_q + 1]; }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int q = 4 * (e_k + 8 * cb) + 2 * e_odd;
+        const int qc = q + 1 < Lg ? q : 0;        // clamped: unconditional loads
+        e_w[cb][0] = FWD ? 1.f : win[qc];
+        e_w[cb][1] = FWD ? 1.f : win[qc + 1];
+    }
     float w_mu = 0.f, w_sc = 1.f;                // whitening constants of this tile's band (uniform)
     if (FWD && a.xin) { w_mu = a.mean[bd.jband]; w_sc = a.scale[bd.jband]; }
     for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];      // read back in store_set, after the barrier below
@@ -230,95 +240,73 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     store_set(0);
     __syncthreads();
     int cur = 0;
+    const int ncb = wide ? 4 : 2;
     for (int k0 = 0; k0 < K; k0 += 16) {
         const bool more = k0 + 16 < K;
         if (more) load_set(k0 + 16);
-        const float* As = As0 + (cur * 4 + wave) * D4_BM * D4_LD;     // this wave's residue
-        const float* Bs = Bs0 + cur * 64 * D4_LD;
-        float av[2][8], bv[2][8];
+        const float* As = As0 + cur * 4 * D4_BM * D4_LD + (wave * 16 + l16) * D4_LD + 4 * kq;     // + residue * D4_BM * D4_LD
+        const float* Bs = Bs0 + cur * 64 * D4_LD + l16 * D4_LD + 4 * kq;                          // + 16 cb * D4_LD
+        float4 av[4], bv[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float4 lo = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk]);
-            const float4 hi = *reinterpret_cast<const float4*>(&As[(i * 32 + lrow) * D4_LD + 8 * lk + 4]);
-            av[i][0] = lo.x; av[i][1] = lo.y; av[i][2] = lo.z; av[i][3] = lo.w;
-            av[i][4] = hi.x; av[i][5] = hi.y; av[i][6] = hi.z; av[i][7] = hi.w;
-        }
+        for (int r = 0; r < 4; ++r) av[r] = *reinterpret_cast<const float4*>(As + r * D4_BM * D4_LD);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !wide) break;
-            const float4 lo = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk]);
-            const float4 hi = *reinterpret_cast<const float4*>(&Bs[(j * 32 + lrow) * D4_LD + 8 * lk + 4]);
-            bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;
-            bv[j][4] = hi.x; bv[j][5] = hi.y; bv[j][6] = hi.z; bv[j][7] = hi.w;
-        }
-        if (wide) {
+        for (int cb = 0; cb < 4; ++cb) bv[cb] = cb < ncb ? *reinterpret_cast<const float4*>(Bs + 16 * cb * D4_LD) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const float ax = j == 0 ? av[r].x : j == 1 ? av[r].y : j == 2 ? av[r].z : av[r].w;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (XSQ_D4_ABL & 1) { acc[i][j][kk] += av[i][kk] * bv[j][kk]; continue; }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
-                    }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[0][kk], acc[i][0], 0, 0, 0);
-        }
+                for (int cb = 0; cb < 4; ++cb) {
+                    if (cb >= 2 && !wide) break;
+                    const float bx = j == 0 ? bv[cb].x : j == 1 ? bv[cb].y : j == 2 ? bv[cb].z : bv[cb].w;
+                    if (XSQ_D4_ABL & 1) { acc[r][cb][j] += ax * bx; continue; }
+                    acc[r][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc[r][cb], 0, 0, 0);
+                }
+            }
         if (more) store_set(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue: wave = residue r, lane column n -> (k = n/2, re/im), output index q = 4k + r.
-    // The four waves hold interleaved parts of every output row, so the tile is transposed through
-    // LDS (32 rows x 256 floats at a time, row stride 260) and written as 16-byte stores of two
-    // consecutive complex outputs per lane -- full 128-byte lines instead of 4-byte scatters.
-    if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][9] == 1.2345e-30f) __builtin_trap(); return; }
-    constexpr int TLD = 260;
-    float* const Tt = lds;                       // reuses the staging buffers (33,280 B needed)
+    // ---- epilogue: register rr of acc[r][cb] is row 16 w + 4 (l >> 4) + rr, column l & 15 = (k', Re / Im) of residue r,
+    // i.e. output q = 4 (k0 + 8 cb + k') + r.  Even lanes end up with (q, q + 1) = residues 0, 1, odd lanes with
+    // residues 2, 3: the even lane takes Im of residues 0 / 1 from its neighbour, the odd lane Re of residues 2 / 3.
+    if (XSQ_D4_ABL & 8) { if (acc[0][0][0] + acc[1][1][3] + acc[2][1][1] + acc[3][0][2] == 1.2345e-30f) __builtin_trap(); return; }
+    auto swap1 = [](float v) {                   // value of lane l ^ 1 (DPP quad_perm [1, 0, 3, 2])
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !wide) break;
-            const int col = 8 * ((j * 32 + lrow) >> 1) + 2 * wave + (lrow & 1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Tt[(acc_row(r) + 4 * lk) * TLD + col] = acc[i][j][r];
+    for (int cb = 0; cb < 4; ++cb) {
+        if (cb >= 2 && !wide) break;
+        const int k = e_k + 8 * cb;
+        const int q = 4 * k + 2 * e_odd;
+        const bool on = k < m_;
+        int pos = q;
+        if (!FWD) {
+            pos = q + 2 * m_;                    // spectrum position p = (q + Lg/2) mod Lg
+            if (pos >= Lg) pos -= Lg;
         }
-        __syncthreads();
-        const int c4 = e_c4, q = e_q;
-        if (e_on) {
-            const float w0 = e_w0, w1 = e_w1;
-            int pos = q;
-            if (!FWD) {
-                pos = q + 2 * m_;                // spectrum position p = (q + Lg/2) mod Lg
-                if (pos >= Lg) pos -= Lg;
-            }
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rl = (tid >> 6) + 4 * it;
-                const int mrow = t.m0 + i * 32 + rl;
-                if (mrow >= M) break;
-                float4 v = *reinterpret_cast<const float4*>(&Tt[rl * TLD + 4 * c4]);
-                v.x *= w0; v.y *= w0; v.z *= w1; v.w *= w1;
-                float* d;
-                if (!FWD && a.row_len) {
-                    d = a.dst + 2 * ((int64_t)mrow * a.row_len + bd.ent + pos);
-                } else {
-                    const int rb = mrow / a.S, rs = mrow - rb * a.S;
-                    d = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg + pos);
-                }
-                if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
-                if (FWD && a.xin) {
-                    float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
-                    if (a.split) bf3_words2(o.x, o.y, o.x, o.y);
-                    *reinterpret_cast<float2*>(a.xin + ((d - a.dst) >> 1)) = o;
-                }
+        for (int rr = 0; rr < 4; ++rr) {
+            const float x = swap1(e_odd ? acc[0][cb][rr] : acc[2][cb][rr]);      // even lane receives Im of residue 0, odd lane Re of residue 2
+            const float y = swap1(e_odd ? acc[1][cb][rr] : acc[3][cb][rr]);      //                    Im of residue 1,          Re of residue 3
+            float4 v = e_odd ? make_float4(x, acc[2][cb][rr], y, acc[3][cb][rr]) : make_float4(acc[0][cb][rr], x, acc[1][cb][rr], y);
+            v.x *= e_w[cb][0]; v.y *= e_w[cb][0]; v.z *= e_w[cb][1]; v.w *= e_w[cb][1];
+            const int mrow = t.m0 + wave * 16 + 4 * kq + rr;
+            if (!on || mrow >= M) continue;
+            float* d;
+            if (!FWD && a.row_len) {
+                d = a.dst + 2 * ((int64_t)mrow * a.row_len + bd.ent + pos);
+            } else {
+                const int rb = mrow / a.S, rs = mrow - rb * a.S;
+                d = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg + pos);
+            }
+            if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
+            if (FWD && a.xin) {
+                float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
+                if (a.split) bf3_words2(o.x, o.y, o.x, o.y);
+                *reinterpret_cast<float2*>(a.xin + ((d - a.dst) >> 1)) = o;
             }
         }
     }
