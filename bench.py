@@ -362,6 +362,8 @@ def bench_track(args, sep, dev, world, rank, dist):
     my_items = [it.length for it in chunk_items([TRACK_SAMPLES], CHUNK)]
     variants = {}
     if world == 1 and not args.no_variants and rank == 0:
+        if not args.graph:
+            variants["hip_graph"] = variant_graph(args, sep, track, out)
         if args.precision == "fp32":
             variants.update(variant_precisions(args, sep, step, out))
         if not args.wiener:
@@ -395,6 +397,25 @@ def bench_track(args, sep, dev, world, rank, dist):
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     return result
+
+
+def variant_graph(args, sep, track, out):
+    """The same step replayed from a captured HIP graph (Separator.forward_graphed): no host-side launch work,
+    bitwise the eager result."""
+    import torch
+    for _ in range(max(1, args.warmup)):
+        g = sep.forward_graphed(track)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(g, out))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sep.forward_graphed(track)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sep.drop_graphs()
+    return {"what": "the headline step as one HIP graph replay (Separator.forward_graphed)",
+            "value": round(args.steps * TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "bitwise_equal_to_eager": same}
 
 
 def variant_precisions(args, sep, step, out):

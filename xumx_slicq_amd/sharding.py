@@ -250,6 +250,7 @@ class ShardedDemixer:
             self.recv = [torch.empty(self.world * w, dtype=dt, device=self.dev) for w in self.plan.width]
         self._offs = {}       # (round, pass) -> (audio builder inputs, row-offset tensor)
         self._place_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self._tail_stream = None
 
     # element offsets of packed channel (target, item*nb + b, c) for one pass
     def _row_offsets(self, k: int, pi: int, placed: Sequence[PlacedItem]) -> Tensor:
@@ -271,12 +272,39 @@ class ShardedDemixer:
             t = self._offs[key] = rows.to(self.dev)
         return t
 
-    def _compute_round(self, k: int):
+    def _run_pass(self, k: int, pi: int, placed: Sequence[PlacedItem]):
         target = self.send[k] if self.gather else self.flat
+        audio = [self.get_chunk(p.item) for p in placed]
+        audio = audio[0] if len(audio) == 1 else torch.cat(audio, dim=0)
+        self.sep.demix_into(audio, target, self._row_offsets(k, pi, placed), group=self.plan.nb)
+
+    def _is_tail(self, placed: Sequence[PlacedItem]) -> bool:
+        return placed[0].item.length < self.plan.chunk_size
+
+    def _compute_round(self, k: int, skip_tails: bool = False):
         for pi, placed in enumerate(self.plan.passes(k, self.rank)):
-            audio = [self.get_chunk(p.item) for p in placed]
-            audio = audio[0] if len(audio) == 1 else torch.cat(audio, dim=0)
-            self.sep.demix_into(audio, target, self._row_offsets(k, pi, placed), group=self.plan.nb)
+            if not (skip_tails and self._is_tail(placed)):
+                self._run_pass(k, pi, placed)
+
+    def _tails_on_side_stream(self):
+        """The short last chunks of the tracks are launch-bound passes (a dozen kernels of a few hundred workgroups):
+        like ``Separator.forward`` does for one track, they go out FIRST, on a side stream with its own workspaces, and
+        fill in beside the stacked passes; the caller's stream joins before the first collective that carries one.
+        Returns the first round that holds a tail (None: nothing was moved)."""
+        if self.dev.type != "cuda":
+            return None
+        tails = [(k, pi, placed) for k in range(len(self.plan.rounds))
+                 for pi, placed in enumerate(self.plan.passes(k, self.rank)) if self._is_tail(placed)]
+        if not tails:
+            return None
+        if self._tail_stream is None:
+            self._tail_stream = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        self._tail_stream.wait_stream(main)
+        with torch.cuda.stream(self._tail_stream):
+            for k, pi, placed in tails:
+                self._run_pass(k, pi, placed)
+        return min(k for k, _, _ in tails)
 
     def _place_round(self, k: int):
         """recv[k] (rank-major packed blocks) -> the per-track tensors: the hard concat by placement."""
@@ -290,15 +318,21 @@ class ShardedDemixer:
     @torch.no_grad()
     def run(self) -> Dict[int, Tensor]:
         nrounds = len(self.plan.rounds)
-        if not self.gather:
-            for k in range(nrounds):
-                self._compute_round(k)
-            return self.out
         cuda = self.dev.type == "cuda"
         main = torch.cuda.current_stream(self.dev) if cuda else None
+        first_tail = self._tails_on_side_stream()
+        moved = first_tail is not None
+        if not self.gather:
+            for k in range(nrounds):
+                self._compute_round(k, skip_tails=moved)
+            if moved:
+                main.wait_stream(self._tail_stream)
+            return self.out
         pending = []
         for k in range(nrounds):
-            self._compute_round(k)
+            self._compute_round(k, skip_tails=moved)
+            if moved and k >= first_tail:
+                main.wait_stream(self._tail_stream)       # this round's buffer also holds tails computed on the side stream
             # async: the collective waits for this round's kernels on the backend's own stream and runs beside
             # the next round's kernels; the placement of the round before is queued behind its collective on a
             # side stream, so the host never blocks here with RCCL
