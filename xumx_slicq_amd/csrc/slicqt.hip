@@ -352,6 +352,9 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
+#ifndef XSQ_D4_MIN_LG_DEFAULT
+#define XSQ_D4_MIN_LG_DEFAULT 64
+#endif
 #ifndef XSQ_FFT_NT_FWD
 #define XSQ_FFT_NT_FWD 512
 #endif
@@ -541,11 +544,14 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
     {   // ---- radix-4 band kernel tables (band_dft4.h): bands with Lg >= 64 -------------------------
         std::vector<Band4Dev> b4;
         std::vector<float> pf, pi;      // analysis / synthesis pools
+        // bands at least this long take the radix-4 kernel (XSQ_D4_MIN_LG: diagnostic A/B of the split point)
+        int d4_min_lg = XSQ_D4_MIN_LG_DEFAULT;
+        if (const char* e = getenv("XSQ_D4_MIN_LG")) d4_min_lg = atoi(e) >= 16 ? atoi(e) : d4_min_lg;
         std::map<int, int64_t> doff, twoff;
         auto alloc2 = [&](size_t n) { size_t o = pf.size(); pf.resize(o + n, 0.f); pi.resize(o + n, 0.f); return (int64_t)o; };
         for (int j = 0; j < nbands; ++j) {
             const BandDev& b = P->bands[j];
-            if (b.Lg < 64 || b.Lg > 4 * D4_MPAD) { P->bands4_small.push_back(j); continue; }   // dense engine (gemm_tile.h)
+            if (b.Lg < d4_min_lg || b.Lg > 4 * D4_MPAD) { P->bands4_small.push_back(j); continue; }   // dense engine (gemm_tile.h)
             const int n = b.Lg, m = n / 4;
             Band4Dev d;
             memset(&d, 0, sizeof(d));
