@@ -314,18 +314,27 @@ DTYPES = {"fp32": "f32", "bf16x6": "f32 (conv contractions: exact 3-way bf16 cut
           "bf16x3": "f32 (conv contractions as 3 x bf16 MFMA, fp32 accumulate)"}
 
 
-def instrumented_warmup(step, warmup):
+def instrumented_warmup(step, warmup, serial=None):
     """Warm-up steps; every kernel is timed with HIP events on its launch stream in the LAST one (the first
-    ones build tile tables etc.).  Returns {kernel: (ms, launches)} of that step, or None."""
+    ones build tile tables etc.).  `serial(flag)`: called with True around that step so that the caller can
+    take the short tail pass off its side stream -- a kernel timed while another stream's kernels share the
+    chip reads long, and the per-kernel roofline fractions are meant per kernel.  Returns {kernel: (ms,
+    launches)} of that step, or None."""
     import torch
     from xumx_slicq_amd import _lib
     _lib.profile_filter(None)
     _lib.profile_enable(True)
     for i in range(warmup):
-        if i == warmup - 1:
+        last = i == warmup - 1
+        if last:
             torch.cuda.synchronize()
             _lib.profile_reset()
+            if serial:
+                serial(True)
         step()
+        if last and serial:
+            torch.cuda.synchronize()
+            serial(False)
     torch.cuda.synchronize()
     return _lib.profile_read() if warmup >= 2 else None
 
@@ -345,7 +354,10 @@ def bench_track(args, sep, dev, world, rank, dist):
     # Warm-up steps: every kernel is timed with HIP events on its launch stream (the per-kernel table and the
     # choice of the dominant kernel).  Timed region: only the dominant kernel keeps its two events per launch --
     # event records around all launches of a step cost ~0.1 ms of it (tools/prof_overhead.py).
-    prof_all = instrumented_warmup(step, args.warmup)
+    def serial(on):                       # the instrumented step runs the tail pass after the stacked pass, not beside it
+        sep.overlap_tail = not on
+
+    prof_all = instrumented_warmup(step, args.warmup, None if args.graph else serial)
     dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
     _lib.profile_filter(dom)            # None (fewer than two warm-up steps): every kernel stays instrumented
     _lib.profile_reset()
@@ -389,7 +401,7 @@ def bench_track(args, sep, dev, world, rank, dist):
         "roofline": roofline,
         "roofline_hbm": hbm,
         "roofline_mfma": mfma,
-        "kernels_source": "last warm-up step (all kernels instrumented); the timed region instruments the roofline kernel only",
+        "kernels_source": "last warm-up step: all kernels instrumented and the tail pass serialised behind the stacked pass (clean per-kernel times; their sum exceeds ms_per_step, whose timed region overlaps the two passes and instruments the roofline kernel only)",
         "kernels": kernels,
     }
     if variants:
@@ -459,7 +471,10 @@ def variant_wiener(args, dev, track, plan, my_items):
     def step():
         return sepw(track)
 
-    prof_all = instrumented_warmup(step, max(2, args.warmup))
+    def serial(on):
+        sepw.overlap_tail = not on
+
+    prof_all = instrumented_warmup(step, max(2, args.warmup), serial)
     dom = max(prof_all, key=lambda k: prof_all[k][0])
     _lib.profile_filter(dom)
     _lib.profile_reset()
