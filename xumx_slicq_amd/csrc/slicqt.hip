@@ -774,7 +774,6 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
                            const float* scale, int split, void* ws, size_t ws_bytes, void* stream_) {
     XSQ_REQUIRE(P && x && coef && ws, "xsq_slicqt_forward: null argument");
     XSQ_REQUIRE(!xin || (mean && scale), "xsq_slicqt_forward_xin: xin needs the mean / scale tables");
-    XSQ_REQUIRE(!xin || (P->band_radix4 && P->nbands4), "xsq_slicqt_forward_xin: needs the radix-4 band path");
     XSQ_REQUIRE(BC > 0 && n > 0, "xsq_slicqt_forward: BC=%d n=%lld", BC, (long long)n);
     hipStream_t stream = (hipStream_t)stream_;
     const int S = xsq_plan_num_slices(P, n);

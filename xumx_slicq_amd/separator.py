@@ -134,8 +134,6 @@ class Separator(nn.Module):
                 or audio.device.type != "cuda":
             return self.nsgt(audio), False
         eng = self.nsgt.nsgt.nsgt
-        if not getattr(eng, "_band_radix4", True):
-            return self.nsgt(audio), False
         S = eng.plan.num_slices(audio.shape[-1])
         ws, mean, scale, split = self.xumx_model.whitening_target(audio.device, audio.shape[0], S)
         arena, lead, S = eng.forward(audio, whiten=(ws.data_ptr(), mean, scale, split))
