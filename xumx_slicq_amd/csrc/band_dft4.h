@@ -8,9 +8,10 @@
 // The four quarters x[t1 + a m] are contiguous in memory, so the butterflies cost 8 independent 8-byte
 // loads per lane and K-step and happen in registers on the way into LDS.
 //
-// One workgroup = 4 wavefronts; wave r owns residue r for a tile of 64 rows x 64 real columns (32 k's):
-// all four waves read the same B fragments (DFT_m) and their own A fragments (y_r), 32 MFMAs per wave and
-// K-step between barriers.  LDS: 2 x (4 x 64 + 64) rows x 20 floats = 51,200 B -> 3 workgroups per CU.
+// One workgroup = 4 wavefronts on a tile of 64 rows x 64 real columns (32 k's; N tails of 16, 32 or 48 columns): wave w
+// owns rows 16 w .. 16 w + 15 for all four residues (see the MFMA section), all waves read the same B fragments
+// (DFT_m), up to 64 MFMAs per wave and K-step between barriers.
+// LDS: 2 x (4 x 64 + 64) rows x 20 floats = 51,200 B -> 3 workgroups per CU.
 //
 // FWD (analysis, nsgt/nsgtf.py:50-81 closed form F*):  x[q] = g'[q] * U~[bin0 + (q + Lg/2) mod Lg]
 //      (window, sign and 1/Lg folded into g'; Hermitian reflection outside [0, L/2]), inverse-DFT sign,
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    const bool wide = t.narrow == 0;
-    const Band4Dev& bd = a.bands[t.group];
+    const int ncb = t.narrow;                  // 16-column blocks of this tile, 1..4 (uniform)
+    const Band4Dev bd = a.bands[t.group];      // by value: see the epilogue
     const int m_ = bd.m, Lg = bd.Lg, K = 2 * m_, M = a.BC * a.S;
     const int64_t BCS = (int64_t)a.BC * a.S;
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     const int mpad = (m_ + 7) & ~7;
     const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
     const float* bp = a.pool + bd.d_off + (int64_t)(t.n0 + s_row) * bd.ldd + 4 * s_kq;
-    const bool b_on = wide || s_row < 32;
+    const bool b_on = s_row < 16 * ncb;
 
     // Operand staging.  load_set only ISSUES loads -- unconditionally, from clamped addresses, nothing consumed --
     // so that the K-step's ~9 loads per lane are in flight together while the previous step's MFMAs run; every
@@ -240,34 +241,43 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     store_set(0);
     __syncthreads();
     int cur = 0;
-    const int ncb = wide ? 4 : 2;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const bool more = k0 + 16 < K;
-        if (more) load_set(k0 + 16);
+    // One K-step of one wave: 4 A fragments (its 16 rows, four residues) and 4 B fragments from LDS, then 16 MFMAs per
+    // 16-column block of the tile, the block loop OUTERMOST: one uniform branch per block.  (With the width test in
+    // front of every MFMA pair -- the innermost position -- the K-step carried 40 scalar branches between its 64 MFMAs;
+    // a switch over four fully specialised K-steps spilled 60 registers.)  MFMA j takes k = 4 (l >> 4) + j of the
+    // chunk, i.e. every MFMA spans the whole K-step: a ragged last K-step (K = 2m not a multiple of 16) cannot skip any.
+    auto k_step = [&]() {
         const float* As = As0 + cur * 4 * D4_BM * D4_LD + (wave * 16 + l16) * D4_LD + 4 * kq;     // + residue * D4_BM * D4_LD
         const float* Bs = Bs0 + cur * 64 * D4_LD + l16 * D4_LD + 4 * kq;                          // + 16 cb * D4_LD
         float4 av[4], bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) av[r] = *reinterpret_cast<const float4*>(As + r * D4_BM * D4_LD);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) bv[cb] = cb < ncb ? *reinterpret_cast<const float4*>(Bs + 16 * cb * D4_LD) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cb = 0; cb < 4; ++cb) bv[cb] = *reinterpret_cast<const float4*>(Bs + 16 * cb * D4_LD);   // zero rows past the tile's width
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int cb = 0; cb < 4; ++cb) {
+            if (cb >= ncb) break;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ax = j == 0 ? av[r].x : j == 1 ? av[r].y : j == 2 ? av[r].z : av[r].w;
+            for (int j = 0; j < 4; ++j) {
+                const float bx = j == 0 ? bv[cb].x : j == 1 ? bv[cb].y : j == 2 ? bv[cb].z : bv[cb].w;
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    if (cb >= 2 && !wide) break;
-                    const float bx = j == 0 ? bv[cb].x : j == 1 ? bv[cb].y : j == 2 ? bv[cb].z : bv[cb].w;
+                for (int r = 0; r < 4; ++r) {
+                    const float ax = j == 0 ? av[r].x : j == 1 ? av[r].y : j == 2 ? av[r].z : av[r].w;
                     if (XSQ_D4_ABL & 1) { acc[r][cb][j] += ax * bx; continue; }
                     acc[r][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc[r][cb], 0, 0, 0);
                 }
             }
-        if (more) store_set(cur ^ 1);
+        }
+    };
+    int k0 = 0;
+    for (; k0 + 16 < K; k0 += 16) {
+        load_set(k0 + 16);
+        k_step();
+        store_set(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    k_step();      // the band's last K-step: nothing to stage, no barrier behind it
 
     // ---- epilogue: register rr of acc[r][cb] is row 16 w + 4 (l >> 4) + rr, column l & 15 = (k', Re / Im) of residue r,
     // i.e. output q = 4 (k0 + 8 cb + k') + r.  Even lanes end up with (q, q + 1) = residues 0, 1, odd lanes with
@@ -276,9 +286,30 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
     auto swap1 = [](float v) {                   // value of lane l ^ 1 (DPP quad_perm [1, 0, 3, 2])
         return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     };
+    // Everything the stores need is in registers before the first one is issued: the band descriptor is a by-value
+    // copy (through the reference into a.bands the compiler had to RE-LOAD its fields after every store -- they might
+    // alias -- and each reload's s_waitcnt vmcnt(0) also waited for the store before it: one HBM round trip per
+    // 16-byte store, half of the kernel's time, measured with the XSQ_D4_ABL builds), and the four row bases are
+    // computed once.
+    float* rowp[4];
+    bool rok[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int mrow = t.m0 + wave * 16 + 4 * kq + rr;
+        rok[rr] = mrow < M;
+        const int mr = rok[rr] ? mrow : 0;
+        if (!FWD && a.row_len) {
+            rowp[rr] = a.dst + 2 * ((int64_t)mr * a.row_len + bd.ent);
+        } else {
+            const int rb = mr / a.S, rs = mr - rb * a.S;
+            rowp[rr] = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg);
+        }
+    }
+    float* const xin = FWD ? a.xin : nullptr;
+    const bool split = a.split;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-        if (cb >= 2 && !wide) break;
+        if (cb >= ncb) break;
         const int k = e_k + 8 * cb;
         const int q = 4 * k + 2 * e_odd;
         const bool on = k < m_;
@@ -293,20 +324,13 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_kernel(Band4Args a, 
             const float y = swap1(e_odd ? acc[1][cb][rr] : acc[3][cb][rr]);      //                    Im of residue 1,          Re of residue 3
             float4 v = e_odd ? make_float4(x, acc[2][cb][rr], y, acc[3][cb][rr]) : make_float4(acc[0][cb][rr], x, acc[1][cb][rr], y);
             v.x *= e_w[cb][0]; v.y *= e_w[cb][0]; v.z *= e_w[cb][1]; v.w *= e_w[cb][1];
-            const int mrow = t.m0 + wave * 16 + 4 * kq + rr;
-            if (!on || mrow >= M) continue;
-            float* d;
-            if (!FWD && a.row_len) {
-                d = a.dst + 2 * ((int64_t)mrow * a.row_len + bd.ent + pos);
-            } else {
-                const int rb = mrow / a.S, rs = mrow - rb * a.S;
-                d = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg + pos);
-            }
+            if (!on || !rok[rr]) continue;
+            float* const d = rowp[rr] + 2 * pos;
             if (!(XSQ_D4_ABL & 16) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(d) = v;
-            if (FWD && a.xin) {
+            if (FWD && xin) {
                 float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
-                if (a.split) bf3_words2(o.x, o.y, o.x, o.y);
-                *reinterpret_cast<float2*>(a.xin + ((d - a.dst) >> 1)) = o;
+                if (split) bf3_words2(o.x, o.y, o.x, o.y);
+                *reinterpret_cast<float2*>(xin + ((d - a.dst) >> 1)) = o;
             }
         }
     }

@@ -470,6 +470,29 @@ struct CdaeL4Op {
         float2* Y2 = a.Y ? reinterpret_cast<float2*>(a.Y) + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST : nullptr;
         float* Mk = a.masks ? a.masks + (int64_t)a.Bn * 8 * a.S * g.cum + (int64_t)g.tgt * a.Bn * 2 * FST : nullptr;
         const int off = c * FST + dt;
+        if (!Y2 && rowb + 32 <= g.M && perb >= 32) {
+            // masks only (inference), every row of the block valid (uniform): eight stores back to back.  In the general
+            // loop below the load of X sits between the stores and each row is a divergent region; the s_waitcnt vmcnt(0)
+            // the compiler places at the top of every region (for the bias, for X) is executed whether or not anything
+            // was loaded, and waits for the previous row's STORE: one round trip per row.  The T = 16 .. 60 bands -- a
+            // third of all tiles -- go through this function only.
+            const int m0 = rowb + 4 * q16;
+            const int b0 = rowb / perb;                       // uniform; at most one batch boundary inside 32 rows
+            const int obase = m0 * g.hop + b0 * FST + off, ocut = (b0 + 1) * perb - m0;
+            float mk[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[rb][r] = __builtin_amdgcn_rcpf(1.f + __expf(-(acc[rb][r] + bias)));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dm = 16 * rb + r;
+                    Mk[obase + dm * g.hop + (dm >= ocut ? FST : 0)] = mk[rb][r];
+                }
+            return;
+        }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll

@@ -150,6 +150,8 @@ struct BandFwdOp {
         const bool c0 = n < g.N, c1 = wide && n + 32 < g.N;
         int bc = row0 / S, s = row0 - bc * S;          // one division per lane, then carry
         int prev = 0;
+        // loaded BEFORE the first store: a load between two stores makes the compiler wait for the store as well
+        const float mu = xin ? mean[g.j] : 0.f, sc = xin ? scale[g.j] : 1.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s += acc_row(r) - prev; prev = acc_row(r);
@@ -161,7 +163,6 @@ struct BandFwdOp {
             if (xin) {       // uniform.  Column n = 2t + (re/im): the even lane of a pair forms |c| and stores it
                 const float o0 = __shfl_xor(a0[r], 1), o1 = __shfl_xor(a1[r], 1);
                 if (!(n & 1)) {
-                    const float mu = mean[g.j], sc = scale[g.j];
                     float* x = xin + ((d - coef) >> 1);
                     if (c0) { float v = whiten_mag(a0[r], o0, mu, sc); if (split) v = bf3_word(v); x[0] = v; }
                     if (c1) { float v = whiten_mag(a1[r], o1, mu, sc); if (split) v = bf3_word(v); x[16] = v; }
@@ -273,7 +274,7 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
     return XSQ_OK;
 }
 
-// radix-4 kernel tiles: 64 rows x 64 (or 32) real columns of the m-point DFT
+// radix-4 kernel tiles: 64 rows x 64 (N tail: 16, 32 or 48) real columns of the m-point DFT
 // `share` > 0 (masked synthesis): rows r and r + share, r + 2*share, ... read the same mix rows (the targets of one
 // (sample, channel, slice)); their tiles are made neighbours so the mix is fetched once per XCD.  When share is not a
 // multiple of the tile height the last tile of a copy runs into the next copy's first rows and recomputes them
@@ -289,7 +290,7 @@ static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) 
         const int N = 2 * P->bands4_m[i];
         for (int m0 = 0; m0 < span; m0 += D4_BM)
             for (int n0 = 0; n0 < N; n0 += 64)
-                for (int k = 0; k < copies; ++k) t.push_back(TileDev{i, m0 + k * span, n0, (N - n0 <= 32) ? 1 : 0});
+                for (int k = 0; k < copies; ++k) t.push_back(TileDev{i, m0 + k * span, n0, (std::min(64, N - n0) + 15) / 16});   // narrow = 16-column blocks
     }
     TileTable tt;
     int rc = upload_tiles(t, &tt);
