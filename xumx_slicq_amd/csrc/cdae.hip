@@ -203,12 +203,33 @@ struct CdaeL1Op {
         r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
         return r;
     }
+    // k = (ci*kf + df)*T + dt.  The cursor keeps dt, df and the element offset (ci*F + df)*Ti of the segment; a step of
+    // 16 crosses at most one segment boundary (T >= 16).
+    struct Cursor { int k, dt, df, off; };
+    __device__ Cursor cursor(const Group& g, int k) const {
+        Cursor c;
+        const int seg = k / g.T, ci = seg / g.kf;
+        c.k = k; c.dt = k - seg * g.T; c.df = seg - ci * g.kf;
+        c.off = (ci * g.F + c.df) * g.Ti;                      // < 2^31: the input arena holds fewer floats (launch check)
+        return c;
+    }
+    __device__ void advance(const Group& g, Cursor& c) const {
+        c.k += 16; c.dt += 16;
+        if (c.dt >= g.T) {
+            c.dt -= g.T; c.off += g.Ti;
+            if (++c.df == g.kf) { c.df = 0; c.off += (g.F - g.kf) * g.Ti; }
+        }
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, const Cursor& c) const { return load_at(g, r, c.k, c.off, c.dt); }
     __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r.p == nullptr || k >= g.K) return v;
         const int seg = k / g.T, dt = k - seg * g.T;          // seg = ci*kf + df
         const int ci = seg / g.kf, df = seg - ci * g.kf;
-        const float* p = r.p + ((int64_t)ci * g.F + df) * g.Ti + dt;
+        return load_at(g, r, k, (ci * g.F + df) * g.Ti, dt);
+    }
+    __device__ float4 load_at(const Group& g, const RowA& r, int k, int off, int dt) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r.p == nullptr || k >= g.K) return v;
+        const float* p = r.p + (off + dt);
         if (!a.causal) {                                       // 8-byte aligned: hop even, dt % 4 == 0
             const float2 lo = *reinterpret_cast<const float2*>(p);
             const float2 hi = *reinterpret_cast<const float2*>(p + 2);

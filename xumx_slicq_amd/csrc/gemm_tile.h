@@ -39,6 +39,15 @@ struct NoAux {};
 template <class Op, class = void> struct aux_of { typedef NoAux type; static constexpr bool on = false; };
 template <class Op> struct aux_of<Op, std::void_t<typename Op::Aux>> { typedef typename Op::Aux type; static constexpr bool on = true; };
 
+// Optional K cursor of an operator whose operand address is an expensive function of k (layer 1: two integer
+// divisions by run-time values per load -- 80 of the 180 vector instructions of its K-step, in a kernel whose K-step
+// holds 770 cycles of MFMAs).  The engine asks for the operand of k = s_kq, s_kq + 16, s_kq + 32, ... in that order:
+// `Cursor cursor(g, k)` positions a cursor, `load_a4(g, row, cursor)` loads through it, `advance(g, cursor)` moves it
+// 16 further; the operator keeps the k-dependent part of the address incrementally.
+struct NoCursor {};
+template <class Op, class = void> struct cursor_of { typedef NoCursor type; static constexpr bool on = false; };
+template <class Op> struct cursor_of<Op, std::void_t<typename Op::Cursor>> { typedef typename Op::Cursor type; static constexpr bool on = true; };
+
 // Blocks b and b+8 share an XCD (observed round-robin placement; speed only, never
 // correctness).  Tiles that are neighbours in the table share the B matrix of their group and
 // often their A rows, so they should meet in one XCD's 4 MiB L2 -- but the work per tile varies
@@ -105,15 +114,19 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     // (Measured: issuing the loads unconditionally -- out-of-range addresses redirected to a zero buffer so that
     // the compiler can count the loads in flight instead of waiting with vmcnt(0) -- made the short-K operators
     // SLOWER (layer 1: 0.74 -> 0.85 ms): two extra load sets per tile and a 64-bit select per address.)
-    auto load_set = [&](int set, int k) {          // set is a compile-time constant at every call site
+    typename cursor_of<Op>::type kc;               // k = s_kq + 16 * (number of load_set calls so far)
+    if constexpr (cursor_of<Op>::on) kc = op.cursor(g, s_kq);
+    auto load_set = [&](int set, int k) {          // set is a compile-time constant at every call site; k advances by 16 per call
         if (k < K) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 if (!(XSQ_ABLATE & 2) || k == 0) {
-                    ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
+                    if constexpr (cursor_of<Op>::on) ga[set][i] = op.load_a4(g, ra[i], kc);
+                    else ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
                     if constexpr (aux_of<Op>::on) gx[set][i] = op.load_aux(g, ra[i], k + s_kq);
                 }
             if (b_on && (!(XSQ_ABLATE & 4) || k == 0)) gb[set] = *reinterpret_cast<const float4*>(bp + k);
+            if constexpr (cursor_of<Op>::on) op.advance(g, kc);
         }
     };
     auto store_set = [&](int set, int buf) {
