@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    const bool wide = t.narrow == 0;          // wave-uniform
+    // wave-uniform.  XW = 1 operators have N = 52: one tile, always the full width -- a compile-time fact, or the K-step
+    // carries both MFMA sequences and 16 accumulator copies where their register assignments meet
+    const bool wide = XW == 1 ? true : t.narrow == 0;
     const int kind = XW == 2 ? t.narrow : (wide ? 0 : 1);
     const typename Op::Group g = op.group(t.group);
     const int K = (XSQ_ABLATE & 32) ? 16 : g.K;      // bit 5: one K-step only (epilogue cost in isolation)
