@@ -40,7 +40,7 @@ def scan(asm):
 
 
 def main():
-    files = sys.argv[1:] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    files = [os.path.abspath(f) for f in sys.argv[1:]] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     for f in files:
         with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
             subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, f, "-o", tmp.name], check=True, cwd=CSRC,
