@@ -116,7 +116,7 @@ def test_rocfft_and_lds_fft_backends_agree(fb, oracle_plan):
 
 
 def test_radix4_band_kernel_matches_dense_gemm(fb, oracle_plan):
-    """Bands with Lg >= 64 run on the radix-4 DFT kernel by default; the dense grouped GEMM is the
+    """Bands with Lg >= 48 run on the radix-4 DFT kernel by default; the dense grouped GEMM is the
     reference implementation of the same sums."""
     from oracle import slicqt as O
     base, enc, dec = fb
@@ -148,7 +148,7 @@ def test_radix4_band_kernel_matches_dense_gemm(fb, oracle_plan):
 
 @pytest.mark.parametrize("n,lead", [(70000, (1, 2)), (9031, (4, 1, 2)), (30000, (2, 2))])
 def test_short_bands_in_kernel_equal_the_dense_gemm_path(fb, n, lead):
-    """Inverse transform A/B: bands with Lg < 64 synthesised inside the slice-FFT kernel (radix-4 stage + 4..15-point
+    """Inverse transform A/B: bands with Lg < 48 synthesised inside the slice-FFT kernel (radix-4 stage + 4..15-point
     codelets; an opt-in experiment) against the dense DFT-matrix GEMM with its workspace round trip (default);
     even/odd slice counts, odd and even output row offsets (the fused overlap-add takes 8-byte stores only on
     aligned rows)."""

@@ -35,7 +35,7 @@ struct xsq_plan {
     std::vector<xsq::BandDev> bands;
     std::vector<xsq::BlockHost> blocks;
     // device tables
-    int band_radix4 = 1;            // 1: bands with Lg >= 64 run on the radix-4 kernel (band_dft4.h), 0: all on the dense GEMM
+    int band_radix4 = 1;            // 1: bands with Lg >= 48 (XSQ_D4_MIN_LG_DEFAULT) run on the radix-4 kernel (band_dft4.h), 0: all on the dense GEMM
     void* d_bands4 = nullptr;       // Band4Dev table of the eligible bands
     float* d_pool4f = nullptr;      // DFT_m matrices, twiddles, windows: analysis direction
     float* d_pool4i = nullptr;      //                                     synthesis direction
@@ -45,7 +45,7 @@ struct xsq_plan {
     float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)
     int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap
     int phase_begin[5] = {0, 0, 0, 0, 0};
-    // short bands (Lg < 64) synthesised inside k_slice_irfft (slice_fft.h: ShortSched); valid when short_n1 > 0
+    // short bands (below the radix-4 split) synthesised inside k_slice_irfft (slice_fft.h: ShortSched); valid when short_n1 > 0
     int short_inline = 0;           // 0 (default, faster as measured): short bands on the dense GEMM + Z round trip (band_synthesis_gemm)
     void *d_s_item1 = nullptr, *d_s_tw1 = nullptr;
     int *d_s_item2 = nullptr, *d_s_tgt = nullptr;

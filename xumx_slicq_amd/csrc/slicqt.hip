@@ -380,8 +380,10 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
+// Bands at least this long take the radix-4 kernel, shorter ones the dense engine.  Measured with the full-width kernel
+// (r03o, sum of the four band kernels): 64 -> 1.53 ms, 48 -> 1.485, 32 -> 1.49, 16 -> 1.53.
 #ifndef XSQ_D4_MIN_LG_DEFAULT
-#define XSQ_D4_MIN_LG_DEFAULT 64
+#define XSQ_D4_MIN_LG_DEFAULT 48
 #endif
 #ifndef XSQ_FFT_NT_FWD
 #define XSQ_FFT_NT_FWD 512
@@ -569,7 +571,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
             XSQ_HIP(hipMemcpy(P->d_bands, P->bands.data(), P->bands.size() * sizeof(BandDev), hipMemcpyHostToDevice));
         }
     }
-    {   // ---- radix-4 band kernel tables (band_dft4.h): bands with Lg >= 64 -------------------------
+    {   // ---- radix-4 band kernel tables (band_dft4.h): bands with Lg >= d4_min_lg -------------------------
         std::vector<Band4Dev> b4;
         std::vector<float> pf, pi;      // analysis / synthesis pools
         // bands at least this long take the radix-4 kernel (XSQ_D4_MIN_LG: diagnostic A/B of the split point)

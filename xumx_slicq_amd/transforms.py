@@ -62,7 +62,7 @@ class SliCQEngine:
             _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(self._band_radix4)), "xsq_plan_set_band_radix4")
 
     def set_short_inline(self, on: bool):
-        """False (default): bands with Lg < 64 on the dense GEMM with a round trip through the workspace; True: the inverse
+        """False (default): bands with Lg < 48 on the dense GEMM with a round trip through the workspace; True: the inverse
         transform synthesises them inside the slice-FFT kernel (A/B switch, same results to fp32 rounding; measured slower)."""
         self._short_inline = bool(on)
         for h in self._handles.values():
