@@ -54,8 +54,11 @@ template <class Op> struct cursor_of<Op, std::void_t<typename Op::Cursor>> { typ
 // by 20x across groups, so an XCD must not own one contiguous eighth of the table.  Deal the
 // table out in chunks of 16 tiles: chunk c goes to XCD c % 8.  Bijective for any grid size
 // (the ragged tail of fewer than 128 tiles keeps the identity order).
+#ifndef XSQ_XCD_CHUNK
+#define XSQ_XCD_CHUNK 16      // diagnostic builds: -DXSQ_XCD_CHUNK=n
+#endif
 __device__ inline int xcd_remap(int bid, int nblocks) {
-    constexpr int G = 16;
+    constexpr int G = XSQ_XCD_CHUNK;
     const int full = (nblocks / (8 * G)) * (8 * G);
     if (bid >= full) return bid;
     const int x = bid & 7, l = bid >> 3;
