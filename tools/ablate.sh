@@ -1,6 +1,6 @@
 # Diagnostic: build ablated variants of the library and time the bench with each (results of the
 # ablated builds are wrong by construction; only their timings matter).  Run on the GPU box.
-# FLAG = the ablation macro (XSQ_ABLATE: gemm_tile.h, XSQ_D4_ABL: band_dft4.h), VARIANTS = its values, SHOW = kernel-name filters.
+# FLAG = the ablation macro (XSQ_ABLATE: gemm_tile.h / slice_fft.h, XSQ_SLAB_ABL: cdae_slab.h), VARIANTS = its values, SHOW = kernel-name filters.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/xumx_slicq_amd/csrc
 for v in ${VARIANTS:-0 1 2 4 6 8 14 15}; do

@@ -274,34 +274,12 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
     return XSQ_OK;
 }
 
-// radix-4 kernel tiles: 64 rows x 64 (N tail: 16, 32 or 48) real columns of the m-point DFT
+// tiles of the radix-4 kernel (band_dft4_full_kernel): 32 rows x every column of the band; TileDev.narrow = number of
+// 16-column blocks.
 // `share` > 0 (masked synthesis): rows r and r + share, r + 2*share, ... read the same mix rows (the targets of one
 // (sample, channel, slice)); their tiles are made neighbours so the mix is fetched once per XCD.  When share is not a
 // multiple of the tile height the last tile of a copy runs into the next copy's first rows and recomputes them
 // (same values, written twice).
-static int get_dft4_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) {
-    std::lock_guard<std::mutex> lk(P->mu);
-    auto key = std::make_tuple(1, rows, share);
-    auto it = P->tiles.find(key);
-    if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
-    std::vector<TileDev> t;
-    const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
-    for (int i = P->nbands4 - 1; i >= 0; --i) {
-        const int N = 2 * P->bands4_m[i];
-        for (int m0 = 0; m0 < span; m0 += D4_BM)
-            for (int n0 = 0; n0 < N; n0 += 64)
-                for (int k = 0; k < copies; ++k) t.push_back(TileDev{i, m0 + k * span, n0, (std::min(64, N - n0) + 15) / 16});   // narrow = 16-column blocks
-    }
-    TileTable tt;
-    int rc = upload_tiles(t, &tt);
-    if (rc) return rc;
-    P->tiles[key] = tt;
-    *out = tt;
-    return XSQ_OK;
-}
-
-// tiles of the full-width radix-4 kernel (band_dft4_full_kernel): 32 rows x every column of the band; TileDev.narrow =
-// number of 16-column blocks.  `share` as above.
 static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) {
     std::lock_guard<std::mutex> lk(P->mu);
     auto key = std::make_tuple(3, rows, share);
@@ -320,11 +298,6 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
     P->tiles[key] = tt;
     *out = tt;
     return XSQ_OK;
-}
-
-static bool d4_full() {      // XSQ_D4_FULL=0: diagnostic A/B against the 64 x 64-tile kernel
-    static const bool on = [] { const char* e = getenv("XSQ_D4_FULL"); return !e || atoi(e) != 0; }();
-    return on;
 }
 
 static int get_fft(xsq_plan* P, int inverse, int batch, FftPlan* out) {
@@ -839,12 +812,11 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
     BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L, xin, mean, scale, split};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
-        rc = d4_full() ? get_dft4_full_tiles(P, rows, &t4) : get_dft4_tiles(P, rows, &t4);
+        rc = get_dft4_full_tiles(P, rows, &t4);
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0, xin, mean, scale, split};
         XSQ_PROF("band_analysis_dft4", stream);
-        if (d4_full()) hipLaunchKernelGGL(band_dft4_full_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
-        else hipLaunchKernelGGL(band_dft4_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+        hipLaunchKernelGGL(band_dft4_full_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
     if (tt.ntiles) { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
@@ -912,13 +884,12 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
     if (P->band_radix4 && P->nbands4) {
         TileTable t4;
-        rc = d4_full() ? get_dft4_full_tiles(P, rows, &t4, mask ? BCx * S : 0) : get_dft4_tiles(P, rows, &t4, mask ? BCx * S : 0);
+        rc = get_dft4_full_tiles(P, rows, &t4, mask ? BCx * S : 0);
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
                      lds_fft(P) ? (int)P->sumFT : 0, mask, BCx, nullptr, nullptr, nullptr, 0};
         XSQ_PROF("band_synthesis_dft4", stream);
-        if (d4_full()) hipLaunchKernelGGL(band_dft4_full_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
-        else hipLaunchKernelGGL(band_dft4_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+        hipLaunchKernelGGL(band_dft4_full_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
     }
     // short bands: inside k_slice_irfft when the plan allows it, else dense GEMM + Z round trip
     const bool inl = lds_fft(P) && P->band_radix4 && P->short_inline && P->short_n1 > 0;
