@@ -152,6 +152,35 @@ def pmc_traffic(kernel, tag=None):
     return (int(total / steps), launches / steps) if launches else None
 
 
+def pmc_issue(kernel, tag=None):
+    """What the SQ counters of the committed rocprofv3 pass say bounds `kernel` (profiles/*_pmc_sq.csv, the same command
+    as this bench): vector-ALU issue utilisation = 4 cycles x SQ_INSTS_VALU over the SIMD cycles of the kernel's busy
+    time (SQ_BUSY_CYCLES is summed over the 32 shader engines; 1024 SIMDs), matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES
+    over the same base, and the share of wave cycles spent in s_waitcnt.  None without a committed profile."""
+    import csv
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.csv"))
+                   if (tag is None) == ("wiener" not in os.path.basename(f)))
+    if not files or kernel not in _PMC_NAMES:
+        return None
+    tot = {}
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if row["Kernel"] in _PMC_NAMES[kernel]:
+                for c in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"):
+                    try:
+                        tot[c] = tot.get(c, 0.0) + float(row[c])
+                    except (KeyError, ValueError):
+                        return None
+                break          # the summary repeats a kernel once per launch shape: the first row is the main launch
+    if not tot or tot["SQ_BUSY_CYCLES"] <= 0 or tot["SQ_WAVE_CYCLES"] <= 0:
+        return None
+    return {"valu_issue": round(tot["SQ_INSTS_VALU"] / (8.0 * tot["SQ_BUSY_CYCLES"]), 3),
+            "mfma_busy": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * tot["SQ_BUSY_CYCLES"]), 3),
+            "waitcnt_share_of_wave_cycles": round(tot["SQ_WAIT_INST_ANY"] / tot["SQ_WAVE_CYCLES"], 3),
+            "source": os.path.basename(files[-1])}
+
+
 def cpu_baseline(threads):
     """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this
     box's host cores on a bounded sample: one 30 s clip through the same configuration."""
@@ -189,12 +218,12 @@ def roofline_tables(work, prof_step, steps_in_prof, wiener=False):
             tr = pmc_traffic(k, "wiener" if wiener else None)
             hbm.append({"kernel": k, "ms_per_step": round(ms / steps_in_prof, 4), "achieved": round(ach, 1), "unit": "GB/s",
                         "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(amount),
-                        "traffic_per_step": tr[0] if tr else None})
+                        "traffic_per_step": tr[0] if tr else None, "pmc": pmc_issue(k, "wiener" if wiener else None)})
         else:
             ach = amount / sec / 1e12
             mfma.append({"kernel": k, "ms_per_step": round(ms / steps_in_prof, 4), "achieved": round(ach, 2), "unit": "TFLOP/s",
                          "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "algorithmic_flops_per_step": int(amount)})
+                         "algorithmic_flops_per_step": int(amount), "pmc": pmc_issue(k, "wiener" if wiener else None)})
     return hbm, mfma
 
 
