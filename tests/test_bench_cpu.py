@@ -1,0 +1,49 @@
+"""bench.py's bookkeeping on CPU: the algorithmic-work numerators, the BASELINE configs[3] workload
+definition, and the lookups into the committed rocprofv3 summaries that fill `roofline.traffic` and `pmc`."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from xumx_slicq_amd.plan import build_plan  # noqa: E402
+
+
+def test_testset_is_fifty_seeded_lengths_in_range():
+    a, b = bench.testset_lengths(), bench.testset_lengths()
+    assert a == b and len(a) == 50
+    assert all(150 * 44100 <= n <= 420 * 44100 for n in a)
+    assert abs(sum(a) / 44100 - 13514) < 1.0          # the duration DESIGN.md / README.md quote
+
+
+def test_algorithmic_work_of_the_bench_track():
+    plan = build_plan()
+    chunk, n = 2621440, 10584000
+    w = bench.algorithmic_work(plan, 1, [chunk] * 4 + [n - 4 * chunk], wiener=True)
+    # every instrumented kernel of the default path has a numerator of the right kind
+    for k in ("slice_rfft", "slice_irfft_ola", "wiener_stats", "wiener_apply"):
+        assert w[k][0] == "hbm" and w[k][1] > 0
+    for k in ("band_analysis_dft4", "band_synthesis_dft4", "cdae_l1_gemm", "cdae_l2_slab", "cdae_l3_slab", "cdae_l4_gemm"):
+        assert w[k][0] == "mfma" and w[k][1] > 0
+    # the synthesis transforms four targets, the analysis one mix; layer 3 is counted like layer 2 (per input position)
+    assert w["band_synthesis_dft4"][1] == 4 * w["band_analysis_dft4"][1]
+    assert w["cdae_l3_slab"][1] == w["cdae_l2_slab"][1]
+    # the figures DESIGN.md section 4 quotes (GFLOP per 240 s track)
+    assert abs(w["cdae_l2_slab"][1] / 1e9 - 112.3) < 0.5
+    assert abs(w["cdae_l1_gemm"][1] / 1e9 - 46.4) < 0.5
+    # radix-4 split point: the bands at or above XSQ_D4_MIN_LG_DEFAULT carry 97 % of the band-DFT flops
+    Lg = np.asarray(plan.Lg, dtype=np.int64)
+    assert abs((Lg[Lg >= 48] ** 2).sum() / (Lg ** 2).sum() - 0.970) < 0.005
+
+
+def test_committed_profiles_fill_the_traffic_and_counter_fields():
+    tr = bench.pmc_traffic("cdae_l3_slab")
+    assert tr is not None
+    per_step, launches = tr
+    assert launches >= 1 and 0.8e9 < per_step / launches < 2.0e9      # ~1.2 GB per launch against 1.0 GB of activations
+    pm = bench.pmc_issue("cdae_l3_slab")
+    assert pm is not None and 0.4 < pm["mfma_busy"] <= 1.0 and 0.0 < pm["valu_issue"] < 1.0
+    fft = bench.pmc_issue("slice_irfft_ola")
+    assert fft is not None and fft["mfma_busy"] == 0.0 and fft["valu_issue"] > 0.4     # a vector-ALU kernel
+    assert bench.pmc_traffic("no_such_kernel") is None and bench.pmc_issue("no_such_kernel") is None
