@@ -323,7 +323,13 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     }
 #undef XSQ_MF
 
-    if (XSQ_SLAB_ABL & 16) { if (acc0[0] + acc1[1] + acc0[7] == 1.2345e-30f) __builtin_trap(); return; }
+    if (XSQ_SLAB_ABL & 16) {      // every accumulator set of the mode stays live (or its MFMAs would be removed with the epilogue)
+        float sacc = acc0[0] + acc0[7];
+        if constexpr (EXW) sacc += acc16[0][1] + acc16[1][2] + accv[0] + accv[1] + accv[2] + accv[3];
+        else sacc += acc1[1];
+        if (sacc == 1.2345e-30f) __builtin_trap();
+        return;
+    }
     if constexpr (EXW) {
         // (the slot loop ended on a barrier: the slab planes are free; each wave transposes its 32 x 52 block through
         //  6.6 KB of them and stores it as whole 16-byte lanes -- relu_shift_epilogue_xw, cdae.hip)
