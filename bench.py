@@ -349,11 +349,12 @@ def instrumented_warmup(step, warmup, serial=None):
     ones build tile tables etc.).  `serial(flag)`: called with True around that step so that the caller can
     take the short tail pass off its side stream -- a kernel timed while another stream's kernels share the
     chip reads long, and the per-kernel roofline fractions are meant per kernel.  Returns {kernel: (ms,
-    launches)} of that step, or None."""
+    launches)} of that step."""
     import torch
     from xumx_slicq_amd import _lib
     _lib.profile_filter(None)
     _lib.profile_enable(True)
+    warmup = max(warmup, 1)       # the roofline needs one instrumented (untimed) step even with --warmup 0
     for i in range(warmup):
         last = i == warmup - 1
         if last:
@@ -366,7 +367,7 @@ def instrumented_warmup(step, warmup, serial=None):
             torch.cuda.synchronize()
             serial(False)
     torch.cuda.synchronize()
-    return _lib.profile_read() if warmup >= 2 else None
+    return _lib.profile_read()
 
 
 def bench_track(args, sep, dev, world, rank, dist):
@@ -389,7 +390,7 @@ def bench_track(args, sep, dev, world, rank, dist):
 
     prof_all = instrumented_warmup(step, args.warmup, None if args.graph else serial)
     dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
-    _lib.profile_filter(dom)            # None (fewer than two warm-up steps): every kernel stays instrumented
+    _lib.profile_filter(dom)
     _lib.profile_reset()
     dt, out = timed_steps(step, args.steps, world, dist, dev)
     prof = _lib.profile_read()          # the dominant kernel only, over the timed region
