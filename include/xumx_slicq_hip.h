@@ -196,6 +196,14 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
                   int B, int S, int win_len, int batch_group, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* ---- placement of packed stems (sharded path) -------------------------------------------------
+ * Replaces the hard torch.cat of separator.py:229-231 for stems that were computed on OTHER ranks and arrive packed
+ * in an all-gather buffer (xumx_slicq_amd/sharding.py): row i of the table is copied as
+ *   dst[table[3i+1] : + table[3i+2]] = src[table[3i] : + table[3i+2]]      (float offsets / lengths)
+ * in ONE launch for all rows (item x target x sample x channel) of an exchange.  table: DEVICE int64[nrows][3];
+ * max_len = the largest row length (sizes the grid).  Rows must not overlap in dst.                     */
+int xsq_place_rows(const float* src, float* dst, const int64_t* table, int nrows, int64_t max_len, void* stream);
+
 /* ---- loss forward (validation half of training.loop, training.py:34-112 with train=False) -------
  * Replaces ComplexMSELossCriterion (loss.py:37-76) and MaskSumLossCriterion (loss.py:79-96).
  *   pred, target  complex arenas, 8*B channels (4 targets, B, 2, ...)

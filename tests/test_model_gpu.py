@@ -474,6 +474,38 @@ def test_per_block_call_matches_the_grouped_launch_and_the_reference_masks(seps)
         blk(X[1], abs_of_real_complex(X[1]))
 
 
+@pytest.mark.parametrize("realtime", [False, True])
+@pytest.mark.parametrize("F_,T_", [(3, 4), (12, 8), (25, 12), (7, 20), (21, 16)])
+def test_blocks_with_short_windows_match_the_oracle(F_, T_, realtime):
+    """Blocks outside the Bark-262 plan (whose shortest window is 16): T = 4, 8, 12 make a 16-value K-step of layer 1
+    cross several (channel, frequency-tap) segments -- the operand cursor has to follow (csrc/cdae.hip, CdaeL1Op)."""
+    from oracle import model as omodel
+    from xumx_slicq_amd.model import _SlicedUnmixCDAE
+    from xumx_slicq_amd.phase import abs_of_real_complex
+    torch.manual_seed(100 * F_ + T_)
+    B, S = 2, 6
+    blk = _SlicedUnmixCDAE(torch.zeros(B, 2, F_, S, T_), realtime=realtime)
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():
+            if k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand_like(v))
+            elif k.endswith(("running_mean", "input_mean")):
+                v.copy_(0.1 * torch.randn_like(v))
+            elif k.endswith("input_scale"):
+                v.copy_(0.5 + torch.rand_like(v))
+    blk = blk.cuda()
+    blk.freeze()
+    X = torch.randn(B, 2, F_, S, T_, 2)
+    mag = abs_of_real_complex(X)
+    Y, M = blk(X.cuda(), mag.cuda())
+    sd = {"sliced_umx.0." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    want = omodel.cdae_masks(sd, 0, mag, causal=realtime)               # (4, B, 2, F, S, T)
+    assert M.shape == want.shape
+    assert float((M.cpu() - want).abs().max()) < 5e-5, (F_, T_, realtime, float((M.cpu() - want).abs().max()))
+    if realtime:                                 # mix-phase estimate = mask * X (offline blocks go on through Wiener-EM)
+        assert float((Y.cpu() - want.unsqueeze(-1) * X).abs().max()) < 5e-4
+
+
 def test_graph_cache_follows_parameter_and_postfilter_changes(seeded_sd):
     """A captured forward holds raw pointers into the model handle: after load_state_dict / a post-filter switch
     the stale graph must be dropped, not replayed (it would run the old weights out of freed memory)."""

@@ -81,16 +81,27 @@ def test_shard_plan_rounds_cover_every_item_once():
             for k, rnd in enumerate(plan.rounds):
                 for r, placed in enumerate(rnd):
                     assert len(placed) <= stack
-                    end = 0
-                    for p in placed:                          # packed back to back, inside the round's width
-                        assert p.offset == end
-                        end += 8 * p.item.length
-                    assert end <= plan.width[k]
+                    end = [0, 0]
+                    for p in placed:                          # packed back to back per exchange (full pass / tails)
+                        assert p.part == (0 if p.item.length == 600 else 1)
+                        assert p.offset == end[p.part]
+                        end[p.part] += 8 * p.item.length
+                    assert end[0] <= plan.width[k][0] and end[1] <= plan.width[k][1]
                     # passes: equal lengths only, every item exactly once
                     ps = plan.passes(k, r)
                     assert sorted(id(p) for g in ps for p in g) == sorted(id(p) for p in placed)
                     assert all(len({p.item.length for p in g}) == 1 for g in ps)
             assert plan.imbalance() >= 1.0
+            # exchange accounting: one collective per non-empty (round, part); a rank receives every other rank's block
+            ex = plan.exchanges()
+            assert ex == [(k, p) for k in range(len(plan.rounds)) for p in (0, 1)
+                          if any(q.part == p for per_rank in plan.rounds[k] for q in per_rank)]
+            acct = plan.exchange_bytes()
+            assert acct["collectives_per_step"] == len(ex)
+            assert acct["bytes_in_per_rank_per_step"] == sum(4 * (world - 1) * plan.width[k][p] for k, p in ex)
+            stems = 32 * sum(lengths)
+            assert acct["stem_bytes_in_per_rank_per_step"] <= acct["bytes_in_per_rank_per_step"] or world == 1
+            assert acct["stem_bytes_in_per_rank_per_step"] <= stems
 
 
 def test_sharded_demixer_single_process_places_every_chunk():

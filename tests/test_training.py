@@ -231,7 +231,16 @@ def test_optimizer_state_round_trip_and_incremental_sync():
     for _ in range(2):
         tr.step(x, y_t)
     opt, params = tr.optimizer_state_dict(), tr.state_dict()
-    assert opt["step"] == 2 and float(opt["exp_avg_sq"]["sliced_umx.1.cdaes.0.3.weight"].abs().sum()) > 0
+    # torch.optim.AdamW's own layout: the reference's optimizer loads it and hands it back unchanged
+    keys = [k for k in params if not k.endswith(("running_mean", "running_var"))]
+    assert sorted(opt) == ["param_groups", "state"] and opt["param_groups"][0]["params"] == list(range(len(keys)))
+    i3 = keys.index("sliced_umx.1.cdaes.0.3.weight")
+    assert float(opt["state"][i3]["step"]) == 2.0 and float(opt["state"][i3]["exp_avg_sq"].abs().sum()) > 0
+    topt = torch.optim.AdamW([torch.nn.Parameter(params[k].clone()) for k in keys], lr=1e-3, weight_decay=1e-5)
+    topt.load_state_dict(opt)
+    back = topt.state_dict()
+    assert all(torch.equal(back["state"][i]["exp_avg"], opt["state"][i]["exp_avg"]) for i in (0, i3, len(keys) - 1))
+    opt = back                                    # resume from what torch re-emits
     tr.step(x, y_t)
     want = tr.state_dict()
     sep2, tr2 = _trainer(False)

@@ -79,6 +79,7 @@ _SIGS = {
     "xsq_train_write": (C.c_int, [_vp, C.c_int, _vp]),
     "xsq_train_step_count": (C.c_int64, [_vp, C.c_int64]),
     "xsq_train_set_precision": (C.c_int, [_vp, C.c_int]),
+    "xsq_place_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),
     "xsq_profile_filter": (C.c_int, [C.c_char_p]),

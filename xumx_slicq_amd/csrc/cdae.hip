@@ -204,7 +204,8 @@ struct CdaeL1Op {
         return r;
     }
     // k = (ci*kf + df)*T + dt.  The cursor keeps dt, df and the element offset (ci*F + df)*Ti of the segment; a step of
-    // 16 crosses at most one segment boundary (T >= 16).
+    // 16 crosses one segment boundary at most when T >= 16 (every Bark-262 block) and several for T = 4, 8, 12, which
+    // xsq_model_create accepts: hence a loop.
     struct Cursor { int k, dt, df, off; };
     __device__ Cursor cursor(const Group& g, int k) const {
         Cursor c;
@@ -215,7 +216,7 @@ struct CdaeL1Op {
     }
     __device__ void advance(const Group& g, Cursor& c) const {
         c.k += 16; c.dt += 16;
-        if (c.dt >= g.T) {
+        while (c.dt >= g.T) {
             c.dt -= g.T; c.off += g.Ti;
             if (++c.df == g.kf) { c.df = 0; c.off += (g.F - g.kf) * g.Ti; }
         }

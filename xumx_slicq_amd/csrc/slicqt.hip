@@ -783,6 +783,9 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
     const int rows = BC * S;
     XSQ_REQUIRE(S >= 2, "xsq_slicqt_forward: signal too short");
     XSQ_REQUIRE((int64_t)BC * S <= 65535, "xsq_slicqt_forward: BC*S=%lld rows exceed one launch", (long long)BC * S);
+    // band_dft4.h addresses the slice spectra and the arena through 32-bit float offsets
+    XSQ_REQUIRE((int64_t)2 * BC * S * (P->sumFT > P->nbins ? P->sumFT : P->nbins) < (1ll << 31),
+                "xsq_slicqt_forward: BC*S=%lld rows exceed 2^31 floats of coefficients; split the call", (long long)BC * S);
     FftPlan f;
     int rc = lds_fft(P) ? XSQ_OK : get_fft(P, 0, rows, &f);
     if (rc) return rc;
@@ -863,6 +866,9 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     XSQ_REQUIRE(length <= (int64_t)2 * S * P->h, "xsq_slicqt_inverse: length %lld exceeds the %d slices",
                 (long long)length, S);
     XSQ_REQUIRE((int64_t)BC * S <= 65535, "xsq_slicqt_inverse: BC*S=%lld rows exceed one launch", (long long)BC * S);
+    // the band kernels carry arena offsets in 32 bits (band_dft4.h: xoff / moff; the mix arena is the smaller one)
+    XSQ_REQUIRE((int64_t)2 * BC * S * P->sumFT < (1ll << 31), "xsq_slicqt_inverse: the coefficient arena of BC*S=%lld rows "
+                "exceeds 2^31 floats; split the call (fewer stacked chunks)", (long long)BC * S);
     hipStream_t stream = (hipStream_t)stream_;
     const int rows = BC * S;
     FftPlan f;

@@ -38,8 +38,10 @@ def separate_and_evaluate(separator: Separator, track, device: Union[str, torch.
     estimates = {k: v[0].detach().cpu().numpy().T for k, v in estimates.items()}      # (T, C), as museval wants them
     try:
         import museval
+    except ImportError:                 # only the import: an error INSIDE museval must not turn into the other metric
+        museval = None
+    if museval is not None:
         return {"metric": "museval-bsseval-v4", "scores": museval.eval_mus_track(track, estimates), "estimates": estimates}
-    except ImportError:
-        scores = {name: global_sdr(np.asarray(track.targets[name].audio), est)
-                  for name, est in estimates.items() if name in getattr(track, "targets", {})}
-        return {"metric": "global-sdr", "scores": scores, "estimates": estimates}
+    scores = {name: global_sdr(np.asarray(track.targets[name].audio), est)
+              for name, est in estimates.items() if name in getattr(track, "targets", {})}
+    return {"metric": "global-sdr", "scores": scores, "estimates": estimates}

@@ -150,19 +150,33 @@ def demix_sharded(separate_chunk: Callable[[Tensor], Tensor], tracks: Sequence[T
 # BASELINE configs[3]: a set of tracks as one chunk batch over the ranks, stems all-gathered
 # --------------------------------------------------------------------------------------------------
 class _Done:
+    """Handle of the host-staged (gloo) exchange: ``wait()`` orders the CURRENT stream behind the copy of the
+    gathered block into device memory (issued on the stream that was current when the exchange ran)."""
+
+    def __init__(self, event=None):
+        self.event = event
+
     def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
         return True
 
 
 def all_gather_stems(recv: Tensor, send: Tensor, group=None, async_op: bool = True):
     """``dist.all_gather_into_tensor`` (RCCL over xGMI with the ``nccl`` backend: device buffers, asynchronous on
-    the backend's stream).  With the ``gloo`` backend -- CPU tests, and two ranks sharing the one GPU of a test
-    box, which RCCL refuses -- device tensors are staged through the host (functional path only)."""
-    if send.device.type == "cuda" and dist.get_backend(group) == "gloo":
-        h_send = send.cpu()
-        h_recv = torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_gather_into_tensor(h_recv, h_send, group=group)
-        recv.copy_(h_recv)
+    the backend's stream; ``send`` may be this rank's slice of ``recv`` -- the in-place form, no local copy).  With
+    the ``gloo`` backend -- CPU tests, and two ranks sharing the one GPU of a test box, which RCCL refuses -- device
+    tensors are staged through the host (functional path only)."""
+    if dist.get_backend(group) == "gloo":
+        if send.device.type == "cuda":
+            h_send = send.cpu()                                    # synchronises the producing stream
+            h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(h_recv, h_send, group=group)
+            recv.copy_(h_recv)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(recv.device))
+            return _Done(ev)
+        dist.all_gather_into_tensor(recv, send.clone(), group=group)     # host tensors: no aliasing of in / out
         return _Done()
     return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
 
@@ -170,7 +184,8 @@ def all_gather_stems(recv: Tensor, send: Tensor, group=None, async_op: bool = Tr
 @dataclass(frozen=True)
 class PlacedItem:
     item: WorkItem
-    offset: int          # float offset of the item's packed stems (4, nb, 2, length) in its rank's round buffer
+    part: int            # exchange of the round the item travels in: 0 = the stacked full-size pass, 1 = the short tails
+    offset: int          # float offset of the item's packed stems (4, nb, 2, length) in its rank's block of that exchange
 
 
 class ShardPlan:
@@ -178,8 +193,13 @@ class ShardPlan:
     rank's queue cut into rounds of ``stack`` items (longest first, so the full-size chunks of a round form
     one stacked pass and the short tails come last), and per round the packed send layout.
 
-    Round k of rank r packs its items back to back as (4, nb, 2, length_i) row blocks; the round's buffer
-    width is the largest packed size over the ranks (ranks with less send padding that nobody reads)."""
+    A round has up to two exchanges ("parts"), one per KIND of pass, so that a pass's stems leave as soon as the
+    pass has finished: part 0 carries the round's full-size chunks (one stacked pass), part 1 its short tails.
+    In part p of round k rank r packs its items back to back as (4, nb, 2, length_i) row blocks; the block width
+    is the largest packed size over the ranks (ranks with less send padding that nobody reads), and a part that is
+    empty on every rank does not exist (``width[k][p] == 0``)."""
+
+    PARTS = 2
 
     def __init__(self, track_lengths: Sequence[int], chunk_size: int, world_size: int, nb_samples: int = 1,
                  stack: int = 4):
@@ -188,18 +208,19 @@ class ShardPlan:
         self.queues = assign_lpt(chunk_items(self.lengths, self.chunk_size), self.world)
         nrounds = max((len(q) + self.stack - 1) // self.stack for q in self.queues) if self.queues else 0
         self.rounds: List[List[List[PlacedItem]]] = []      # [round][rank] -> placed items
-        self.width: List[int] = []                          # floats per rank in round k
+        self.width: List[List[int]] = []                    # [round][part] -> floats per rank
         for k in range(nrounds):
-            per_rank, width = [], 0
+            per_rank, width = [], [0] * self.PARTS
             for q in self.queues:
-                off, placed = 0, []
+                off, placed = [0] * self.PARTS, []
                 for it in q[k * self.stack:(k + 1) * self.stack]:
-                    placed.append(PlacedItem(it, off))
-                    off += 8 * self.nb * it.length
+                    part = 0 if it.length == self.chunk_size else 1
+                    placed.append(PlacedItem(it, part, off[part]))
+                    off[part] += 8 * self.nb * it.length
                 per_rank.append(placed)
-                width = max(width, off)
+                width = [max(w, o) for w, o in zip(width, off)]
             self.rounds.append(per_rank)
-            self.width.append((width + 63) // 64 * 64)      # 256-byte granules
+            self.width.append([(w + 63) // 64 * 64 for w in width])      # 256-byte granules
         self.audio_seconds = sum(self.lengths)
 
     def passes(self, k: int, rank: int) -> List[List[PlacedItem]]:
@@ -208,6 +229,20 @@ class ShardPlan:
         for p in self.rounds[k][rank]:
             groups.setdefault(p.item.length, []).append(p)
         return [groups[n] for n in sorted(groups, reverse=True)]
+
+    def exchanges(self) -> List[tuple]:
+        """(round, part) of every exchange of a step, in issue order (the same on every rank)."""
+        return [(k, p) for k in range(len(self.rounds)) for p in range(self.PARTS) if self.width[k][p] > 0]
+
+    def exchange_bytes(self) -> Dict[str, int]:
+        """What one step moves per rank: bytes a rank RECEIVES from the others (incl. the padding of ragged blocks),
+        the bytes of stems among them, and the number of collectives."""
+        ex = self.exchanges()
+        wire = sum(4 * (self.world - 1) * self.width[k][p] for k, p in ex)
+        loads = [sum(32 * self.nb * i.length for i in q) for q in self.queues]
+        return {"collectives_per_step": len(ex), "bytes_in_per_rank_per_step": wire,
+                "stem_bytes_in_per_rank_per_step": sum(loads) - min(loads) if self.world > 1 else 0,
+                "largest_collective_bytes_per_rank": max((4 * self.width[k][p] for k, p in ex), default=0)}
 
     def imbalance(self) -> float:
         """max rank load / mean rank load (1.0 = perfectly balanced)."""
@@ -220,18 +255,24 @@ class ShardedDemixer:
 
     ``separator``: a ``Separator`` (``demix_into`` is the compute step).  ``get_chunk(item)`` returns the
     (nb_samples, 2, item.length) audio of a work item, resident on this rank's device (a rank only ever asks
-    for its own items).  All buffers (send / receive rounds, the per-track result tensors) are allocated once;
+    for its own items).  All buffers (the exchange blocks, the per-track result tensors) are allocated once;
     ``run()`` may be called repeatedly (the bench's steps) and returns {track: (4, nb_samples, 2, N_t)}.
 
-    gather=True  : every rank ends up holding every track (RCCL all-gather of the stems, then placement).
+    gather=True  : every rank ends up holding every track.  The kernels of a pass write its stems into this rank's
+                   slice of the exchange block, ONE in-place ``all_gather_into_tensor`` per pass kind and round is issued
+                   right behind them (RCCL over xGMI, asynchronous: it runs beside the next pass's kernels), and ONE
+                   placement launch per exchange (``xsq_place_rows``) moves every row of every rank into the per-track
+                   tensors on a side stream -- the final waveform concat of separator.py:231.
     gather=False : the kernels write this rank's items straight into the result tensors; chunks computed by
-                   other ranks stay zero (no data-path collective)."""
+                   other ranks stay zero (no data-path collective).
+    solo=True    : ignore the process group and run the whole set on this rank (world = 1): the single-GPU
+                   rate on the same workload."""
 
     def __init__(self, separator, track_lengths: Sequence[int], get_chunk: Callable[[WorkItem], Tensor],
                  device: torch.device, group: Optional[dist.ProcessGroup] = None, gather: bool = True,
-                 nb_samples: int = 1, stack: int = 4, only_rank: Optional[int] = None):
+                 nb_samples: int = 1, stack: int = 4, solo: bool = False):
         self.sep, self.get_chunk, self.dev, self.group, self.gather = separator, get_chunk, torch.device(device), group, gather
-        live = dist.is_initialized() and only_rank is None
+        live = dist.is_initialized() and not solo
         self.world = dist.get_world_size(group) if live else 1
         self.rank = dist.get_rank(group) if live else 0
         self.plan = ShardPlan(track_lengths, separator.chunk_size, self.world, nb_samples, stack)
@@ -245,10 +286,16 @@ class ShardedDemixer:
             self.track_off.append(self.track_off[-1] + 8 * nb * n)
         self.flat = torch.zeros(self.track_off[-1], dtype=dt, device=self.dev)
         self.out = {t: self.flat[self.track_off[t]:self.track_off[t + 1]].view(4, nb, 2, lens[t]) for t in range(len(lens))}
+        self.recv: Dict[tuple, Tensor] = {}       # (round, part) -> (world * width) floats, rank-major
+        self.send: Dict[tuple, Tensor] = {}       # this rank's slice of it: what the kernels write (in-place all-gather)
+        self._place: Dict[tuple, tuple] = {}      # (round, part) -> (row table on the device, rows, longest row)
         if self.gather:
-            self.send = [torch.zeros(w, dtype=dt, device=self.dev) for w in self.plan.width]
-            self.recv = [torch.empty(self.world * w, dtype=dt, device=self.dev) for w in self.plan.width]
-        self._offs = {}       # (round, pass) -> (audio builder inputs, row-offset tensor)
+            for key in self.plan.exchanges():
+                w = self.plan.width[key[0]][key[1]]
+                self.recv[key] = torch.zeros(self.world * w, dtype=dt, device=self.dev)
+                self.send[key] = self.recv[key][self.rank * w:(self.rank + 1) * w]
+                self._place[key] = self._place_table(*key)
+        self._offs = {}       # (round, pass) -> row-offset tensor
         self._place_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self._tail_stream = None
 
@@ -265,24 +312,42 @@ class ShardedDemixer:
                     for b in range(nb):
                         for c in range(2):
                             r = (tg * nb + b) * 2 + c
-                            if self.gather:       # packed (4, nb, 2, length) block of the round buffer
+                            if self.gather:       # packed (4, nb, 2, length) block of the exchange buffer
                                 rows[tg, i * nb + b, c] = p.offset + r * it.length
                             else:                 # final position inside the track's (4, nb, 2, N_t)
                                 rows[tg, i * nb + b, c] = self.track_off[it.track] + r * self.plan.lengths[it.track] + it.start
             t = self._offs[key] = rows.to(self.dev)
         return t
 
+    def _place_table(self, k: int, part: int):
+        """Row table of one exchange for xsq_place_rows: every (rank, item, target, sample, channel) row of the
+        gathered block -> its span of the flat per-track allocation."""
+        nb, w = self.plan.nb, self.plan.width[k][part]
+        rows = []
+        for r in range(self.world):
+            for p in self.plan.rounds[k][r]:
+                if p.part != part:
+                    continue
+                it = p.item
+                for row in range(8 * nb):
+                    rows.append((r * w + p.offset + row * it.length,
+                                 self.track_off[it.track] + row * self.plan.lengths[it.track] + it.start, it.length))
+        table = torch.tensor(rows, dtype=torch.int64).reshape(-1, 3)
+        return table.to(self.dev), len(rows), max((r[2] for r in rows), default=0)
+
     def _run_pass(self, k: int, pi: int, placed: Sequence[PlacedItem]):
-        target = self.send[k] if self.gather else self.flat
+        target = self.send[(k, placed[0].part)] if self.gather else self.flat
         audio = [self.get_chunk(p.item) for p in placed]
         audio = audio[0] if len(audio) == 1 else torch.cat(audio, dim=0)
         self.sep.demix_into(audio, target, self._row_offsets(k, pi, placed), group=self.plan.nb)
 
     def _is_tail(self, placed: Sequence[PlacedItem]) -> bool:
-        return placed[0].item.length < self.plan.chunk_size
+        return placed[0].part == 1
 
-    def _compute_round(self, k: int, skip_tails: bool = False):
+    def _compute_round(self, k: int, part: Optional[int] = None, skip_tails: bool = False):
         for pi, placed in enumerate(self.plan.passes(k, self.rank)):
+            if part is not None and placed[0].part != part:
+                continue
             if not (skip_tails and self._is_tail(placed)):
                 self._run_pass(k, pi, placed)
 
@@ -290,13 +355,13 @@ class ShardedDemixer:
         """The short last chunks of the tracks are launch-bound passes (a dozen kernels of a few hundred workgroups):
         like ``Separator.forward`` does for one track, they go out FIRST, on a side stream with its own workspaces, and
         fill in beside the stacked passes; the caller's stream joins before the first collective that carries one.
-        Returns the first round that holds a tail (None: nothing was moved)."""
+        Returns True when tails were moved."""
         if self.dev.type != "cuda":
-            return None
+            return False
         tails = [(k, pi, placed) for k in range(len(self.plan.rounds))
                  for pi, placed in enumerate(self.plan.passes(k, self.rank)) if self._is_tail(placed)]
         if not tails:
-            return None
+            return False
         if self._tail_stream is None:
             self._tail_stream = torch.cuda.Stream(device=self.dev)
         main = torch.cuda.current_stream(self.dev)
@@ -304,40 +369,48 @@ class ShardedDemixer:
         with torch.cuda.stream(self._tail_stream):
             for k, pi, placed in tails:
                 self._run_pass(k, pi, placed)
-        return min(k for k, _, _ in tails)
+        return True
 
-    def _place_round(self, k: int):
-        """recv[k] (rank-major packed blocks) -> the per-track tensors: the hard concat by placement."""
-        nb, w = self.plan.nb, self.plan.width[k]
-        for r in range(self.world):
-            for p in self.plan.rounds[k][r]:
-                it = p.item
-                src = self.recv[k][r * w + p.offset: r * w + p.offset + 8 * nb * it.length].view(4, nb, 2, it.length)
-                self.out[it.track][..., it.start:it.start + it.length].copy_(src)
+    def _place_exchange(self, key):
+        """recv[key] (rank-major packed blocks) -> the per-track tensors: the hard concat by placement, one launch."""
+        table, nrows, longest = self._place[key]
+        if nrows == 0:
+            return
+        if self.dev.type == "cuda":
+            from . import _lib
+            _lib.check(_lib.lib.xsq_place_rows(self.recv[key].data_ptr(), self.flat.data_ptr(), table.data_ptr(),
+                                               nrows, longest, _lib.stream_ptr()), "xsq_place_rows")
+            return
+        src = self.recv[key]                      # host tensors: the gloo tests' stand-in separator
+        for so, do, n in table.tolist():
+            self.flat[do:do + n].copy_(src[so:so + n])
 
     @torch.no_grad()
     def run(self) -> Dict[int, Tensor]:
         nrounds = len(self.plan.rounds)
         cuda = self.dev.type == "cuda"
         main = torch.cuda.current_stream(self.dev) if cuda else None
-        first_tail = self._tails_on_side_stream()
-        moved = first_tail is not None
+        moved = self._tails_on_side_stream()
         if not self.gather:
             for k in range(nrounds):
                 self._compute_round(k, skip_tails=moved)
             if moved:
                 main.wait_stream(self._tail_stream)
             return self.out
-        pending = []
-        for k in range(nrounds):
-            self._compute_round(k, skip_tails=moved)
-            if moved and k >= first_tail:
-                main.wait_stream(self._tail_stream)       # this round's buffer also holds tails computed on the side stream
-            # async: the collective waits for this round's kernels on the backend's own stream and runs beside
-            # the next round's kernels; the placement of the round before is queued behind its collective on a
+        pending, joined = [], False
+        for key in self.plan.exchanges():
+            k, part = key
+            if part == 1 and moved:
+                if not joined:                            # every tail of the step was issued up front on the side stream
+                    main.wait_stream(self._tail_stream)
+                    joined = True
+            else:
+                self._compute_round(k, part=part)
+            # async: the collective waits for this pass's kernels on the backend's own stream and runs beside
+            # the next pass's kernels; the placement of the exchange before is queued behind its collective on a
             # side stream, so the host never blocks here with RCCL
-            work = all_gather_stems(self.recv[k], self.send[k], group=self.group, async_op=True)
-            pending.append((k, work))
+            work = all_gather_stems(self.recv[key], self.send[key], group=self.group, async_op=True)
+            pending.append((key, work))
             if len(pending) > 1:
                 self._finish(*pending.pop(0))
         while pending:
@@ -346,11 +419,11 @@ class ShardedDemixer:
             main.wait_stream(self._place_stream)
         return self.out
 
-    def _finish(self, k: int, work):
+    def _finish(self, key, work):
         if self._place_stream is None:
             work.wait()
-            self._place_round(k)
+            self._place_exchange(key)
             return
         with torch.cuda.stream(self._place_stream):
             work.wait()              # NCCL/RCCL: a stream-level wait of the place stream on the collective
-            self._place_round(k)
+            self._place_exchange(key)

@@ -132,22 +132,64 @@ class Trainer:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib.xsq_train_write(self._h, what, buf.ctypes.data), "xsq_train_write")
 
+    def _trainable(self):
+        """Keys of ``unmix.parameters()`` in the order torch.optim.AdamW numbers them (training.py:391-393): the
+        state_dict order without the BatchNorm running statistics (buffers)."""
+        return [k for k, _ in self._spec if not k.endswith(("running_mean", "running_var"))]
+
     def optimizer_state_dict(self) -> dict:
-        """What ``optimizer.state_dict()`` holds in the reference's checkpoints (training.py:419-430): the AdamW
-        step counter and both moments, keyed like the parameters (running statistics carry zeros)."""
+        """``torch.optim.AdamW.state_dict()`` as the reference checkpoints it (training.py:419-430, :526): ``state``
+        {parameter index: {step, exp_avg, exp_avg_sq}} over ``unmix.parameters()`` and ONE entry in ``param_groups``
+        (lr, betas, eps, weight_decay, params) -- a reference ``.chkpnt``'s ``checkpoint["optimizer"]`` loads here and
+        what is saved here loads into the reference's optimizer.  Before the first step ``state`` is empty, as torch's."""
         step = int(_lib.lib.xsq_train_step_count(self._h, -1))
-        return {"step": step, "exp_avg": self._read(2), "exp_avg_sq": self._read(3),
-                "lr": self.lr, "weight_decay": self.weight_decay}
+        if step < 0:
+            raise _lib.XsqError(f"xsq_train_step_count failed ({step}): {_lib.last_error()}")
+        keys = self._trainable()
+        state = {}
+        if step > 0:
+            m, v = self._read(2), self._read(3)
+            state = {i: {"step": torch.tensor(float(step)), "exp_avg": m[k], "exp_avg_sq": v[k]} for i, k in enumerate(keys)}
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(keys)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, state: dict):
-        """Resume: restores the moments and the step counter, so bias correction continues where it stopped."""
-        self._write(2, state["exp_avg"])
-        self._write(3, state["exp_avg_sq"])
-        _lib.lib.xsq_train_step_count(self._h, int(state["step"]))
-        self.steps = int(state["step"])
+        """Resume from ``optimizer.state_dict()`` (torch AdamW layout, see above): restores both moments and the step
+        counter, so bias correction continues where it stopped.  One parameter group, one common step count (what a
+        single AdamW over ``unmix.parameters()`` produces); anything else is rejected."""
+        groups = state["param_groups"]
+        keys = self._trainable()
+        if len(groups) != 1 or list(groups[0]["params"]) != list(range(len(keys))):
+            raise ValueError(f"expected one param group over {len(keys)} parameters (torch.optim.AdamW(unmix.parameters()))")
+        g = groups[0]
+        if tuple(g.get("betas", (0.9, 0.999))) != (0.9, 0.999) or float(g.get("eps", 1e-8)) != 1e-8 or g.get("amsgrad", False):
+            raise ValueError("the step implements AdamW with betas (0.9, 0.999), eps 1e-8, amsgrad off (training.py:391-393)")
+        st = state["state"]
+        shapes = dict(self._spec)
+        if st:
+            if sorted(st) != list(range(len(keys))):
+                raise ValueError("optimizer state must cover every parameter (or none)")
+            steps = {int(float(st[i]["step"])) for i in st}
+            if len(steps) != 1:
+                raise ValueError(f"parameters disagree on the step count: {sorted(steps)[:4]}")
+            step = steps.pop()
+        else:
+            step = 0
+        for what, name in ((2, "exp_avg"), (3, "exp_avg_sq")):
+            full = {k: torch.zeros(shapes[k]) for k, _ in self._spec}          # running statistics carry no moments
+            for i, k in enumerate(keys):
+                if st:
+                    full[k] = st[i][name]
+            self._write(what, full)
+        rc = int(_lib.lib.xsq_train_step_count(self._h, step))
+        if rc < 0:
+            raise _lib.XsqError(f"xsq_train_step_count failed ({rc}): {_lib.last_error()}")
+        self.steps = step
         self._synced = self.steps
-        self.lr = float(state.get("lr", self.lr))
-        self.weight_decay = float(state.get("weight_decay", self.weight_decay))
+        self.lr = float(g.get("lr", self.lr))
+        self.weight_decay = float(g.get("weight_decay", self.weight_decay))
 
     def load_state_dict(self, sd: Dict[str, Tensor]):
         """Parameters + running statistics from a (reference-layout) state_dict."""
