@@ -61,7 +61,7 @@ def testset_lengths(ntracks=TESTSET_TRACKS):
 def algorithmic_work(plan, B, chunk_lengths, wiener):
     """Per-kernel ALGORITHMIC work of one pass over the given chunks: name -> (bound, amount)
     in bytes (hbm) or flops (mfma).  Per-unit figures are SURVEY.md 8(d): per channel-slice
-    sliCQT = read 9030*4 + write 18640*8 B; CDAE flops formula; Wiener 160 B per TF point."""
+    sliCQT = read 9030*4 + write 18640*8 B; CDAE flops formula; Wiener-EM 48 + 112 B per TF point (from the masks)."""
     L, nbins, sumFT = plan.L, plan.L // 2 + 1, plan.coefs_per_slice
     Lg = plan.Lg.astype("int64")
     w = {}
@@ -110,8 +110,12 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         add("irfft_L", "hbm", r8 * nbins * 8 + r8 * L * 4)
         add("overlap_add", "hbm", r8 * L * 4 + 8 * B * n * 4)
         if wiener:
-            add("wiener_stats", "hbm", B * S * sumFT * 80)
-            add("wiener_apply", "hbm", B * S * sumFT * 144)
+            # per time-frequency point (both channels, four targets).  From the masks (default, xsq_wiener_em_masked):
+            # pass 1 reads 8 masks + 2 mix values = 48 B, pass 3 reads the same and writes 8 estimates = 112 B.  The
+            # two-step form (XSQ_WIENER_MASKED=0) reads the 8 complex initial estimates instead: 80 B / 80 + 64 B.
+            masked = os.environ.get("XSQ_WIENER_MASKED", "1") != "0"
+            add("wiener_stats", "hbm", B * S * sumFT * (48 if masked else 80))
+            add("wiener_apply", "hbm", B * S * sumFT * (112 if masked else 144))
     return w
 
 

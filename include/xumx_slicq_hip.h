@@ -204,6 +204,15 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
  * max_len = the largest row length (sizes the grid).  Rows must not overlap in dst.                     */
 int xsq_place_rows(const float* src, float* dst, const int64_t* table, int nrows, int64_t max_len, void* stream);
 
+/* The same EM iteration fed by the MASKS (real arena, 8*B channels: what xsq_cdae_forward writes with Y = NULL): the
+ * initial estimate y0 = mask * x (model.py:262-264 -> phase.py:96-113; == mask * X) is formed
+ * while both passes load, so the CDAE's last layer stores 4 instead of 8 bytes per coefficient and the statistics pass
+ * reads 48 instead of 80 bytes per time-frequency point.  Y is written only (refined estimates); same bits as
+ * xsq_cdae_forward(Y) + xsq_wiener_em.  win_len and every S*T_b must be even (two frames per thread).       */
+int xsq_wiener_em_masked(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* masks,
+                         float* Y, int B, int S, int win_len, int batch_group, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ---- loss forward (validation half of training.loop, training.py:34-112 with train=False) -------
  * Replaces ComplexMSELossCriterion (loss.py:37-76) and MaskSumLossCriterion (loss.py:79-96).
  *   pred, target  complex arenas, 8*B channels (4 targets, B, 2, ...)

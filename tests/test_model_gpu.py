@@ -474,6 +474,33 @@ def test_per_block_call_matches_the_grouped_launch_and_the_reference_masks(seps)
         blk(X[1], abs_of_real_complex(X[1]))
 
 
+def test_wiener_from_masks_is_bitwise_the_two_step_form(seps):
+    """xsq_wiener_em_masked (layer 4 stores masks, the EM passes form mask * X on the way in) against
+    xsq_cdae_forward(Y) + xsq_wiener_em: same bits, incl. several windows per block and stacked chunks with their own
+    window maxima."""
+    sep = seps["offline_wiener"]
+    x = synth_audio(460_000, seed=77).cuda()           # S = 52: blocks with T >= 100 get two or more 5000-frame windows
+    old_cs = sep.chunk_size
+    try:
+        for cs in (old_cs, 150_000):                   # one pass / three stacked chunks + tail
+            sep.chunk_size = cs
+            sep.xumx_model.wiener_masked = True
+            a = sep(x).clone()
+            sep.xumx_model.wiener_masked = False
+            b = sep(x).clone()
+            assert torch.equal(a, b), (cs, float((a - b).abs().max()))
+    finally:
+        sep.chunk_size = old_cs
+        sep.xumx_model.wiener_masked = True
+    X = sep.nsgt(x[..., :100_000])
+    sep.xumx_model.wiener_masked = True
+    Ya, Ma = sep.xumx_model(X, return_masks=True)
+    sep.xumx_model.wiener_masked = False
+    Yb, Mb = sep.xumx_model(X, return_masks=True)
+    sep.xumx_model.wiener_masked = True
+    assert all(torch.equal(p, q) for p, q in zip(Ya, Yb)) and all(torch.equal(p, q) for p, q in zip(Ma, Mb))
+
+
 @pytest.mark.parametrize("realtime", [False, True])
 @pytest.mark.parametrize("F_,T_", [(3, 4), (12, 8), (25, 12), (7, 20), (21, 16)])
 def test_blocks_with_short_windows_match_the_oracle(F_, T_, realtime):

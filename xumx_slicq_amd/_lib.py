@@ -85,6 +85,7 @@ _SIGS = {
     "xsq_profile_filter": (C.c_int, [C.c_char_p]),
     "xsq_profile_read": (C.c_int, [C.c_char_p, C.c_size_t, _vp, _vp, C.c_int]),
     "xsq_wiener_em": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "xsq_wiener_em_masked": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

@@ -215,6 +215,144 @@ __global__ __launch_bounds__(256) void k_wiener_apply(const float2* __restrict__
     }
 }
 
+// ---- the same two passes fed by MASKS: y0 = mask * x is formed on the way in ---------------------------------
+// The CDAE's last layer then writes 4 bytes per coefficient instead of 8 (and does not read the mix), pass 1 reads
+// 48 instead of 80 bytes per time-frequency point, pass 3 reads 48 and writes 64 instead of 80 + 64.  The products
+// mask * re, mask * im are the ones the layer-4 epilogue would have stored (one fp32 rounding each), and everything
+// downstream is the same expression tree: bitwise the two-step result.  Two frames per thread (N = S*T and the
+// window length are even on this path): 16-byte loads of the mix, 8-byte loads of the masks, 16-byte stores.
+__device__ inline int64_t ridx(const WRow& r, int nchan, int S, int chan, int64_t n) {      // real arena (masks)
+    return (int64_t)nchan * S * r.cum + ((int64_t)chan * r.F + r.f) * ((int64_t)S * r.T) + n;
+}
+
+__global__ __launch_bounds__(256) void k_wiener_stats_masked(const float2* __restrict__ X, const float* __restrict__ Mk,
+                                                              const WRow* __restrict__ rows, const int* __restrict__ work,
+                                                              float* __restrict__ stats, int Bn, int S, int win_len) {
+    const int row = work[2 * blockIdx.x], w = work[2 * blockIdx.x + 1];
+    const WRow r = rows[row];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n0 = (int64_t)w * win_len;
+    const int64_t n1 = n0 + win_len < N ? n0 + win_len : N;
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+    const float2* x0 = X + cidx(r, 2 * Bn, S, r.b * 2, 0);
+    const float2* x1 = X + cidx(r, 2 * Bn, S, r.b * 2 + 1, 0);
+    const float* m0 = Mk + ridx(r, 8 * Bn, S, r.b * 2, 0);            // target 0, channel 0 of this row
+    const int64_t cstride = (int64_t)r.F * N, jstride = (int64_t)Bn * 2 * cstride;
+    // The reduction keeps the two-step kernel's shape -- lane t adds frames n0 + t, n0 + t + 256, ... in order -- so the
+    // sums round identically; the pair (t, t + 256) is what one thread of THIS kernel owns per 512-frame step.
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+        const float2 a = x0[n], b = x1[n];
+        acc[16] = fmaxf(acc[16], fmaxf(a.x * a.x + a.y * a.y, b.x * b.x + b.y * b.y));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ma = m0[j * jstride + n], mb = m0[j * jstride + cstride + n];
+            const float2 y0 = make_float2(ma * a.x, ma * a.y);
+            const float2 y1 = make_float2(mb * b.x, mb * b.y);
+            const float2 c01 = cmulc(y0, y1);
+            acc[4 * j + 0] += y0.x * y0.x + y0.y * y0.y;
+            acc[4 * j + 1] += y1.x * y1.x + y1.y * y1.y;
+            acc[4 * j + 2] += c01.x;
+            acc[4 * j + 3] += c01.y;
+        }
+    }
+    __shared__ float red[4][17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v, off, 64);
+            v = (i == 16) ? fmaxf(v, o) : v + o;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        const int i = threadIdx.x;
+        float v;
+        if (i == 16) v = fmaxf(fmaxf(red[0][i], red[1][i]), fmaxf(red[2][i], red[3][i]));
+        else v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        stats[r.stat + (int64_t)w * STAT + i] = v;
+    }
+}
+
+// one time-frequency point of pass 3 (shared by both apply kernels: same expression tree, same bits)
+__device__ inline void wiener_point(const float* __restrict__ st, float2 x0, float2 x1, const float2 (&y)[4][2],
+                                    float2 (&o)[4][2]) {
+    const float inv_ma2 = st[16];
+    float v[4];
+    float2 R01[4];
+    float R00[4], R11[4];
+    const float reg = sqrtf(FLT_EPSILON);
+    float c00 = reg, c11 = reg;
+    float2 c01 = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 y0 = y[j][0], y1 = y[j][1];
+        v[j] = 0.5f * ((y0.x * y0.x + y0.y * y0.y) * inv_ma2 + (y1.x * y1.x + y1.y * y1.y) * inv_ma2);
+        R00[j] = st[4 * j]; R11[j] = st[4 * j + 1]; R01[j] = make_float2(st[4 * j + 2], st[4 * j + 3]);
+        c00 += v[j] * R00[j];
+        c11 += v[j] * R11[j];
+        c01.x += v[j] * R01[j].x;
+        c01.y += v[j] * R01[j].y;
+    }
+    const float det = c00 * c11 - (c01.x * c01.x + c01.y * c01.y);
+    const float idet = 1.f / det;
+    const float i00 = c11 * idet, i11 = c00 * idet;
+    const float2 i01 = make_float2(-c01.x * idet, -c01.y * idet);
+    const float2 i10 = make_float2(-c01.x * idet, c01.y * idet);
+    const float2 z0 = make_float2(i00 * x0.x + (i01.x * x1.x - i01.y * x1.y), i00 * x0.y + (i01.x * x1.y + i01.y * x1.x));
+    const float2 z1 = make_float2((i10.x * x0.x - i10.y * x0.y) + i11 * x1.x, (i10.x * x0.y + i10.y * x0.x) + i11 * x1.y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 a = cmul(R01[j], z1);
+        const float2 b = cmulc(z0, R01[j]);
+        o[j][0] = make_float2(v[j] * (R00[j] * z0.x + a.x), v[j] * (R00[j] * z0.y + a.y));
+        o[j][1] = make_float2(v[j] * (b.x + R11[j] * z1.x), v[j] * (b.y + R11[j] * z1.y));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wiener_apply_masked(const float2* __restrict__ X, const float* __restrict__ Mk,
+                                                              float2* __restrict__ Y, const WRow* __restrict__ rows,
+                                                              const float* __restrict__ stats, int Bn, int S, int win_len) {
+    const WRow r = rows[blockIdx.y];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);       // frames n, n + 1 (same window: both even)
+    if (n >= N) return;
+    const float* st = stats + r.stat + (n / win_len) * STAT;
+    const float4 xa = *reinterpret_cast<const float4*>(X + cidx(r, 2 * Bn, S, r.b * 2, n));
+    const float4 xb = *reinterpret_cast<const float4*>(X + cidx(r, 2 * Bn, S, r.b * 2 + 1, n));
+    const int64_t cstride = (int64_t)r.F * N, jstride = (int64_t)Bn * 2 * cstride;
+    const float* m0 = Mk + ridx(r, 8 * Bn, S, r.b * 2, n);
+    float2 ma[4], mb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ma[j] = *reinterpret_cast<const float2*>(m0 + j * jstride);
+        mb[j] = *reinterpret_cast<const float2*>(m0 + j * jstride + cstride);
+    }
+    float2 y[4][2], o0[4][2], o1[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        y[j][0] = make_float2(ma[j].x * xa.x, ma[j].x * xa.y);
+        y[j][1] = make_float2(mb[j].x * xb.x, mb[j].x * xb.y);
+    }
+    wiener_point(st, make_float2(xa.x, xa.y), make_float2(xb.x, xb.y), y, o0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        y[j][0] = make_float2(ma[j].y * xa.z, ma[j].y * xa.w);
+        y[j][1] = make_float2(mb[j].y * xb.z, mb[j].y * xb.w);
+    }
+    wiener_point(st, make_float2(xa.z, xa.w), make_float2(xb.z, xb.w), y, o1);
+    float2* y0p = Y + cidx(r, 8 * Bn, S, r.b * 2, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float4*>(y0p + j * jstride) = make_float4(o0[j][0].x, o0[j][0].y, o1[j][0].x, o1[j][0].y);
+        *reinterpret_cast<float4*>(y0p + j * jstride + cstride) = make_float4(o0[j][1].x, o0[j][1].y, o1[j][1].x, o1[j][1].y);
+    }
+}
+
 // ---- backward of the EM iteration (training: loss.backward() through norbert, training.py:107) --------
 // Notation of the header; per point n: w = Cxx^-1 x, out_j = v_j R_j w.  With gO_j the incoming gradient,
 //   q = sum_j v_j R_j gO_j,  p = Cxx^-1 q,  u_j = gO_j - p,
@@ -510,6 +648,33 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
     { XSQ_PROF("wiener_apply", stream);
     hipLaunchKernelGGL(k_wiener_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
                        (const float2*)X, (float2*)Y, t.d_rows, stats, Bn, S, win_len); }
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+int xsq_wiener_em_masked(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* masks, float* Y,
+                         int Bn, int S, int win_len, int batch_group, void* ws, size_t ws_bytes, void* stream_) {
+    int rc = check_table("xsq_wiener_em_masked", nblocks, F, T, Bn, S);
+    if (rc) return rc;
+    XSQ_REQUIRE(X && masks && Y && ws, "xsq_wiener_em_masked: null argument");
+    XSQ_REQUIRE(win_len > 0 && win_len % 2 == 0, "xsq_wiener_em_masked: win_len=%d must be even (two frames per thread)", win_len);
+    for (int b = 0; b < nblocks; ++b)
+        XSQ_REQUIRE(((int64_t)S * T[b]) % 2 == 0, "xsq_wiener_em_masked: block %d has an odd frame count S*T=%lld", b, (long long)S * T[b]);
+    if (batch_group <= 0) batch_group = Bn;
+    XSQ_REQUIRE(Bn % batch_group == 0, "xsq_wiener_em_masked: batch_group=%d does not divide B=%d", batch_group, Bn);
+    XSQ_REQUIRE(ws_bytes >= xsq_wiener_workspace(nblocks, F, T, Bn, S, win_len), "xsq_wiener_em_masked: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    WTable t;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, batch_group, &t))) return rc;
+    float* stats = (float*)ws;
+    { XSQ_PROF("wiener_stats", stream);
+    hipLaunchKernelGGL(k_wiener_stats_masked, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, masks,
+                       t.d_rows, t.d_work, stats, Bn, S, win_len); }
+    { XSQ_PROF("wiener_finalize", stream);
+    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats); }
+    { XSQ_PROF("wiener_apply", stream);
+    hipLaunchKernelGGL(k_wiener_apply_masked, dim3((unsigned)((t.max_frames / 2 + 255) / 256), t.nrows), dim3(256), 0, stream,
+                       (const float2*)X, masks, (float2*)Y, t.d_rows, stats, Bn, S, win_len); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

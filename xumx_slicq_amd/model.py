@@ -332,7 +332,7 @@ class Unmix(nn.Module):
         [+ masks (4, B, 2, F_b, S, T_b)].  model.py:69-82.  ``wiener_batch_group`` (extension):
         runs of that many batch items share the Wiener window maximum (0 = the whole batch, the
         reference's behaviour); Separator uses it to stack independent chunks along the batch."""
-        from .phase import wiener_em_arena
+        from .phase import wiener_em_arena, wiener_em_masked_arena
         X, lead, S = self.table.as_arena(list(Xcomplex))
         if len(lead) != 2 or lead[1] != 2:
             raise ValueError(f"expected blocks of shape (nb_samples, 2, F, S, T, 2); got lead dims {lead}")
@@ -343,18 +343,25 @@ class Unmix(nn.Module):
         if len(modes) != 1:
             raise _lib.XsqError("mixed per-block post-filters (some mix-phase, some Wiener) are not supported")
         phasemix = modes.pop()
+        # Wiener-EM from the masks (default): the last layer stores the real masks only and both EM passes form the
+        # initial estimate mask * X while they load -- same bits, a third less traffic.  ``wiener_masked = False`` /
+        # XSQ_WIENER_MASKED=0 restores the two-step form (layer 4 writes mask * X, the EM refines it in place).
+        masked = (not phasemix and all(int(t) % 2 == 0 for t in self._T) and
+                  bool(getattr(self, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")))
         with torch.cuda.device(dev):
             Y = torch.empty(self.table.numel(8 * B, S), dtype=torch.float32, device=dev)
             masks = torch.empty(self.table.numel(8 * B, S, complex_=False), dtype=torch.float32,
-                                device=dev) if return_masks else None
+                                device=dev) if (return_masks or masked) else None
             nbytes = _lib.lib.xsq_cdae_workspace(h, B, S)
             if nbytes == 0:
                 raise _lib.XsqError(f"xsq_cdae_workspace(B={B}, S={S}) failed: need at least 3 slices")
             ws = self._workspace(dev, nbytes)
             _lib.check(_lib.lib.xsq_cdae_forward_xin(
-                h, X.data_ptr(), B, S, Y.data_ptr(), masks.data_ptr() if return_masks else None,
+                h, X.data_ptr(), B, S, None if masked else Y.data_ptr(), masks.data_ptr() if masks is not None else None,
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr(), int(bool(xin_ready))), "xsq_cdae_forward")
-            if not phasemix:
+            if masked:
+                wiener_em_masked_arena(self.table, X, masks, Y, B, S, batch_group=wiener_batch_group)
+            elif not phasemix:
                 wiener_em_arena(self.table, X, Y, B, S, batch_group=wiener_batch_group)
         Ylist = self.table.views(Y, (4, B, 2), S)
         if return_masks:

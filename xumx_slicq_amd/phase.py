@@ -56,6 +56,23 @@ def wiener_em_arena(table: BlockTable, X: Tensor, Y: Tensor, B: int, S: int, win
                    "xsq_wiener_em")
 
 
+def wiener_em_masked_arena(table: BlockTable, X: Tensor, masks: Tensor, Y: Tensor, B: int, S: int, win_len: int = 5000,
+                           batch_group: int = 0):
+    """The same iteration fed by the sigmoid masks (real arena, 8B channels): the initial estimate mask * X
+    (model.py:262-264) is formed while the two passes load, Y (8B channels, complex) is only written.
+    Same bits as ``xsq_cdae_forward(Y)`` + ``wiener_em_arena``; a third less HBM traffic."""
+    F, T = _tables(table)
+    with torch.cuda.device(X.device):
+        nbytes = _lib.lib.xsq_wiener_workspace(len(table), F.ctypes.data, T.ctypes.data, B, S, win_len)
+        if nbytes == 0:
+            raise _lib.XsqError("xsq_wiener_workspace: bad arguments")
+        ws = _workspace(X.device, nbytes)
+        _lib.check(_lib.lib.xsq_wiener_em_masked(len(table), F.ctypes.data, T.ctypes.data, X.data_ptr(), masks.data_ptr(),
+                                                 Y.data_ptr(), B, S, win_len, int(batch_group), ws.data_ptr(), ws.numel(),
+                                                 _lib.stream_ptr()),
+                   "xsq_wiener_em_masked")
+
+
 def _one_block(mix_slicqt: Tensor, slicqtgrams: Tensor):
     if mix_slicqt.dim() != 6 or mix_slicqt.shape[-1] != 2 or mix_slicqt.shape[1] != 2:
         raise ValueError(f"mix must be (nb_samples, 2, F, S, T, 2); got {tuple(mix_slicqt.shape)}")

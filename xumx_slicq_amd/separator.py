@@ -80,7 +80,8 @@ class Separator(nn.Module):
                 bool(getattr(self, "overlap_tail", True)), bool(getattr(self, "batch_chunks", True)),
                 int(getattr(self, "max_stack", 8)), int(getattr(self, "pass_streams", 1)),
                 m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused(),
-                bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")))
+                bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")),
+                bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")))
 
     def drop_graphs(self):
         """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
