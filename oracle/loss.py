@@ -45,16 +45,17 @@ def validation_step(plan, sd, x, y_targets):
 TRAINABLE_SUFFIXES = ("input_mean", "input_scale", ".weight", ".bias")
 
 
-def training_gradients(plan, sd, x, y_targets, causal: bool, wiener: bool):
+def training_gradients(plan, sd, x, y_targets, causal: bool, wiener: bool, minima=None):
     """One forward + backward of training.loop (training.py:66-108, train=True, SDR term off, fp32):
     BatchNorm on batch statistics, loss = ComplexMSE + MaskSum, torch autograd.  Returns
-    (loss, mse, mask, {key: grad}) for every trainable tensor of the state_dict."""
+    (loss, mse, mask, {key: grad}) for every trainable tensor of the state_dict.  ``minima`` (optional dict) receives,
+    per BatchNorm key, the smallest |BatchNorm output| of the batch: how close the step came to a ReLU kink."""
     params = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and k.endswith(TRAINABLE_SUFFIXES)) else v)
               for k, v in sd.items()}
     with torch.no_grad():
         X = oslicqt.forward(plan, x)
         Yt = oslicqt.forward(plan, y_targets)
-    Y, masks = omodel.unmix(params, X, causal=causal, wiener=wiener, training=True)
+    Y, masks = omodel.unmix(params, X, causal=causal, wiener=wiener, training=True, minima=minima)
     mse, msk = complex_mse(Y, Yt), mask_sum(masks)
     loss = mse + msk
     loss.backward()

@@ -33,16 +33,19 @@ def abs_of_real_complex(X: torch.Tensor) -> torch.Tensor:
     return torch.sqrt(X[..., 0] ** 2 + X[..., 1] ** 2)
 
 
-def _bn(x, sd, key, training=False):
+def _bn(x, sd, key, training=False, minima=None):
     if training:      # batch statistics (nn.BatchNorm2d in train mode); running stats are not touched here
-        return F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], training=True, eps=BN_EPS)
+        y = F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], training=True, eps=BN_EPS)
+        if minima is not None:       # distance of the closest pre-activation to the ReLU kink (tests: subgradient ambiguity)
+            minima[key] = float(y.detach().abs().min())
+        return y
     return F.batch_norm(
         x, sd[key + ".running_mean"], sd[key + ".running_var"],
         sd[key + ".weight"], sd[key + ".bias"], training=False, eps=BN_EPS)
 
 
 def cdae_masks(sd: Dict[str, torch.Tensor], b: int, mag: torch.Tensor,
-               causal: bool, training: bool = False) -> torch.Tensor:
+               causal: bool, training: bool = False, minima=None) -> torch.Tensor:
     """Sigmoid masks of the four target CDAEs of block ``b``.
 
     mag (B, 2, F, S, T) fp32 -> (4, B, 2, F, S, T).  model.py:213-261 (whiten
@@ -59,11 +62,11 @@ def cdae_masks(sd: Dict[str, torch.Tensor], b: int, mag: torch.Tensor,
         p = f"{pre}cdaes.{t}."
         y = F.pad(x, (T - 1, 0)) if causal else x
         y = F.conv2d(y, sd[p + "0.weight"], stride=(1, hop))
-        y = F.relu(_bn(y, sd, p + "1", training))
+        y = F.relu(_bn(y, sd, p + "1", training, minima))
         y = F.conv2d(y, sd[p + "3.weight"])
-        y = F.relu(_bn(y, sd, p + "4", training))
+        y = F.relu(_bn(y, sd, p + "4", training, minima))
         y = F.conv_transpose2d(y, sd[p + "6.weight"])
-        y = F.relu(_bn(y, sd, p + "7", training))
+        y = F.relu(_bn(y, sd, p + "7", training, minima))
         y = F.conv_transpose2d(y, sd[p + "9.weight"], sd[p + "9.bias"], stride=(1, hop))
         y = torch.sigmoid(y)
         y = y[..., :Fb, : S * T]
@@ -129,7 +132,7 @@ def blockwise_wiener(X: torch.Tensor, Ymag: torch.Tensor,
 
 
 def unmix(sd: Dict[str, torch.Tensor], X_list: List[torch.Tensor],
-          causal: bool, wiener: bool, training: bool = False) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+          causal: bool, wiener: bool, training: bool = False, minima=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """model.py:69-82 (Unmix.forward, return_masks=True).
 
     ``causal`` selects _CausalConv2d for layer 1 (the reference's
@@ -142,7 +145,7 @@ def unmix(sd: Dict[str, torch.Tensor], X_list: List[torch.Tensor],
     Ys, masks = [], []
     for b, X in enumerate(X_list):
         mag = abs_of_real_complex(X)
-        m = cdae_masks(sd, b, mag, causal, training)
+        m = cdae_masks(sd, b, mag, causal, training, minima)
         Ymag = m * mag
         Ys.append(blockwise_wiener(X, Ymag) if wiener else phasemix_sep(X, Ymag))
         masks.append(m)
