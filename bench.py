@@ -556,22 +556,52 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
     x = y_t.sum(0)
     losses = [tr.step(x, y_t)[0] for _ in range(max(2, args.warmup))]
     torch.cuda.synchronize()
-    _lib.profile_filter(None)
-    _lib.profile_enable(True)
-    _lib.profile_reset()
+    # (1) the reference's loop: the loss is looked at after every step (loss.item(), training.py:110)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(tr.step(x, y_t)[0])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    # (2) pipelined: step k + 1 is issued before the loss of step k is looked at (Trainer.step(wait=False))
+    t0 = time.perf_counter()
+    prev = None
+    for _ in range(args.steps):
+        cur = tr.step(x, y_t, wait=False)
+        if prev is not None:
+            losses.append(prev[0])
+        prev = cur
+    losses.append(prev[0])
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t0) / args.steps
+    # (3) per-kernel table: an extra instrumented pass (event records cost ~0.2 ms per step and are not in (1) / (2))
+    _lib.profile_filter(None)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    for _ in range(2):
+        tr.step(x, y_t)
+    torch.cuda.synchronize()
     prof = _lib.profile_read()
     _lib.profile_enable(False)
-    kern = {k: round(ms / args.steps, 4) for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    kern = {k: round(ms / 2, 4) for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     dom = next(iter(kern))
+    # algorithmic flops: the four convolution layers forward (SURVEY.md 8(d) formula at B = 16, S = 11), their data
+    # gradients (the mirrored layers: same contraction sizes) and their weight gradients (same again)
+    w = algorithmic_work(sep.nsgt.nsgt.plan, batch, [n], False)
+    fwd = sum(v for k, (_, v) in w.items() if k.startswith("cdae_"))
+    flops = 3 * fwd
     return {"what": "BASELINE configs[4]: training.py step, CDAE fwd+bwd with the X-UMX combined loss (ComplexMSE 14 "
-                    "combinations + MaskSum), differentiable Wiener-EM, AdamW; batch = 16 chunks of 2 s, offline model, "
-                    "fp32 (every kernel event-timed: ~0.2 ms of the step is event overhead)",
+                    "combinations + MaskSum), differentiable Wiener-EM, AdamW; batch = 16 chunks of 2 s (S = 11), offline "
+                    "model, fp32; incl. the five forward sliCQTs (mix + 4 targets) of the batch",
             "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(batch / dt, 1), "steps_per_s": round(1.0 / dt, 2),
+            "ms_per_step_pipelined": round(dtp * 1e3, 3),
+            "loss_readback": "ms_per_step: looked at after every step, as loss.item() in training.py:110; "
+                             "ms_per_step_pipelined: step k + 1 issued before the loss of step k is looked at",
+            "algorithmic_flops_per_step": int(flops),
+            "flops_note": "forward + data-gradient + weight-gradient contractions of the four convolution layers "
+                          "(3 x %.1f GFLOP); BatchNorm, loss, Wiener-EM, sliCQTs and AdamW are not counted" % (fwd / 1e9),
+            "achieved_tflops": round(flops / dt / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "frac": round(flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "parity": "tests/test_training.py::test_hip_training_step_at_config_size_matches_the_oracle (this batch, fp32 and bf16x6)",
             "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
             "dominant_kernel": {"kernel": dom, "ms_per_step": kern[dom], "share_of_step": round(kern[dom] / (dt * 1e3), 4)},
             "kernels_ms": dict(list(kern.items())[:12])}

@@ -243,8 +243,8 @@ int xsq_magnitude_stats(int nblocks, const int32_t* F, const int32_t* T, const f
  *     X        mix arena (2B channels, complex)      Yt   target arena (8B channels, complex)
  *     wiener   0: mix-phase (realtime model)         1: differentiable Wiener-EM (offline model)
  *     apply_update 0: gradients only (parameters and running statistics untouched)
- *     loss_out HOST double[2]: complex-MSE term, mask-sum term (the step synchronises the stream,
- *              as loss.item() at training.py:110 does)
+ *     loss_out HOST double[2]: complex-MSE term, mask-sum term (the step waits for them,
+ *              as loss.item() at training.py:110 does); NULL: do not wait, see xsq_train_loss
  *   xsq_train_read: what = 0 parameters, 1 gradients, 2 / 3 AdamW first / second moments -> HOST
  *   float[nparams].  xsq_train_write restores parameters (0) or a moment pool (2 / 3) from the host and
  *   xsq_train_step_count reads (set < 0) or restores the AdamW step counter: together they are the
@@ -257,6 +257,12 @@ size_t xsq_train_workspace(const xsq_train* t, int B, int S, int wiener);      /
 int xsq_train_step(xsq_train* t, const float* X, const float* Yt, int B, int S, int wiener,
                    float lr, float weight_decay, int apply_update, double* loss_out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* loss_out == NULL: the step does not wait.  The loss terms of the last 4 steps stay retrievable by ticket
+ * (xsq_train_ticket: ticket of the step issued last, 0-based count of steps on this handle); xsq_train_loss blocks
+ * until that step has finished and returns its two terms -- a loop can issue step k + 1 before it looks at the loss
+ * of step k, which keeps the device busy across the read-back that loss.item() makes every step.            */
+int64_t xsq_train_ticket(xsq_train* t);
+int xsq_train_loss(xsq_train* t, int64_t ticket, double* loss_out);
 int xsq_train_read(xsq_train* t, int what, float* host_out);
 int xsq_train_write(xsq_train* t, int what, const float* host_in);
 int64_t xsq_train_step_count(xsq_train* t, int64_t set);

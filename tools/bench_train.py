@@ -16,6 +16,8 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--realtime", action="store_true")
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6"])
+ap.add_argument("--no-profile", action="store_true", help="no per-kernel events: the clean wall time")
+ap.add_argument("--pipelined", action="store_true", help="look at a step's loss after the next step has been issued")
 a = ap.parse_args()
 n = int(a.seq_dur * 44100)
 with redirect_stdout(sys.stderr):
@@ -27,10 +29,19 @@ losses = []
 for _ in range(a.warmup):
     losses.append(tr.step(x, y_t)[0])
 torch.cuda.synchronize()
-_lib.profile_enable(True); _lib.profile_reset()
+_lib.profile_enable(not a.no_profile); _lib.profile_reset()
 t0 = time.perf_counter()
+prev = None
 for _ in range(a.steps):
-    losses.append(tr.step(x, y_t)[0])
+    if a.pipelined:
+        cur = tr.step(x, y_t, wait=False)
+        if prev is not None:
+            losses.append(prev[0])
+        prev = cur
+    else:
+        losses.append(tr.step(x, y_t)[0])
+if prev is not None:
+    losses.append(prev[0])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 prof = _lib.profile_read()

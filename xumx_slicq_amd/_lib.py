@@ -75,6 +75,8 @@ _SIGS = {
     "xsq_train_destroy": (C.c_int, [_vp]),
     "xsq_train_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int, C.c_int]),
     "xsq_train_step": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_train_ticket": (C.c_int64, [_vp]),
+    "xsq_train_loss": (C.c_int, [_vp, C.c_int64, _vp]),
     "xsq_train_read": (C.c_int, [_vp, C.c_int, _vp]),
     "xsq_train_write": (C.c_int, [_vp, C.c_int, _vp]),
     "xsq_train_step_count": (C.c_int64, [_vp, C.c_int64]),

@@ -78,8 +78,12 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const float* mean, const float* scale,
                           int Bn, int S, hipStream_t stream, int split = 0);
 
-// backward of the Wiener-EM iteration (wiener.hip), in place on the gradient arena G
-int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, float* G,
-                       int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream);
+// backward of the Wiener-EM iteration (wiener.hip), in place on the gradient arena G.  The pre-filter estimate is
+// either given (Y0, complex arena) or formed from the masks while loading (Y0 == nullptr, masks = real arena).
+int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, const float* masks,
+                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream);
+// loss forward (loss.hip), optionally with the gradients of both terms written in the same pass (gY / gM non-null)
+int loss_forward_backward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
+                          const float* masks, int Bn, int S, double* out, float* gY, float* gM, void* ws, hipStream_t stream);
 
 }  // namespace xsq

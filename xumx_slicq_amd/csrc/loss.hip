@@ -6,6 +6,8 @@
 // training.py:86-103 adds the two.  With e_j = pred_j - target_j per real element, s1 = sum_j e_j and
 // s2 = sum_j e_j^2, the 14 squared sums add up to 4*s2 + 3*s1^2 (pairs: 2*s2 + s1^2, triples: 2*s1^2 + s2).
 // One streaming pass, fp64 partial sums, fixed-order reductions (bitwise reproducible, no atomics).
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/xumx_slicq_hip.h"
@@ -25,11 +27,18 @@ struct LossWork {     // one workgroup: `count` float4 quads of one block's per-
     int64_t nreal;    // floats per target in the real arena (complex has 2x)
 };
 
+// BWD: the same pass also writes the loss gradients (training step, training.py:107): d/dpred_j = (8 e_j + 6 sum_k e_k)
+// / (14 n_b nblocks) into gY and the mask-sum gradient 2 (sum_j m_j - 1) / (n'_b nblocks) into gM (the same value for
+// the four targets) -- the operands are in registers already, a second read of pred / target / masks is saved.
+template <bool BWD>
 __global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                        const float* __restrict__ masks,
-                                                       const LossWork* __restrict__ work, double* __restrict__ partial) {
+                                                       const LossWork* __restrict__ work, double* __restrict__ partial,
+                                                       float* __restrict__ gY, float* __restrict__ gM, int nblocks) {
     const LossWork w = work[blockIdx.x];
     double mse = 0.0, msk = 0.0;
+    const float cb = BWD ? 1.f / (14.f * (float)(2 * w.nreal) * (float)nblocks) : 0.f;
+    const float cm = BWD ? 1.f / ((float)w.nreal * (float)nblocks) : 0.f;
     for (int64_t q = threadIdx.x; q < w.count; q += 256) {
         const int64_t i = 4 * (w.first + q);                 // float index inside the per-target complex sub-arena
         float4 e[4];
@@ -45,15 +54,29 @@ __global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) s2 += e[j].x * e[j].x + e[j].y * e[j].y + e[j].z * e[j].z + e[j].w * e[j].w;
         mse += (double)(4.f * s2 + 3.f * (s1x * s1x + s1y * s1y + s1z * s1z + s1w * s1w));
+        if (BWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(gY + w.base_c + j * w.tstride_c + i) =
+                    make_float4((8.f * e[j].x + 6.f * s1x) * cb, (8.f * e[j].y + 6.f * s1y) * cb,
+                                (8.f * e[j].z + 6.f * s1z) * cb, (8.f * e[j].w + 6.f * s1w) * cb);
+        }
         if (masks && i < w.nreal) {       // the real arena is half as long: quads [0, nreal/4) of this block
             float4 m = *reinterpret_cast<const float4*>(masks + w.base_r + i);
+            float4 sm = make_float4(-1.f + m.x, -1.f + m.y, -1.f + m.z, -1.f + m.w);      // the gradient's own summation order
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
                 const float4 mj = *reinterpret_cast<const float4*>(masks + w.base_r + j * w.tstride_r + i);
                 m.x += mj.x; m.y += mj.y; m.z += mj.z; m.w += mj.w;
+                sm.x += mj.x; sm.y += mj.y; sm.z += mj.z; sm.w += mj.w;
             }
             m.x -= 1.f; m.y -= 1.f; m.z -= 1.f; m.w -= 1.f;
             msk += (double)(m.x * m.x + m.y * m.y + m.z * m.z + m.w * m.w);
+            if (BWD) {
+                const float4 gm = make_float4(2.f * sm.x * cm, 2.f * sm.y * cm, 2.f * sm.z * cm, 2.f * sm.w * cm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(gM + w.base_r + j * w.tstride_r + i) = gm;
+            }
         }
     }
     __shared__ double red[2][256];
@@ -85,21 +108,17 @@ __global__ void k_loss_combine(const double* __restrict__ partial, const int* __
 
 using namespace xsq;
 
-extern "C" {
+// work tables of one (block table, B, S): built once, resident (the step must not wait for the host in mid-flight)
+struct LossTables { LossWork* d_work = nullptr; double* d_inv = nullptr; int* d_first = nullptr; int nwork = 0; };
+static std::mutex g_loss_mu;
+static std::map<std::vector<int>, LossTables> g_loss_tables;
 
-size_t xsq_loss_workspace(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S) {
-    if (nblocks <= 0 || !F || !T || Bn <= 0 || S <= 0) return 0;
-    size_t nwg = 0;
-    for (int b = 0; b < nblocks; ++b) nwg += ((size_t)Bn * 2 * F[b] * S * T[b] * 2 / 4 + 4095) / 4096;
-    return nwg * (sizeof(LossWork) + 16) + (size_t)nblocks * 64 + 1024;
-}
-
-int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
-                     const float* masks, int Bn, int S, double* out, void* ws, size_t ws_bytes, void* stream_) {
-    XSQ_REQUIRE(nblocks > 0 && F && T && pred && target && out && ws, "xsq_loss_forward: null argument");
-    XSQ_REQUIRE(Bn > 0 && S > 0, "xsq_loss_forward: B=%d S=%d", Bn, S);
-    XSQ_REQUIRE(ws_bytes >= xsq_loss_workspace(nblocks, F, T, Bn, S), "xsq_loss_forward: workspace too small");
-    hipStream_t stream = (hipStream_t)stream_;
+static int loss_tables(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, LossTables* out) {
+    std::vector<int> key{nblocks, Bn, S};
+    for (int b = 0; b < nblocks; ++b) { key.push_back(F[b]); key.push_back(T[b]); }
+    std::lock_guard<std::mutex> lk(g_loss_mu);
+    auto it = g_loss_tables.find(key);
+    if (it != g_loss_tables.end()) { *out = it->second; return XSQ_OK; }
     std::vector<LossWork> work;
     std::vector<int> first(nblocks + 1, 0);
     std::vector<double> inv(2 * nblocks);
@@ -120,20 +139,52 @@ int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const floa
         cum += (int64_t)F[b] * T[b];
     }
     first[nblocks] = (int)work.size();
-    char* p = (char*)ws;
-    LossWork* d_work = (LossWork*)p; p += work.size() * sizeof(LossWork);
-    double* d_partial = (double*)p;  p += work.size() * 16;
-    double* d_inv = (double*)p;      p += (size_t)nblocks * 16;
-    int* d_first = (int*)p;
-    XSQ_HIP(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(LossWork), hipMemcpyHostToDevice, stream));
-    XSQ_HIP(hipMemcpyAsync(d_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    XSQ_HIP(hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    XSQ_HIP(hipStreamSynchronize(stream));     // the host vectors go out of scope; loss evaluation is not on the hot path
+    LossTables t;
+    t.nwork = (int)work.size();
+    XSQ_HIP(hipMalloc(&t.d_work, work.size() * sizeof(LossWork)));
+    XSQ_HIP(hipMemcpy(t.d_work, work.data(), work.size() * sizeof(LossWork), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&t.d_inv, inv.size() * sizeof(double)));
+    XSQ_HIP(hipMemcpy(t.d_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&t.d_first, first.size() * sizeof(int)));
+    XSQ_HIP(hipMemcpy(t.d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+    g_loss_tables[key] = t;
+    *out = t;
+    return XSQ_OK;
+}
+
+namespace xsq {
+// loss forward, optionally with the gradients of both terms in the same pass (gY / gM non-null: training step)
+int loss_forward_backward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
+                          const float* masks, int Bn, int S, double* out, float* gY, float* gM, void* ws, hipStream_t stream) {
+    LossTables t;
+    if (int rc = loss_tables(nblocks, F, T, Bn, S, &t)) return rc;
+    double* d_partial = (double*)ws;
     { XSQ_PROF("loss_partial", stream);
-    hipLaunchKernelGGL(k_loss_partial, dim3((unsigned)work.size()), dim3(256), 0, stream, pred, target, masks, d_work, d_partial); }
-    hipLaunchKernelGGL(k_loss_combine, dim3((nblocks + 63) / 64), dim3(64), 0, stream, d_partial, d_first, d_inv, out, nblocks);
+      if (gY && gM && masks)
+          hipLaunchKernelGGL(k_loss_partial<true>, dim3((unsigned)t.nwork), dim3(256), 0, stream, pred, target, masks, t.d_work, d_partial, gY, gM, nblocks);
+      else
+          hipLaunchKernelGGL(k_loss_partial<false>, dim3((unsigned)t.nwork), dim3(256), 0, stream, pred, target, masks, t.d_work, d_partial, nullptr, nullptr, nblocks); }
+    hipLaunchKernelGGL(k_loss_combine, dim3((nblocks + 63) / 64), dim3(64), 0, stream, d_partial, t.d_first, t.d_inv, out, nblocks);
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
+}
+}  // namespace xsq
+
+extern "C" {
+
+size_t xsq_loss_workspace(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S) {
+    if (nblocks <= 0 || !F || !T || Bn <= 0 || S <= 0) return 0;
+    size_t nwg = 0;
+    for (int b = 0; b < nblocks; ++b) nwg += ((size_t)Bn * 2 * F[b] * S * T[b] * 2 / 4 + 4095) / 4096;
+    return nwg * (sizeof(LossWork) + 16) + (size_t)nblocks * 64 + 1024;
+}
+
+int xsq_loss_forward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
+                     const float* masks, int Bn, int S, double* out, void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(nblocks > 0 && F && T && pred && target && out && ws, "xsq_loss_forward: null argument");
+    XSQ_REQUIRE(Bn > 0 && S > 0, "xsq_loss_forward: B=%d S=%d", Bn, S);
+    XSQ_REQUIRE(ws_bytes >= xsq_loss_workspace(nblocks, F, T, Bn, S), "xsq_loss_forward: workspace too small");
+    return xsq::loss_forward_backward(nblocks, F, T, pred, target, masks, Bn, S, out, nullptr, nullptr, ws, (hipStream_t)stream_);
 }
 
 }  // extern "C"

@@ -74,26 +74,43 @@ static const int BN_ROWS = 256;
 struct BnTile { int group, r0, r1; };
 struct BnInfo { int base, n; };
 
-// stage 1, one workgroup per row tile: per channel sum and sum of squares
+// stage 1, one workgroup per row tile: per channel sum and sum of squares.  A row is 13 float4 (52 channels, 208 B,
+// 16-byte aligned): thread = (row lane tid / 13 of 16, channel quad tid % 13), 16-byte loads, 16 rows of the tile per
+// step (the first form read 4 bytes per lane and walked 64 rows per thread: 0.05 ms per launch of pure latency).
+static const int BN_RL = 16, BN_Q = CS / 4;             // row lanes, float4 per row
+__device__ __forceinline__ void bn_tile_reduce(double (&s1)[4], double (&s2)[4], double* __restrict__ o) {
+    __shared__ double q1[BN_RL][CS], q2[BN_RL][CS];
+    const int tid = threadIdx.x, rl = tid / BN_Q, q = tid - rl * BN_Q;
+    if (tid < BN_RL * BN_Q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q1[rl][4 * q + k] = s1[k]; q2[rl][4 * q + k] = s2[k]; }
+    }
+    __syncthreads();
+    if (tid < CS) {                  // fixed order: bitwise reproducible
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int r = 0; r < BN_RL; ++r) { a += q1[r][tid]; b += q2[r][tid]; }
+        o[tid] = a;
+        o[64 + tid] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ z, const TrainGroup* __restrict__ groups,
                                                            const BnTile* __restrict__ tiles, TrainDims d, int layer,
                                                            double* __restrict__ part) {
     const BnTile t = tiles[blockIdx.x];
     const TrainGroup g = groups[t.group];
-    const float* zz = z + (layer == 1 ? act2_off(g, d) : act1_off(g, d));
-    const int C = layer == 1 ? g.C2 : g.C1;
-    const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int m = t.r0 + rs; m < t.r1; m += 4) { const double v = zz[(int64_t)m * CS + c]; s1 += v; s2 += v * v; }
-    __shared__ double q1[256], q2[256];
-    q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
-    __syncthreads();
-    if (rs == 0) {
-        double* o = part + (int64_t)blockIdx.x * 128;
-        o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
-        o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
-    }
+    const float4* zz = reinterpret_cast<const float4*>(z + (layer == 1 ? act2_off(g, d) : act1_off(g, d)));
+    const int tid = threadIdx.x, rl = tid / BN_Q, q = tid - rl * BN_Q;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (tid < BN_RL * BN_Q)
+        for (int m = t.r0 + rl; m < t.r1; m += BN_RL) {
+            const float4 v = zz[(int64_t)m * BN_Q + q];
+            const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            s1[0] += x0; s1[1] += x1; s1[2] += x2; s1[3] += x3;
+            s2[0] += x0 * x0; s2[1] += x1 * x1; s2[2] += x2 * x2; s2[3] += x3 * x3;
+        }
+    bn_tile_reduce(s1, s2, part + (int64_t)blockIdx.x * 128);
 }
 
 // stage 2, one 64-thread workgroup per group: batch mean / biased variance, running-stat update (momentum 0.1)
@@ -159,27 +176,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     const BnTile t = tiles[blockIdx.x];
     const TrainGroup g = groups[t.group];
     const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
-    const int C = layer == 1 ? g.C2 : g.C1;
-    const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    const float4* z4 = reinterpret_cast<const float4*>(z + off);
+    const float4* a4 = reinterpret_cast<const float4*>(a + off);
+    const float4* g4 = reinterpret_cast<const float4*>(ga + off);
+    const int tid = threadIdx.x, rl = tid / BN_Q, q = tid - rl * BN_Q;
     const float* st = stats + ((int64_t)t.group * 3 + layer) * 256;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        const float mean = st[c], inv = st[64 + c];
-        for (int m = t.r0 + rs; m < t.r1; m += 4) {
-            const int64_t i = off + (int64_t)m * CS + c;
-            const float gb = a[i] > 0.f ? ga[i] : 0.f;
-            s1 += gb;
-            s2 += (double)gb * (double)((z[i] - mean) * inv);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (tid < BN_RL * BN_Q) {
+        const float4 mean = *reinterpret_cast<const float4*>(st + 4 * q), inv = *reinterpret_cast<const float4*>(st + 64 + 4 * q);
+        for (int m = t.r0 + rl; m < t.r1; m += BN_RL) {
+            const int64_t i = (int64_t)m * BN_Q + q;
+            const float4 zv = z4[i], av = a4[i], gv = g4[i];
+            const float g0 = av.x > 0.f ? gv.x : 0.f, g1 = av.y > 0.f ? gv.y : 0.f;
+            const float g2 = av.z > 0.f ? gv.z : 0.f, g3 = av.w > 0.f ? gv.w : 0.f;
+            s1[0] += g0; s1[1] += g1; s1[2] += g2; s1[3] += g3;
+            s2[0] += (double)g0 * (double)((zv.x - mean.x) * inv.x);
+            s2[1] += (double)g1 * (double)((zv.y - mean.y) * inv.y);
+            s2[2] += (double)g2 * (double)((zv.z - mean.z) * inv.z);
+            s2[3] += (double)g3 * (double)((zv.w - mean.w) * inv.w);
         }
     }
-    __shared__ double q1[256], q2[256];
-    q1[threadIdx.x] = s1; q2[threadIdx.x] = s2;
-    __syncthreads();
-    if (rs == 0) {
-        double* o = part + (int64_t)blockIdx.x * 128;
-        o[c] = (q1[c] + q1[c + 64]) + (q1[c + 128] + q1[c + 192]);
-        o[64 + c] = (q2[c] + q2[c + 64]) + (q2[c + 128] + q2[c + 192]);
-    }
+    bn_tile_reduce(s1, s2, part + (int64_t)blockIdx.x * 128);
 }
 
 __global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
@@ -232,33 +249,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float4* __restrict__
 }
 
 // ---- loss gradients ---------------------------------------------------------------------------------
-// grid (ceil(per-target complex floats / 256), nblocks): gY_j = (8 e_j + 6 s1) / (14 * n_b * nblocks);
-// the mask-sum gradient 2 (sum_j m_j - 1) / (n'_b * nblocks) is written to gM (same for the 4 targets).
+// gY_j = (8 e_j + 6 s1) / (14 * n_b * nblocks) and the mask-sum gradient 2 (sum_j m_j - 1) / (n'_b * nblocks) (the same
+// for the 4 targets) come out of the loss pass itself (loss.hip: k_loss_partial<true>).
 struct BlockGeo { int F, T; int64_t cum; };
-__global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ Y, const float* __restrict__ Yt,
-                                                   const float* __restrict__ masks, float* __restrict__ gY,
-                                                   float* __restrict__ gM, const BlockGeo* __restrict__ geo, int nblocks,
-                                                   int Bn, int S) {
-    const BlockGeo b = geo[blockIdx.y];
-    const int64_t per_r = (int64_t)Bn * 2 * b.F * S * b.T;     // real elements per target
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // float index in the per-target complex sub-arena
-    if (i >= 2 * per_r) return;
-    const int64_t base_c = 2 * (int64_t)Bn * 8 * S * b.cum, base_r = (int64_t)Bn * 8 * S * b.cum;
-    float e[4], s1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { e[j] = Y[base_c + j * 2 * per_r + i] - Yt[base_c + j * 2 * per_r + i]; s1 += e[j]; }
-    const float cb = 1.f / (14.f * (float)(2 * per_r) * (float)nblocks);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gY[base_c + j * 2 * per_r + i] = (8.f * e[j] + 6.f * s1) * cb;
-    if (i < per_r) {
-        float sm = -1.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sm += masks[base_r + j * per_r + i];
-        const float gm = 2.f * sm / ((float)per_r * (float)nblocks);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gM[base_r + j * per_r + i] = gm;
-    }
-}
 
 // g_p4 = (Re(conj(X) * gY0) + gM) * m * (1 - m), in place on gM.  grid (ceil(per-target reals/256), groups)
 __global__ __launch_bounds__(256) void k_mask_bwd(const float2* __restrict__ X, const float2* __restrict__ gY0,
@@ -511,6 +504,17 @@ struct xsq_train {
     int *d_frow1 = nullptr, *d_frow2 = nullptr;    // frequency-row index of the act1-like / act2-like arrays -> group
     std::mutex mu;
     std::map<std::pair<int, int>, WgTables> wg;     // (B, S) -> weight-gradient tile tables
+    // The weight gradient of a layer and the data gradient that continues the chain both start from the same g and
+    // are independent of each other; at B = 16 x S = 11 each is a 0.2 ms launch with a long tail, so the weight
+    // gradients go to a side stream (forked / joined with events: capturable into a HIP graph).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+    // loss read-back without stalling the stream (xsq_train_step with loss_out == NULL): the per-block terms of the
+    // last LOSS_RING steps land in pinned host memory behind an event each; xsq_train_loss waits for one of them
+    static const int LOSS_RING = 4;
+    double* h_loss = nullptr;
+    hipEvent_t ev_loss[LOSS_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t seq = 0;                        // steps issued so far (the ticket of the next one)
 };
 
 using namespace xsq;
@@ -605,6 +609,11 @@ int xsq_train_destroy(xsq_train* T) {
     for (auto& kv : T->wg) { (void)hipFree(kv.second.d_t23); (void)hipFree(kv.second.d_t14); (void)hipFree(kv.second.d_i23); (void)hipFree(kv.second.d_i14);
         (void)hipFree(kv.second.d_bt1); (void)hipFree(kv.second.d_bt2); (void)hipFree(kv.second.d_bi1); (void)hipFree(kv.second.d_bi2); }
     (void)hipFree(T->d_frow1); (void)hipFree(T->d_frow2);
+    if (T->side) (void)hipStreamDestroy(T->side);
+    for (hipEvent_t e : T->ev_fork) if (e) (void)hipEventDestroy(e);
+    if (T->ev_join) (void)hipEventDestroy(T->ev_join);
+    for (hipEvent_t e : T->ev_loss) if (e) (void)hipEventDestroy(e);
+    if (T->h_loss) (void)hipHostFree(T->h_loss);
     delete T;
     return XSQ_OK;
 }
@@ -756,7 +765,13 @@ int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32
                      int64_t nparams) {
     XSQ_REQUIRE(out && F && T && params && nblocks > 0, "xsq_train_create: null argument");
     xsq_train* Tr = new xsq_train();
-    const int rc = train_build(Tr, nblocks, F, T, causal, params, nparams);
+    int rc = train_build(Tr, nblocks, F, T, causal, params, nparams);
+    if (!rc && hipStreamCreateWithFlags(&Tr->side, hipStreamNonBlocking) != hipSuccess) rc = XSQ_ERR_HIP;
+    for (hipEvent_t& e : Tr->ev_fork) if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = XSQ_ERR_HIP;
+    if (!rc && hipEventCreateWithFlags(&Tr->ev_join, hipEventDisableTiming) != hipSuccess) rc = XSQ_ERR_HIP;
+    for (hipEvent_t& e : Tr->ev_loss) if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = XSQ_ERR_HIP;
+    if (!rc && hipHostMalloc((void**)&Tr->h_loss, (size_t)xsq_train::LOSS_RING * nblocks * 16, hipHostMallocDefault) != hipSuccess) rc = XSQ_ERR_HIP;
+    if (rc == XSQ_ERR_HIP) set_error("xsq_train_create: side stream / events / pinned loss buffer");
     if (rc) { xsq_train_destroy(Tr); return rc; }
     *out = Tr;
     return XSQ_OK;
@@ -796,7 +811,7 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     const int64_t T1 = Tr->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
     const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
     const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
-    size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + (wiener ? 3 : 2) * alt(n8 * 8);
+    size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + 2 * alt(n8 * 8);
     b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt(part_doubles(Tr, Bn, S) * 8)
          + alt(wg_partial_floats(Tr, Bn, S) * 4);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
@@ -808,7 +823,7 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
 // (gradients stay readable through xsq_train_read).  loss_out: HOST double[2] (complex MSE, mask sum).
 int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S, int wiener, float lr, float wd,
                    int apply_update, double* loss_out, void* ws, size_t ws_bytes, void* stream_) {
-    XSQ_REQUIRE(Tr && X && Yt && ws && loss_out, "xsq_train_step: null argument");
+    XSQ_REQUIRE(Tr && X && Yt && ws, "xsq_train_step: null argument");
     XSQ_REQUIRE(Bn > 0 && S >= 3, "xsq_train_step: B=%d S=%d", Bn, S);
     XSQ_REQUIRE(ws_bytes >= xsq_train_workspace(Tr, Bn, S, wiener), "xsq_train_step: workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
@@ -825,7 +840,6 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     float *z3 = (float*)take(na1 * 4), *a3 = (float*)take(na1 * 4), *g3 = (float*)take(na1 * 4);
     float *masks = (float*)take(n8 * 4), *gM = (float*)take(n8 * 4);
     float *Y = (float*)take(n8 * 8), *gY = (float*)take(n8 * 8);
-    float* Y0 = wiener ? (float*)take(n8 * 8) : nullptr;
     const size_t wst_bytes = wiener ? xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000) : 0;
     void* wst = wiener ? take(wst_bytes) : nullptr;
     void* wbst = wiener ? take(wst_bytes) : nullptr;
@@ -837,7 +851,6 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     float *mean = (float*)take((size_t)Tr->sumF * 4), *scale = (float*)take((size_t)Tr->sumF * 4);
     double* d_loss = (double*)take((size_t)Tr->nblocks * 16);
     void* loss_ws = w;
-    const size_t loss_ws_bytes = xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S);
 
     auto grid1 = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     // ---- parameters -> GEMM layouts -------------------------------------------------------------
@@ -874,26 +887,33 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
       hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, Tr->d_params, apply_update); }
     { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (float4*)a3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     a.act3 = a3;
-    if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks, Y = mask * X
-    if (wiener) {       // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69)
-        XSQ_HIP(hipMemcpyAsync(Y0, Y, n8 * 8, hipMemcpyDeviceToDevice, stream));
-        if ((rc = xsq_wiener_em(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, Y, Bn, S, 5000, Bn, wst, wst_bytes, stream))) return rc;
-    }
-    // ---- loss + its gradients ---------------------------------------------------------------------
-    if ((rc = xsq_loss_forward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, loss_ws, loss_ws_bytes, stream))) return rc;
-    int64_t maxC = 0;
-    for (int b = 0; b < Tr->nblocks; ++b) maxC = std::max<int64_t>(maxC, (int64_t)Bn * 2 * Tr->Fv[b] * S * Tr->Tv[b] * 2);
-    { XSQ_PROF("train_loss_bwd", stream); hipLaunchKernelGGL(k_loss_bwd, dim3(grid1(maxC).x, (unsigned)Tr->nblocks), dim3(256), 0, stream, Y, Yt, masks, gY, gM, Tr->d_geo, Tr->nblocks, Bn, S); }
-    if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, Y0, gY, Bn, S, 5000, Bn, wst, wbst, stream)))
+    // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69).  Layer 4 then stores the
+    // masks only; the EM passes -- forward and backward -- form mask * X while they load (no estimate arena, no copy of it).
+    if (wiener) a.Y = nullptr;
+    if ((rc = cdae_launch_layer(Mo, 4, a, stream))) return rc;                       // masks [, Y = mask * X]
+    if (wiener && (rc = xsq_wiener_em_masked(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, masks, Y, Bn, S, 5000, Bn, wst, wst_bytes, stream)))
+        return rc;
+    // ---- loss + its gradients (one pass) ------------------------------------------------------------
+    if ((rc = loss_forward_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, gY, gM, loss_ws, stream))) return rc;
+    if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, nullptr, masks, gY, Bn, S, 5000, Bn, wst, wbst, stream)))
         return rc;
     { XSQ_PROF("train_mask_bwd", stream); hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d); }
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;
     { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_partial, dim3(2 * Bn, G), dim3(256), 0, stream, gM, Tr->d_groups, d, part);
       hipLaunchKernelGGL(k_l4_bias_final, grid1(2 * Tr->ngroups), dim3(256), 0, stream, part, Tr->d_groups, Tr->ngroups, d, gp); }
-    { XSQ_PROF("train_l4_wgrad", stream);
-      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
-      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
+    // weight gradients: on the side stream, each behind the kernel that finishes its g (XSQ_TRAIN_SIDE=0: in line)
+    static const bool use_side = !(getenv("XSQ_TRAIN_SIDE") && atoi(getenv("XSQ_TRAIN_SIDE")) == 0);
+    hipStream_t ws_ = use_side ? Tr->side : stream;
+    auto fork = [&](int i) {
+        if (!use_side) return hipSuccess;
+        hipError_t e = hipEventRecord(Tr->ev_fork[i], stream);
+        return e != hipSuccess ? e : hipStreamWaitEvent(Tr->side, Tr->ev_fork[i], 0);
+    };
+    XSQ_HIP(fork(0));
+    { XSQ_PROF("train_l4_wgrad", ws_);
+      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
     CdaeArgs bw{Mo->d_blocks, Tr->d_pool_bwd, xin, g1, g2, g3, X, Y, nullptr, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
     if ((rc = cdae_launch_layer(Mo, 1, bw, stream, "train_l4_dgrad_gemm"))) return rc;
@@ -901,29 +921,36 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, wt.d_bt1, d, 2, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (const float4*)a3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
-    { XSQ_PROF("train_l3_wgrad", stream);
-      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
-      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
+    XSQ_HIP(fork(1));
+    { XSQ_PROF("train_l3_wgrad", ws_);
+      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
     if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, wt.d_bt2, d, 1, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (const float4*)a2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
-    { XSQ_PROF("train_l2_wgrad", stream);
-      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, stream, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
-      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, stream, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
+    XSQ_HIP(fork(2));
+    { XSQ_PROF("train_l2_wgrad", ws_);
+      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
     if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
     { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, wt.d_bt1, d, 0, stats, part);
       hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, gp); }
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (const float4*)a1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
-    { XSQ_PROF("train_l1_wgrad", stream);
-      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, stream, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
-      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, stream, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
+    XSQ_HIP(fork(3));
+    { XSQ_PROF("train_l1_wgrad", ws_);
+      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
     bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);
     if ((rc = cdae_launch_layer(Mo, 4, bw, stream, "train_l1_dgrad_gemm"))) return rc;   // gY is free by now
     { XSQ_PROF("train_input_grad_reduce", stream); hipLaunchKernelGGL(k_input_grad_partial, dim3((unsigned)Tr->sumF, 4 * Bn), dim3(256), 0, stream, xin, gY, Tr->d_groups, Tr->d_rows, d, part);
       hipLaunchKernelGGL(k_input_grad_final, grid1(Tr->sumF), dim3(256), 0, stream, part, Tr->d_params, Tr->d_groups, Tr->d_rows, (int)Tr->sumF, 4 * Bn, gp); }
+    if (use_side) {      // the caller's stream joins: every gradient is complete before the update / before returning
+        XSQ_HIP(hipEventRecord(Tr->ev_join, Tr->side));
+        XSQ_HIP(hipStreamWaitEvent(stream, Tr->ev_join, 0));
+    }
     // ---- update ---------------------------------------------------------------------------------------
     if (apply_update) {
         Tr->step += 1;
@@ -932,10 +959,25 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
                            Tr->nparams, lr, wd, b1, b2, 1e-8f, 1.f - powf(b1, (float)Tr->step), 1.f - powf(b2, (float)Tr->step)); }
     }
     XSQ_HIP(hipGetLastError());
-    // loss scalars (the reference calls loss.item() every step as well, training.py:110)
-    std::vector<double> per((size_t)Tr->nblocks * 2);
-    XSQ_HIP(hipMemcpyAsync(per.data(), d_loss, per.size() * 8, hipMemcpyDeviceToHost, stream));
-    XSQ_HIP(hipStreamSynchronize(stream));
+    // loss scalars: per-block terms to pinned host memory behind an event (ring slot = ticket % LOSS_RING)
+    const int64_t ticket = Tr->seq++;
+    const int slot = (int)(ticket % xsq_train::LOSS_RING);
+    XSQ_HIP(hipMemcpyAsync(Tr->h_loss + (size_t)slot * Tr->nblocks * 2, d_loss, (size_t)Tr->nblocks * 16, hipMemcpyDeviceToHost, stream));
+    XSQ_HIP(hipEventRecord(Tr->ev_loss[slot], stream));
+    // loss_out given: wait here, as loss.item() does every step in the reference (training.py:110)
+    return loss_out ? xsq_train_loss(Tr, ticket, loss_out) : XSQ_OK;
+}
+
+int64_t xsq_train_ticket(xsq_train* Tr) { return Tr ? Tr->seq - 1 : XSQ_ERR_ARG; }
+
+int xsq_train_loss(xsq_train* Tr, int64_t ticket, double* loss_out) {
+    XSQ_REQUIRE(Tr && loss_out, "xsq_train_loss: null argument");
+    XSQ_REQUIRE(ticket >= 0 && ticket < Tr->seq && ticket >= Tr->seq - xsq_train::LOSS_RING,
+                "xsq_train_loss: ticket %lld is not among the last %d steps (next ticket %lld)", (long long)ticket,
+                xsq_train::LOSS_RING, (long long)Tr->seq);
+    const int slot = (int)(ticket % xsq_train::LOSS_RING);
+    XSQ_HIP(hipEventSynchronize(Tr->ev_loss[slot]));
+    const double* per = Tr->h_loss + (size_t)slot * Tr->nblocks * 2;
     loss_out[0] = loss_out[1] = 0.0;
     for (int b = 0; b < Tr->nblocks; ++b) { loss_out[0] += per[2 * b]; loss_out[1] += per[2 * b + 1]; }
     loss_out[0] /= Tr->nblocks; loss_out[1] /= Tr->nblocks;

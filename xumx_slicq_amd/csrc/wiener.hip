@@ -414,7 +414,8 @@ __device__ inline void wiener_bwd_point(const float* __restrict__ st, float2 x0,
     }
 }
 
-__device__ inline void wiener_load_point(const float2* __restrict__ X, const float2* __restrict__ Y0,
+// Mk != nullptr: the pre-filter estimate is mask * x (the products the layer-4 epilogue would have stored)
+__device__ inline void wiener_load_point(const float2* __restrict__ X, const float2* __restrict__ Y0, const float* __restrict__ Mk,
                                          const float2* __restrict__ G, const WRow& r, int Bn, int S, int64_t n,
                                          float2& x0, float2& x1, float2 (&y)[4][2], float2 (&g)[4][2], int64_t (&yi)[4]) {
     const int64_t N = (int64_t)S * r.T;
@@ -423,12 +424,18 @@ __device__ inline void wiener_load_point(const float2* __restrict__ X, const flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         yi[j] = cidx(r, 8 * Bn, S, (j * Bn + r.b) * 2, n);
-        y[j][0] = Y0[yi[j]]; y[j][1] = Y0[yi[j] + (int64_t)r.F * N];
+        if (Mk) {
+            const float ma = Mk[yi[j]], mb = Mk[yi[j] + (int64_t)r.F * N];      // real arena: same index, one float each
+            y[j][0] = make_float2(ma * x0.x, ma * x0.y); y[j][1] = make_float2(mb * x1.x, mb * x1.y);
+        } else {
+            y[j][0] = Y0[yi[j]]; y[j][1] = Y0[yi[j] + (int64_t)r.F * N];
+        }
         g[j][0] = G[yi[j]]; g[j][1] = G[yi[j] + (int64_t)r.F * N];
     }
 }
 
 __global__ __launch_bounds__(256) void k_wiener_bwd_stats(const float2* __restrict__ X, const float2* __restrict__ Y0,
+                                                           const float* __restrict__ Mk,
                                                            const float2* __restrict__ G, const WRow* __restrict__ rows,
                                                            const int* __restrict__ work, const float* __restrict__ stats,
                                                            float* __restrict__ bstats, int Bn, int S, int win_len) {
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_stats(const float2* __restri
     for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
         float2 x0, x1, y[4][2], g[4][2];
         int64_t yi[4];
-        wiener_load_point(X, Y0, G, r, Bn, S, n, x0, x1, y, g, yi);
+        wiener_load_point(X, Y0, Mk, G, r, Bn, S, n, x0, x1, y, g, yi);
         WPoint P;
         wiener_bwd_point(st, x0, x1, y, g, P);
 #pragma unroll
@@ -493,6 +500,7 @@ __global__ void k_wiener_bwd_finalize(const WRow* __restrict__ rows, const int* 
 }
 
 __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restrict__ X, const float2* __restrict__ Y0,
+                                                           const float* __restrict__ Mk,
                                                            float2* __restrict__ G, const WRow* __restrict__ rows,
                                                            const float* __restrict__ stats, const float* __restrict__ bstats,
                                                            int Bn, int S, int win_len) {
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restri
     const float* bs = bstats + o;
     float2 x0, x1, y[4][2], g[4][2];
     int64_t yi[4];
-    wiener_load_point(X, Y0, G, r, Bn, S, n, x0, x1, y, g, yi);
+    wiener_load_point(X, Y0, Mk, G, r, Bn, S, n, x0, x1, y, g, yi);
     WPoint P;
     wiener_bwd_point(st, x0, x1, y, g, P);
     const float inv_ma2 = st[16];
@@ -580,22 +588,22 @@ static int check_table(const char* who, int nblocks, const int32_t* F, const int
 
 // backward of xsq_wiener_em: `stats` is the workspace the forward call left behind, G holds dL/d(out) on entry
 // and dL/d(y0) on return, Y0 is the pre-filter estimate.  bstats: another workspace of the same size.
-int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, float* G,
-                       int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream) {
+int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, const float* masks,
+                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream) {
     if (batch_group <= 0) batch_group = Bn;
     WTable t;
     int rc;
     if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, batch_group, &t))) return rc;
     { XSQ_PROF("wiener_bwd_stats", stream);
     hipLaunchKernelGGL(k_wiener_bwd_stats, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, (const float2*)Y0,
-                       (const float2*)G, t.d_rows, t.d_work, (const float*)stats, (float*)bstats, Bn, S, win_len); }
+                       Y0 ? nullptr : masks, (const float2*)G, t.d_rows, t.d_work, (const float*)stats, (float*)bstats, Bn, S, win_len); }
     { XSQ_PROF("wiener_bwd_finalize", stream);
     hipLaunchKernelGGL(k_wiener_bwd_finalize, dim3((t.nwork + 255) / 256), dim3(256), 0, stream, t.d_rows, t.d_work, t.nwork,
                        (const float*)stats, (float*)bstats); }
     { XSQ_PROF("wiener_bwd_apply", stream);
     hipLaunchKernelGGL(k_wiener_bwd_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
-                       (const float2*)X, (const float2*)Y0, (float2*)G, t.d_rows, (const float*)stats, (const float*)bstats,
-                       Bn, S, win_len); }
+                       (const float2*)X, (const float2*)Y0, Y0 ? nullptr : masks, (float2*)G, t.d_rows, (const float*)stats,
+                       (const float*)bstats, Bn, S, win_len); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

@@ -21,6 +21,28 @@ from . import _lib
 from .model import Unmix
 
 
+class PendingLoss:
+    """Loss of a step issued with ``wait=False``: ``result()`` (or indexing / iteration, like the tuple ``step``
+    returns) blocks until THAT step has finished on the device.  Valid for the trainer's last four steps."""
+
+    def __init__(self, trainer: "Trainer", ticket: int):
+        self._trainer, self._ticket, self._value = trainer, int(ticket), None
+
+    def result(self) -> Tuple[float, float, float]:
+        if self._value is None:
+            out = (C.c_double * 2)()
+            _lib.check(_lib.lib.xsq_train_loss(self._trainer._h, self._ticket, out), "xsq_train_loss")
+            mse, mask = float(out[0]), float(out[1])
+            self._value = (mse + mask, mse, mask)
+        return self._value
+
+    def __getitem__(self, i):
+        return self.result()[i]
+
+    def __iter__(self):
+        return iter(self.result())
+
+
 class Trainer:
     """Owns the device-side training state of one ``Unmix``.
 
@@ -66,8 +88,10 @@ class Trainer:
             pass
 
     # -- one step ------------------------------------------------------------------------
-    def step_arena(self, X: Tensor, Yt: Tensor, B: int, S: int, apply_update: bool = True) -> Tuple[float, float, float]:
-        """X: mix arena (2B channels), Yt: target arena (8B channels), both flat fp32 on the device."""
+    def step_arena(self, X: Tensor, Yt: Tensor, B: int, S: int, apply_update: bool = True, wait: bool = True):
+        """X: mix arena (2B channels), Yt: target arena (8B channels), both flat fp32 on the device.
+        ``wait=False``: returns a ``PendingLoss`` without waiting for the device (the next step can be issued before
+        this one's loss is looked at; the reference's ``loss.item()`` every step, training.py:110, is ``wait=True``)."""
         with torch.cuda.device(self.device):
             need = _lib.lib.xsq_train_workspace(self._h, B, S, 1 if self.wiener else 0)
             if need == 0:
@@ -75,28 +99,43 @@ class Trainer:
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            out = (C.c_double * 2)()
+            out = (C.c_double * 2)() if wait else None
             _lib.check(_lib.lib.xsq_train_step(self._h, X.data_ptr(), Yt.data_ptr(), B, S, 1 if self.wiener else 0,
                                                self.lr, self.weight_decay, 1 if apply_update else 0, out,
                                                self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()),
                        "xsq_train_step")
+            if not wait:     # the arenas must outlive the kernels that read them: hand them to the pending object
+                pending = PendingLoss(self, int(_lib.lib.xsq_train_ticket(self._h)))
+                pending._keep = (X, Yt)
         if apply_update:
             self.steps += 1
+        if not wait:
+            return pending
         mse, mask = float(out[0]), float(out[1])
         return mse + mask, mse, mask
 
     @torch.no_grad()
-    def step(self, x: Tensor, y_targets: Tensor, apply_update: bool = True) -> Tuple[float, float, float]:
-        """x (B, 2, N) mix, y_targets (4, B, 2, N): training.py:66-108."""
+    def step(self, x: Tensor, y_targets: Tensor, apply_update: bool = True, wait: bool = True):
+        """x (B, 2, N) mix, y_targets (4, B, 2, N): training.py:66-108.  Returns (loss, mse, mask) -- or, with
+        ``wait=False``, a ``PendingLoss`` that resolves to the same tuple."""
         x = x.to(self.device, torch.float32)
         y_targets = y_targets.to(self.device, torch.float32)
+        # the two transforms are independent: the targets' (4x the rows) goes to a side stream beside the mix's
+        main = torch.cuda.current_stream(self.device)
+        side = self.__dict__.setdefault("_side", None) or torch.cuda.Stream(device=self.device)
+        self._side = side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            Yt = self.nsgt(y_targets)
         Xc = self.nsgt(x)
-        Yt = self.nsgt(y_targets)
+        main.wait_stream(side)
+        for t in Yt:
+            t.record_stream(main)
         X, lead, S = self.table.as_arena(list(Xc))
         Ytg, lead_t, S_t = self.table.as_arena(list(Yt))
         if len(lead) != 2 or lead[1] != 2 or lead_t != (4, lead[0], 2) or S != S_t:
             raise ValueError(f"expected x (B, 2, N) and y_targets (4, B, 2, N); got arenas {lead} / {lead_t}")
-        return self.step_arena(X, Ytg, lead[0], S, apply_update)
+        return self.step_arena(X, Ytg, lead[0], S, apply_update, wait)
 
     # -- state ---------------------------------------------------------------------------
     def _read(self, what: int) -> "OrderedDict[str, Tensor]":
