@@ -322,3 +322,24 @@ def test_hip_training_step_at_config_size_matches_the_oracle(oracle_step16, prec
         assert err <= 2e-3 * scale + 2e-7, (precision, k, err, scale)
     print(f"\n[B=16 step, {precision}] worst strict gradient-norm error {worst:.2e} ({worst_key}); {len(over)} of "
           f"{len(grads_o)} tensors past 2e-3 (all upstream of a near-kink ReLU, all within 15 %): {over[:6]}")
+
+
+@pytest.mark.gpu
+def test_pending_loss_equals_the_waited_step_and_expires_after_four_steps():
+    """Trainer.step(wait=False): same step, same numbers, the loss just read later (by ticket, xsq_train_loss)."""
+    from xumx_slicq_amd import _lib
+    g = load_golden("training_step.npz")
+    x, y_t = _inputs(int(g["n"]))
+    _, tr_a = _trainer(False)
+    _, tr_b = _trainer(False)
+    waited = [tr_a.step(x, y_t) for _ in range(3)]
+    pend = [tr_b.step(x, y_t, wait=False) for _ in range(3)]          # three steps in flight before any loss is read
+    assert [tuple(p) for p in pend] == waited
+    assert pend[1][0] == waited[1][0] and pend[2].result() == waited[2]
+    sa, sb = tr_a.state_dict(), tr_b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    old = tr_b.step(x, y_t, wait=False)
+    for _ in range(4):
+        tr_b.step(x, y_t, wait=False)
+    with pytest.raises(_lib.XsqError):
+        old.result()                                                  # five steps later its ring slot has been reused

@@ -46,6 +46,14 @@ struct Band4Dev {
     int64_t win_off;    // float offset of g' (FWD) / wd (INV), Lg floats in window order q
 };
 
+// One tile of the radix-4 kernel WITH its band's descriptor (72 bytes, read with scalar loads in one go).  Through a
+// tile -> band index -> band table chain the prologue made two dependent round trips before the first operand address
+// was known.
+struct Tile4Dev {
+    int m0, ncb;        // first row; 16-column blocks of the band (1..10)
+    Band4Dev bd;
+};
+
 struct Band4Args {
     const Band4Dev* bands;
     const float* pool;      // matrices, twiddles and windows of this direction
@@ -73,7 +81,7 @@ constexpr int D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan bu
 #endif
 constexpr int D4H_ROWS = 32, D4H_NCB = 10;
 template <bool FWD>
-__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Args a, const TileDev* __restrict__ tiles, int ntiles) {
+__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4H_ROWS + 16 * D4H_NCB) * D4_LD];
     __shared__ __attribute__((aligned(16))) float2 twl[3 * D4_MPAD];      // w^(r t1), r = 1..3, of this tile's band
     __shared__ __attribute__((aligned(16))) float winl[4 * D4_MPAD];      // INV: dual window wd[q] of this tile's band
@@ -82,12 +90,12 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
     float* const Bs0 = lds + 2 * ABUF;          // [buf][col][20]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    const int ncb = t.narrow;                   // 16-column blocks of the band, 1..10 (uniform)
-    // By value: through a reference into a.bands the compiler had to RE-LOAD the fields after every store of the epilogue
-    // (they might alias), and each reload's s_waitcnt vmcnt(0) also waited for the store before it -- one HBM round trip
-    // per 16-byte store (tools/scan_isa.py counts such loads).
-    const Band4Dev bd = a.bands[t.group];
+    // By value: through a reference into global memory the compiler had to RE-LOAD the fields after every store of the
+    // epilogue (they might alias), and each reload's s_waitcnt vmcnt(0) also waited for the store before it -- one HBM
+    // round trip per 16-byte store (tools/scan_isa.py counts such loads).
+    const Tile4Dev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const int ncb = t.ncb;                      // 16-column blocks of the band, 1..10 (uniform)
+    const Band4Dev bd = t.bd;
     const int m_ = bd.m, Lg = bd.Lg, K = 2 * m_, M = a.BC * a.S;
     const int64_t BCS = (int64_t)a.BC * a.S;
 

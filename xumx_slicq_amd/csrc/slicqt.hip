@@ -285,16 +285,20 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
     auto key = std::make_tuple(3, rows, share);
     auto it = P->tiles.find(key);
     if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
-    std::vector<TileDev> t;
+    std::vector<Tile4Dev> t;
+    const Band4Dev* b4 = reinterpret_cast<const Band4Dev*>(P->bands4_host.data());
     const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
     for (int i = P->nbands4 - 1; i >= 0; --i) {
         const int ncb = (2 * P->bands4_m[i] + 15) / 16;
         for (int m0 = 0; m0 < span; m0 += D4H_ROWS)
-            for (int k = 0; k < copies; ++k) t.push_back(TileDev{i, m0 + k * span, 0, ncb});
+            for (int k = 0; k < copies; ++k) t.push_back(Tile4Dev{m0 + k * span, ncb, b4[i]});
     }
-    TileTable tt;
-    int rc = upload_tiles(t, &tt);
-    if (rc) return rc;
+    TileTable tt;                     // (d_tiles holds Tile4Dev entries for this key: cast at the launch sites)
+    tt.ntiles = (int)t.size();
+    if (!t.empty()) {
+        XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(Tile4Dev)));
+        XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(Tile4Dev), hipMemcpyHostToDevice));
+    }
     P->tiles[key] = tt;
     *out = tt;
     return XSQ_OK;
@@ -603,6 +607,8 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
             P->bands4_m.push_back(m);
         }
         P->nbands4 = (int)b4.size();
+        P->bands4_host.assign(reinterpret_cast<const unsigned char*>(b4.data()),
+                              reinterpret_cast<const unsigned char*>(b4.data()) + b4.size() * sizeof(Band4Dev));
         if (P->nbands4) {
             XSQ_HIP(hipMalloc(&P->d_bands4, b4.size() * sizeof(Band4Dev)));
             XSQ_HIP(hipMemcpy(P->d_bands4, b4.data(), b4.size() * sizeof(Band4Dev), hipMemcpyHostToDevice));
@@ -819,7 +825,7 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
         if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0, xin, mean, scale, split};
         XSQ_PROF("band_analysis_dft4", stream);
-        hipLaunchKernelGGL(band_dft4_full_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+        hipLaunchKernelGGL(band_dft4_full_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t4.d_tiles, t4.ntiles);
     }
     if (tt.ntiles) { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
@@ -895,7 +901,7 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
                      lds_fft(P) ? (int)P->sumFT : 0, mask, BCx, nullptr, nullptr, nullptr, 0};
         XSQ_PROF("band_synthesis_dft4", stream);
-        hipLaunchKernelGGL(band_dft4_full_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, t4.d_tiles, t4.ntiles);
+        hipLaunchKernelGGL(band_dft4_full_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t4.d_tiles, t4.ntiles);
     }
     // short bands: inside k_slice_irfft when the plan allows it, else dense GEMM + Z round trip
     const bool inl = lds_fft(P) && P->band_radix4 && P->short_inline && P->short_n1 > 0;
