@@ -76,6 +76,12 @@ int xsq_plan_set_band_radix4(xsq_plan* plan, int on);
  * track (the kernel is bound by its chain of memory / LDS round trips) and is kept as an A/B switch.  Ignored
  * when the plan is not eligible (rocFFT backend, other band lengths).                                       */
 int xsq_plan_set_short_inline(xsq_plan* plan, int on);
+/* hand-written slice FFT only: 1 = its 43 / 14 / 15-point butterflies on packed-fp32 vector instructions (v_pk_fma_f32
+ * on the (re, im) register pair: half the vector instructions, bitwise the same results).  Default 0, and meant to be
+ * switched on ONLY while no split-bf16 MFMA kernel can run beside the transform (xsq_model_set_precision mode 0): a
+ * packed-fp32 transform next to v_mfma_f32_16x16x32_bf16 waves of another stream returned wrong values on MI355X
+ * (tools/probe/pk_mfma_hazard.hip).  The Python Separator sets it per call from the model's mode. */
+int xsq_plan_set_packed_fft(xsq_plan* plan, int on);
 /* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
 int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);
 /* complex coefficients per channel-slice (sum_b F_b*T_b) */

@@ -614,3 +614,31 @@ def test_whitening_fused_into_the_analysis_epilogues_is_bitwise_equal(seps, name
         sep.fuse_whiten = True
         sep.chunk_size = 2621440
         sep.xumx_model.set_precision("fp32")
+
+
+def test_packed_slice_fft_follows_the_contraction_mode(seps):
+    """The packed-fp32 slice FFT kernels run only while every model of the process contracts in fp32 (beside split-bf16
+    MFMA waves of another stream a packed transform returned wrong values): the separator switches
+    them per call, a bf16 mode anywhere in the process switches them off, and the fp32 stems do not depend on the switch."""
+    sep = seps["offline_phasemix"]
+    x = synth_audio(200_000, seed=5).cuda()
+    eng = sep.nsgt.nsgt.nsgt
+    b = sep(x).clone()                             # default: scalar kernels
+    assert not eng._packed_fft
+    sep.packed_fft = True                          # opt in
+    try:
+        a = sep(x).clone()
+        assert sep._packed_fft() and eng._packed_fft and torch.equal(a, b)
+        other = seps["realtime"].xumx_model
+        other.set_precision("bf16x3")              # ANOTHER model of the process goes split-bf16
+        try:
+            sep(x)
+            assert not eng._packed_fft
+        finally:
+            other.set_precision("fp32")
+        c = sep(x)
+        assert eng._packed_fft and torch.equal(a, c)
+    finally:
+        del sep.packed_fft
+        sep(x)
+        assert not eng._packed_fft

@@ -40,3 +40,24 @@ def test_product_flags_are_exact_next_to_every_mfma_aggressor(tmp_path):
         print("\npacked-fp32 build of the probe:\n" + out_on)
     except Exception as e:      # noqa: BLE001
         print("packed build of the probe did not run:", e)
+
+
+def test_hand_packed_transform_is_exact_next_to_the_fp32_aggressors(tmp_path):
+    """The hand-placed v_pk_* butterflies of k_slice_rfft<512, true> (slice_fft.h) are launched only beside fp32 work.
+    Probe built like csrc/slicqt.o (packed ops on, SLP vectoriser off): the scalar kernel is the control and must be exact
+    beside EVERY aggressor; the packed kernel must be exact beside the aggressors of the fp32 path -- v_mfma_f32_32x32x2_f32,
+    v_mfma_f32_16x16x4_f32, plain VALU, nothing -- and bitwise equal to the scalar kernel.  What it does beside the split-bf16
+    MFMAs is printed, not asserted (the Separator never pairs them: test_packed_slice_fft_follows_the_contraction_mode)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available on this box")
+    rows, out = _run(_build(tmp_path, "pk_hand", ["-fno-slp-vectorize", "-DPROBE_HAND_PK"]))
+    print("\n" + out)
+    assert "bitwise equal" in out and "DIFFERENT BITS" not in out, out
+    per_victim = 6
+    assert len(rows) >= 2 * per_victim, out
+    scalar, packed = rows[:per_victim], rows[per_victim:2 * per_victim]
+    assert all(bad == 0 for _, bad, _ in scalar), out
+    fp32_side = ("v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x4_f32", "plain VALU (no MFMA)", "none")
+    for name, bad, _ in packed:
+        if name.replace("aggressor ", "").strip() in fp32_side:
+            assert bad == 0, out

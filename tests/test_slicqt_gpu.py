@@ -179,3 +179,25 @@ def test_short_bands_in_kernel_equal_the_dense_gemm_path(fb, n, lead):
     assert torch.equal(placed, ref_o)
     # nothing outside the rows was touched
     assert bool(torch.isnan(out[0])) and bool(torch.isnan(out[1 + n - 1: 1 + n + 3]).all())
+
+
+def test_packed_butterflies_are_bitwise_the_scalar_ones(fb):
+    """k_slice_rfft<512, true> / k_slice_irfft<512, true> (43 / 14 / 15-point butterflies on hand-placed v_pk_fma_f32 /
+    v_pk_add_f32, slice_fft.h) against the scalar kernels: every lane of a packed instruction is the IEEE operation of its
+    scalar twin, in the same order -- coefficients and reconstructed audio must agree bit for bit, at several sizes
+    (edge slices, interior slices, odd lengths)."""
+    base, enc, dec = fb
+    eng = base.nsgt
+    try:
+        for n in (9031, 70001, 300_000):
+            x = synth_audio(n, seed=7 + n).cuda()
+            eng.set_packed_fft(False)
+            C0 = [c.clone() for c in enc(x)]
+            y0 = dec(C0, n).clone()
+            eng.set_packed_fft(True)
+            C1 = enc(x)
+            assert all(torch.equal(a, b) for a, b in zip(C0, C1)), n
+            y1 = dec(C1, n)
+            assert torch.equal(y0, y1), (n, float((y0 - y1).abs().max()))
+    finally:
+        eng.set_packed_fft(False)

@@ -7,6 +7,11 @@
 //   hipcc -O3 --offload-arch=gfx950 -I xumx_slicq_amd/csrc tools/probe/pk_mfma_hazard.hip -o /tmp/pk_on            (packed ops on)
 //   hipcc -O3 --offload-arch=gfx950 -I xumx_slicq_amd/csrc -DPROBE_NO_PK -Xclang -target-feature -Xclang -packed-fp32-ops ... -o /tmp/pk_off
 //   /tmp/pk_on; /tmp/pk_off          prints, per aggressor, the number of trials (of 20) with a corrupted transform
+// Round 3: the library's slicqt.hip is built with packed ops ON and the SLP vectoriser OFF (csrc/Makefile), so that only
+// the hand-placed v_pk_* codelets of k_slice_rfft<512, true> / k_slice_irfft<512, true> are packed:
+//   hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize -DPROBE_HAND_PK -I xumx_slicq_amd/csrc ... -o /tmp/pk_hand
+// runs the scalar k_slice_rfft<512> (control) and the hand-packed k_slice_rfft<512, true> as victims, with
+// v_mfma_f32_16x16x4_f32 among the aggressors (the fp32 path runs 32x32x2 and 16x16x4 MFMAs beside the transforms).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +45,9 @@ __global__ __launch_bounds__(256) void k_aggressor(float* sink, int iters) {
         } else if (KIND == 2) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4, 0, 0, 0);
+        } else if (KIND == 4) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(s, 0.5f * s, acc4, 0, 0, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 64; ++u) v = fmaf(v, 0.999f, 1e-3f);      // plain VALU, no MFMA
@@ -88,13 +96,32 @@ int main() {
     const FftTables tabs{T, T + FFT_R1 * FFT_M1, T + FFT_R1 * FFT_M1 + FFT_R2 * FFT_R3};
     hipStream_t s1, s2;
     CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
-    auto victim = [&](float2* out) { hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, s1, x, tw, tabs, out, S, n, h); };
+#ifdef PROBE_HAND_PK
+    const int nvictims = 2;
+    const char* vnames[] = {"k_slice_rfft<512> (scalar)", "k_slice_rfft<512, true> (hand-placed v_pk_*)"};
+#else
+    const int nvictims = 1;
+    const char* vnames[] = {"k_slice_rfft<256>"};
+#endif
+    std::vector<float2> a((size_t)rows * (FFT_N + 1)), b(a.size()), a0;
+    const char* names[] = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_bf16", "plain VALU (no MFMA)", "none",
+                           "v_mfma_f32_16x16x4_f32"};
+    for (int vic = 0; vic < nvictims; ++vic) {
+    auto victim = [&](float2* out) {
+#ifdef PROBE_HAND_PK
+        if (vic == 1) hipLaunchKernelGGL((k_slice_rfft<512, true>), dim3(rows), dim3(512), 0, s1, x, tw, tabs, out, S, n, h);
+        else hipLaunchKernelGGL((k_slice_rfft<512, false>), dim3(rows), dim3(512), 0, s1, x, tw, tabs, out, S, n, h);
+#else
+        hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, s1, x, tw, tabs, out, S, n, h);
+#endif
+    };
     victim(Uref);
     CK(hipDeviceSynchronize());
-    std::vector<float2> a((size_t)rows * (FFT_N + 1)), b(a.size());
     CK(hipMemcpy(a.data(), Uref, a.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[] = {"v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_bf16", "plain VALU (no MFMA)", "none"};
-    for (int kind = 0; kind < 5; ++kind) {
+    if (vic == 0) a0 = a;
+    else printf("victim %s alone vs victim %s alone: %s\n", vnames[vic], vnames[0], memcmp(a.data(), a0.data(), a.size() * 8) ? "DIFFERENT BITS" : "bitwise equal");
+    printf("victim %s\n", vnames[vic]);
+    for (int kind = 0; kind < 6; ++kind) {
         int bad = 0;
         long badvals = 0;
         for (int trial = 0; trial < 20; ++trial) {
@@ -105,6 +132,7 @@ int main() {
             if (kind == 1) hipLaunchKernelGGL(k_aggressor<1>, dim3(512), dim3(256), 0, s2, sink, iters / 2);
             if (kind == 2) hipLaunchKernelGGL(k_aggressor<2>, dim3(512), dim3(256), 0, s2, sink, iters);
             if (kind == 3) hipLaunchKernelGGL(k_aggressor<3>, dim3(512), dim3(256), 0, s2, sink, iters / 4);
+            if (kind == 5) hipLaunchKernelGGL(k_aggressor<4>, dim3(512), dim3(256), 0, s2, sink, iters);
             victim(U);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(b.data(), U, b.size() * 8, hipMemcpyDeviceToHost));
@@ -115,6 +143,7 @@ int main() {
         }
         printf("aggressor %-28s: %2d / 20 transforms differ from the run alone (%ld values)\n", names[kind], bad, badvals);
         fflush(stdout);
+    }
     }
     // ---- registers-only victim (explicit v_pk_fma_f32 vs v_fma_f32 chains; same binary in both builds) ----
     const int nb = 2048, nt = nb * 256, vit = 200000;

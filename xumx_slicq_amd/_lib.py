@@ -48,6 +48,7 @@ _SIGS = {
     "xsq_plan_set_fft_backend": (C.c_int, [_vp, C.c_int]),
     "xsq_plan_set_band_radix4": (C.c_int, [_vp, C.c_int]),
     "xsq_plan_set_short_inline": (C.c_int, [_vp, C.c_int]),
+    "xsq_plan_set_packed_fft": (C.c_int, [_vp, C.c_int]),
     "xsq_plan_block_table": (C.c_int, [_vp, _vp]),
     "xsq_plan_coefs_per_slice": (C.c_int64, [_vp]),
     "xsq_plan_num_slices": (C.c_int, [_vp, C.c_int64]),

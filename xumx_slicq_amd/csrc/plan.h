@@ -47,6 +47,7 @@ struct xsq_plan {
     int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap
     int phase_begin[5] = {0, 0, 0, 0, 0};
     // short bands (below the radix-4 split) synthesised inside k_slice_irfft (slice_fft.h: ShortSched); valid when short_n1 > 0
+    int packed_fft = 0;             // 1: slice FFT codelets on v_pk_* (xsq_plan_set_packed_fft; only beside fp32 contractions)
     int short_inline = 0;           // 0 (default, faster as measured): short bands on the dense GEMM + Z round trip (band_synthesis_gemm)
     void *d_s_item1 = nullptr, *d_s_tw1 = nullptr;
     int *d_s_item2 = nullptr, *d_s_tgt = nullptr;

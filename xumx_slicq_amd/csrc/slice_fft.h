@@ -38,17 +38,54 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Complex products with the fused multiply-adds spelled out (and contraction off around them): left to the compiler,
+// `a.x b.x - a.y b.y` may become fma(a.x, b.x, -(a.y b.y)) in one instantiation of a kernel and fma(-a.y, b.y, a.x b.x)
+// in another -- the scalar and the packed-butterfly builds of the forward transform differed in the last bit of 90 % of
+// their outputs that way (round 3), and "the packed kernels return the bits of the scalar ones" is the property the
+// packed-fp32 hazard tests stand on.
 __device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#pragma clang fp contract(off)
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {   // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#pragma clang fp contract(off)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+
+// ---- packed-fp32 forms (PK = true) ---------------------------------------------------------------------------------
+// The butterflies below do the SAME thing to the real and the imaginary part of a value with one constant:
+// P.x = fma(a.x, c, P.x); P.y = fma(a.y, c, P.y) -- one v_pk_fma_f32 on the (x, y) register pair with the constant
+// broadcast from a uniform register.  Each lane of a packed instruction is the IEEE operation of its scalar twin, in
+// the same order on the same operands: the PK codelets are BITWISE the scalar ones at half the vector instructions
+// (the transforms are bound by their instruction count: 64 % vector-ALU issue utilisation, profiles/r03z_pmc_sq.csv).
+// Hand-placed because the compiler's own packing needs more registers than the 128 of a 512-thread workgroup pair
+// (122 spilled registers, 0.66 -> 1.09 ms, round 3) and because the library is BUILT with packed ops off (Makefile:
+// next to split-bf16 MFMAs of another stream a packed-ops transform returned wrong values; the packed kernels are only
+// launched while the model runs its contractions in fp32 -- xsq_plan_set_packed_fft).  Operand selects / negates:
+// tools/probe/pk_ops.hip pins their meaning on the hardware.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f to_v2(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a + i b = (a.x - b.y, a.y + b.x)   /   a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f pk_add_i(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub_i(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// acc + a * u, u = the LOW (HI = false) or HIGH half of the uniform pair cs, negated when NEG
+template <bool HI, bool NEG>
+__device__ __forceinline__ v2f pk_fma_u(v2f a, v2f cs, v2f acc) {
+    v2f d;
+    if constexpr (!HI && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "s"(cs), "v"(acc));
+    else if constexpr (!HI && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "s"(cs), "v"(acc));
+    else if constexpr (HI && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "s"(cs), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(a), "s"(cs), "v"(acc));
+    return d;
 }
 
 // X[k] = sum_n x[n] exp(SIGN * 2 pi i n k / R), results handed to emit(k, X[k]) as they are produced.
 // PARTS = 2 splits the OUTPUTS between two callers that hold the same inputs (two wave groups of a 512-thread
 // workgroup): PART 0 emits k = 0 and the pairs k = 1 .. KSPLIT, PART 1 the pairs KSPLIT + 1 .. H (odd R only).
-template <int R, int SIGN, int PART = 0, int PARTS = 1, class Emit>
+template <int R, int SIGN, int PART = 0, int PARTS = 1, bool PK = false, class Emit>
 __device__ __forceinline__ void dft_small(const float2 (&x)[R], Emit&& emit) {
     constexpr int H = (R - 1) / 2;
     constexpr bool EVEN = (R % 2) == 0;
@@ -56,6 +93,47 @@ __device__ __forceinline__ void dft_small(const float2 (&x)[R], Emit&& emit) {
     constexpr int KSPLIT = (H + 1) / 2;
     constexpr int K_LO = PARTS == 1 ? 1 : (PART == 0 ? 1 : KSPLIT + 1);
     constexpr int K_HI = PARTS == 1 ? H : (PART == 0 ? KSPLIT : H);
+    if constexpr (PK) {
+        v2f a[H], b[H];
+        const v2f x0 = to_v2(x[0]);
+        v2f s0 = x0;
+        static_for<1, H + 1>([&](auto nc) {
+            constexpr int n = nc;
+            a[n - 1] = pk_add(to_v2(x[n]), to_v2(x[R - n]));
+            b[n - 1] = pk_sub(to_v2(x[n]), to_v2(x[R - n]));
+            s0 = pk_add(s0, a[n - 1]);
+        });
+        if constexpr (EVEN) s0 = pk_add(s0, to_v2(x[R / 2]));
+        if constexpr (PART == 0) emit(0, to_f2(s0));
+        static_for<K_LO, K_HI + 1>([&](auto kc) {
+            constexpr int k = kc;
+            v2f P = x0;
+            if constexpr (EVEN) P = (k & 1) ? pk_sub(P, to_v2(x[R / 2])) : pk_add(P, to_v2(x[R / 2]));
+            v2f Q = v2f{0.f, 0.f};
+            static_for<1, H + 1>([&](auto nc) {
+                constexpr int n = nc;
+                constexpr int i = (n * k) % R;
+                constexpr float c = DftTw<R>::c[i];
+                constexpr float sn = DftTw<R>::s[i];
+                constexpr float sa = sn < 0.f ? -sn : sn;
+                const v2f cs = v2f{c, sa};                       // uniform pair: cos in the low half, |sin| in the high half
+                P = pk_fma_u<false, false>(a[n - 1], cs, P);     // P += a * c
+                Q = pk_fma_u<true, (sn < 0.f)>(b[n - 1], cs, Q); // Q += b * s
+            });
+            // X[k] = P + SIGN*i*Q,  X[R-k] = P - SIGN*i*Q
+            if constexpr (SIGN > 0) { emit(k, to_f2(pk_add_i(P, Q))); emit(R - k, to_f2(pk_sub_i(P, Q))); }
+            else { emit(k, to_f2(pk_sub_i(P, Q))); emit(R - k, to_f2(pk_add_i(P, Q))); }
+        });
+        if constexpr (EVEN) {
+            v2f P = ((R / 2) & 1) ? pk_sub(x0, to_v2(x[R / 2])) : pk_add(x0, to_v2(x[R / 2]));
+            static_for<1, H + 1>([&](auto nc) {
+                constexpr int n = nc;
+                P = (n & 1) ? pk_sub(P, a[n - 1]) : pk_add(P, a[n - 1]);
+            });
+            emit(R / 2, to_f2(P));
+        }
+        return;
+    }
     float2 a[H], b[H];
     float2 s0 = x[0];
     static_for<1, H + 1>([&](auto nc) {
@@ -160,8 +238,9 @@ __device__ __forceinline__ void short_dft(float2* base) {      // in place: X[k]
 // here on the load side, where the 14 table reads of a butterfly are independent loads issued
 // together (inside step 1 each one sat behind a 43-point butterfly).  w2s = step-2 twiddles in LDS.
 // SIGN = +1 uses the conjugate twiddles.
-template <int SIGN, int NT>
+template <int SIGN, int NT, bool PK = false>
 __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restrict__ w1, const float2* w2s, int tid) {
+#pragma clang fp contract(off)
     // 645 butterflies over NT threads = 3 (2) rounds; the 14 step-1 twiddles of round i + 1 are requested before
     // round i computes (they come from L2: one exposed round trip per round otherwise)
     constexpr int NB = FFT_R1 * FFT_R3, ROUNDS = (NB + NT - 1) / NT;
@@ -186,7 +265,7 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
             for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = base[n2 * FFT_R3];
 #pragma unroll
             for (int n2 = 0; n2 < FFT_R2; ++n2) v[n2] = SIGN < 0 ? c_mul(v[n2], w[r & 1][n2]) : c_mulc(v[n2], w[r & 1][n2]);
-            dft_small<FFT_R2, SIGN>(v, [&](int k2, float2 X) {
+            dft_small<FFT_R2, SIGN, 0, 1, PK>(v, [&](int k2, float2 X) {
                 const float2 t = w2s[k2 * FFT_R3 + n3];
                 base[k2 * FFT_R3] = SIGN < 0 ? c_mul(X, t) : c_mulc(X, t);
             });
@@ -198,7 +277,7 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
         float2 v[FFT_R3];
 #pragma unroll
         for (int n3 = 0; n3 < FFT_R3; ++n3) v[n3] = base[n3];
-        dft_small<FFT_R3, SIGN>(v, [&](int k3, float2 X) { base[k3] = X; });
+        dft_small<FFT_R3, SIGN, 0, 1, PK>(v, [&](int k3, float2 X) { base[k3] = X; });
     }
     __syncthreads();
 }
@@ -209,10 +288,11 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
 //           (lanes 256..511), both holding the column's 43 inputs: the longest serial stage of the transform is
 //           halved, steps 2 / 3 take 2 rounds instead of 3, and a CU holds 16 waves instead of 8 -- the kernel is
 //           bound by dependent LDS / memory round trips, not by issue slots (27 % VALU utilisation measured).
-template <int NT>
+template <int NT, bool PK = false>
 __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
                                                               const FftTables T, float2* __restrict__ U,
                                                               int S, int64_t n, int h) {
+#pragma clang fp contract(off)          // fused multiply-adds only where written (fmaf): same bits from every instantiation
     __shared__ float2 Z[FFT_N];
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
@@ -250,7 +330,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
                     v[n1].y = (i + 1 >= 0 && i + 1 < n) ? w.y * xb : 0.f;
                 }
             }
-            dft_small<FFT_R1, -1>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
+            dft_small<FFT_R1, -1, 0, 1, PK>(v, [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; });
         }
     } else {
         // 512 threads: the windowed samples go through LDS once (every lane 18 consecutive-lane pairs, all loads in
@@ -287,12 +367,12 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
         __syncthreads();
         if (on) {
             auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
-            if (part == 0) dft_small<FFT_R1, -1, 0, 2>(v, put);
-            else dft_small<FFT_R1, -1, 1, 2>(v, put);
+            if (part == 0) dft_small<FFT_R1, -1, 0, 2, PK>(v, put);
+            else dft_small<FFT_R1, -1, 1, 2, PK>(v, put);
         }
     }
     __syncthreads();
-    fft_steps_2_3<-1, NT>(Z, T.w1, w2s, tid);
+    fft_steps_2_3<-1, NT, PK>(Z, T.w1, w2s, tid);
     // real post-processing: U[k] = E + G, U[N-k] = conj(E - G), E = (Z[k] + conj Z[N-k])/2,
     // G = -i/2 * W_L^k * (Z[k] - conj Z[N-k])
     float2* Ur = U + (int64_t)row * (FFT_N + 1);
@@ -335,10 +415,11 @@ struct OlaArgs {
 };
 
 
-template <int NT>
+template <int NT, bool PK = false>
 __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
                                                       const FftTables T, const OlaArgs O, const ShortSched SS,
                                                       const ShortIn SI) {
+#pragma clang fp contract(off)          // fused multiply-adds only where written (fmaf): same bits from every instantiation
     __shared__ float2 Z[FFT_N + 1];        // bins 0..N while gathering, then the complex sequence
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
@@ -529,13 +610,13 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
         if constexpr (NT != 256) __syncthreads();
         if (on) {
             auto put = [&](int k1, float2 X) { Z[k1 * FFT_M1 + m] = X; };
-            if constexpr (NT == 256) dft_small<FFT_R1, +1>(v, put);
-            else if (part == 0) dft_small<FFT_R1, +1, 0, 2>(v, put);
-            else dft_small<FFT_R1, +1, 1, 2>(v, put);
+            if constexpr (NT == 256) dft_small<FFT_R1, +1, 0, 1, PK>(v, put);
+            else if (part == 0) dft_small<FFT_R1, +1, 0, 2, PK>(v, put);
+            else dft_small<FFT_R1, +1, 1, 2, PK>(v, put);
         }
     }
     __syncthreads();
-    if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1, NT>(Z, T.w1, w2s, tid);
+    if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1, NT, PK>(Z, T.w1, w2s, tid);
     if (XSQ_ABLATE & 128) return;
     // samples 2nn, 2nn+1 of the segment = Re / Im of sequence element nn; output index i = (2s-2)h + 2nn
     float* const yr = O.y + (O.row_off ? O.row_off[bc] : (int64_t)bc * O.length);

@@ -734,6 +734,12 @@ int xsq_plan_set_band_radix4(xsq_plan* P, int on) {
     return XSQ_OK;
 }
 
+int xsq_plan_set_packed_fft(xsq_plan* P, int on) {
+    XSQ_REQUIRE(P, "xsq_plan_set_packed_fft: null plan");
+    P->packed_fft = on ? 1 : 0;
+    return XSQ_OK;
+}
+
 int xsq_plan_set_short_inline(xsq_plan* P, int on) {
     XSQ_REQUIRE(P, "xsq_plan_set_short_inline: null plan");
     P->short_inline = on ? 1 : 0;
@@ -806,7 +812,8 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
     }
     if (lds_fft(P)) {
         XSQ_PROF("slice_rfft", stream);
-        if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
+        if (fft_threads(0) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_rfft<512, true>), dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
+        else if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
         else hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h);
     } else {
         { XSQ_PROF("slice_window", stream);
@@ -927,7 +934,8 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         for (int parity = 0; parity < 2; ++parity) {
             const int nsl = (S + 1 - parity) / 2;
             OlaArgs O{y, row_offsets, S, P->h, parity, length};
-            if (fft_threads(1) == 512) hipLaunchKernelGGL(k_slice_irfft<512>, dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            if (fft_threads(1) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (fft_threads(1) == 512) hipLaunchKernelGGL(k_slice_irfft<512>, dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else hipLaunchKernelGGL(k_slice_irfft<256>, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
         }
         XSQ_HIP(hipGetLastError());

@@ -29,6 +29,18 @@ import os
 # xsq_model_set_precision modes (include/xumx_slicq_hip.h)
 _PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
 
+# Owners (models, trainers) whose contractions currently run on split-bf16 MFMAs.  While the set is non-empty no
+# packed-fp32 slice FFT may be launched in this process (``split_bf16_active``; SliCQEngine.set_packed_fft).
+_SPLIT_BF16_OWNERS = set()
+
+
+def note_precision(owner, precision: str):
+    (_SPLIT_BF16_OWNERS.discard if precision == "fp32" else _SPLIT_BF16_OWNERS.add)(id(owner))
+
+
+def split_bf16_active() -> bool:
+    return bool(_SPLIT_BF16_OWNERS)
+
 
 class _CausalConv2d(Conv2d):
     """model.py:274-290: left-pads time by kernel_width-1 (parameter holder here)."""
@@ -185,6 +197,7 @@ class Unmix(nn.Module):
         self.precision = os.environ.get("XSQ_CDAE_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
             raise ValueError(f"XSQ_CDAE_PRECISION={self.precision!r} not in {sorted(_PRECISIONS)}")
+        note_precision(self, self.precision)
 
     def freeze(self):
         for p in self.parameters():
@@ -268,12 +281,14 @@ class Unmix(nn.Module):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision {precision!r} not in {sorted(_PRECISIONS)}")
         self.precision = precision
+        note_precision(self, precision)
         for idx, (_ver, h) in self._handles.items():
             with torch.cuda.device(idx):       # the split-weight pool is allocated / converted on the model's device
                 _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
 
     def __del__(self):
         try:
+            _SPLIT_BF16_OWNERS.discard(id(self))
             for _, h in self._handles.values():
                 _lib.lib.xsq_model_destroy(h)
         except Exception:

@@ -81,7 +81,7 @@ class Separator(nn.Module):
                 int(getattr(self, "max_stack", 8)), int(getattr(self, "pass_streams", 1)),
                 m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused(),
                 bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")),
-                bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")))
+                bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")), self._packed_fft())
 
     def drop_graphs(self):
         """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
@@ -120,6 +120,19 @@ class Separator(nn.Module):
         static_in.copy_(audio_big)
         graph.replay()
         return static_out
+
+    def _packed_fft(self) -> bool:
+        """Packed-fp32 butterflies in the slice FFTs (``packed_fft = True`` / XSQ_PACKED_FFT=1; bitwise the scalar ones at
+        half the butterflies' vector instructions).  OFF by default: measured, they change nothing -- the transforms are
+        bound by their HBM phases (band-spectrum gather 0.31 ms, output / overlap-add 0.15 ms of the inverse's 0.66 ms; the
+        43 / 14 / 15-point butterflies together 0.11 ms).  When asked for, they run only while no model
+        or trainer of this process contracts on split-bf16 MFMAs: next to v_mfma_f32_16x16x32_bf16 waves of another stream
+        the packed transform returns wrong values (tools/probe/pk_mfma_hazard.hip)."""
+        from .model import split_bf16_active
+        on = bool(getattr(self, "packed_fft", os.environ.get("XSQ_PACKED_FFT", "0") != "0")) and not split_bf16_active()
+        self.nsgt.nsgt.nsgt.set_packed_fft(on)
+        self.insgt.nsgt.nsgt.set_packed_fft(on)
+        return on
 
     def _fused(self) -> bool:
         """Mix-phase models: the CDAE writes the masks only and the inverse transform forms mask * X while it
@@ -164,6 +177,7 @@ class Separator(nn.Module):
         if audio.dim() != 3 or audio.shape[1] != 2:
             raise ValueError(f"audio must be (items * nb_samples, 2, n); got {tuple(audio.shape)}")
         n = audio.shape[-1]
+        self._packed_fft()
         if n > self.chunk_size:
             raise ValueError(f"work items are at most chunk_size = {self.chunk_size} samples (got {n})")
         if tuple(row_offsets.shape) != (4, audio.shape[0], 2) or row_offsets.dtype != torch.int64:
@@ -187,6 +201,7 @@ class Separator(nn.Module):
         nb, N, cs = audio_big.shape[0], audio_big.shape[-1], self.chunk_size
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
         dev = audio_big.device
+        self._packed_fft()
         # every chunk's stems are written straight into their place of the result (the hard concat
         # of separator.py:231 without a copy): packed channel (target, [chunk,] b, c) -> out row
         out = torch.empty(4, nb, 2, N, dtype=torch.float32, device=dev)

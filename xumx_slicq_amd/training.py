@@ -76,12 +76,16 @@ class Trainer:
         if precision not in ("fp32", "bf16x6"):
             raise ValueError(f"precision {precision!r}: the training step offers 'fp32' and 'bf16x6'")
         self.precision = precision
+        from .model import note_precision
+        note_precision(self, precision)          # bf16x6: no packed-fp32 slice FFT in this process meanwhile
         _lib.check(_lib.lib.xsq_train_set_precision(self._h, 2 if precision == "bf16x6" else 0), "xsq_train_set_precision")
         self._ws = None
         self.steps = 0
 
     def __del__(self):
         try:
+            from .model import note_precision
+            note_precision(self, "fp32")
             if self._h:
                 _lib.lib.xsq_train_destroy(self._h)
         except Exception:

@@ -61,6 +61,18 @@ class SliCQEngine:
         for h in self._handles.values():
             _lib.check(_lib.lib.xsq_plan_set_band_radix4(h, int(self._band_radix4)), "xsq_plan_set_band_radix4")
 
+    def set_packed_fft(self, on: bool):
+        """True: the hand-written slice FFT runs its butterflies on packed-fp32 vector instructions (half the vector
+        instructions, bitwise the same results).  Off by default; ``Separator`` switches it on per call while every model
+        of the process runs its contractions in fp32 -- a packed-fp32 transform next to split-bf16 MFMA waves of another
+        stream returned wrong values on MI355X."""
+        on = bool(on)
+        if on == getattr(self, "_packed_fft", False):
+            return
+        self._packed_fft = on
+        for h in self._handles.values():
+            _lib.check(_lib.lib.xsq_plan_set_packed_fft(h, int(on)), "xsq_plan_set_packed_fft")
+
     def set_short_inline(self, on: bool):
         """False (default): bands with Lg < 48 on the dense GEMM with a round trip through the workspace; True: the inverse
         transform synthesises them inside the slice-FFT kernel (A/B switch, same results to fp32 rounding; measured slower)."""
@@ -89,6 +101,7 @@ class SliCQEngine:
                        "xsq_plan_set_band_radix4")
             _lib.check(_lib.lib.xsq_plan_set_short_inline(h, int(getattr(self, "_short_inline", False))),
                        "xsq_plan_set_short_inline")
+            _lib.check(_lib.lib.xsq_plan_set_packed_fft(h, int(getattr(self, "_packed_fft", False))), "xsq_plan_set_packed_fft")
             self._handles[idx] = h
         return h
 
