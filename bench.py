@@ -127,7 +127,8 @@ _PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2O
               "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
               "slice_irfft_ola": ["k_slice_irfft"],
               "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"],
-              "wiener_stats": ["k_wiener_stats"], "wiener_apply": ["k_wiener_apply"]}
+              "wiener_stats": ["k_wiener_stats_masked", "k_wiener_stats"], "wiener_apply": ["k_wiener_apply_masked", "k_wiener_apply"],
+              "place_rows": ["k_place_rows"]}
 
 
 def pmc_traffic(kernel, tag=None):

@@ -20,6 +20,9 @@
 #include "gemm_tile_bf3.h"
 #include "gemm_tile_bf6.h"
 
+#ifndef XSQ_SLAB_PRIO
+#define XSQ_SLAB_PRIO 0     // diagnostic A/B builds: 1 static priority for waves 4..7, 2 priority around every MFMA cluster
+#endif
 #ifndef XSQ_SLAB_ABL
 #define XSQ_SLAB_ABL 0      // diagnostic builds: 1 no MFMAs, 2 no fragment reads, 4 no B loads, 8 no slab loads, 16 no epilogue
 #endif
@@ -209,6 +212,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     // into LDS -- so that slot parity = LDS tile = register set and every index below is compile-time.  The
     // K-step of slot s is loaded in slot s - 3, written to tile s & 1 in slot s - 1 (last read in slot s - 2).
     constexpr int NKS = 7;
+#if XSQ_SLAB_PRIO == 1       // diagnostic A/B: static priority for the second-dispatched half of the workgroup
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
     load_slab(0);
     load_b(0, 0, 0);
     store_slab();
@@ -228,6 +234,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                     const int k = 32 * ks + 16 * c;
                     if (k < SLAB_KRUN) {       // compile-time: the second half of the last K-step does not exist
                         if constexpr (MODE == 3) {
+#if XSQ_SLAB_PRIO == 2       // diagnostic A/B: priority raised around every MFMA cluster
+                            __builtin_amdgcn_s_setprio(1);
+#endif
                             const float* Bf = reinterpret_cast<const float*>(Bb);
                             const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
                             const float4 ahi = *reinterpret_cast<const float4*>(&slabF[a_base + k + 4]);
@@ -258,6 +267,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                                              : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]),
                                                "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
                             }
+#if XSQ_SLAB_PRIO == 2
+                            __builtin_amdgcn_s_setprio(0);
+#endif
                         } else if constexpr (MODE == 0) {
                             const float* Bf = reinterpret_cast<const float*>(Bb);
                             const float4 alo = *reinterpret_cast<const float4*>(&slabF[a_base + k]);
