@@ -44,6 +44,7 @@ struct xsq_plan {
     std::vector<int> bands4_m, bands4_small;   // host copies: m of each eligible band; indices of the other bands
     int fft_backend = 0;            // 0: hand-written LDS FFT when L == 18060, else rocFFT; 1: always rocFFT
     float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)
+    unsigned short* d_tgt16 = nullptr;   // the same table as 16-bit bins (0xFFFF = none) + one pad entry: pairs of entries load as one dword
     int* d_tgt = nullptr;           // (sumFT) target bin per phase-ordered entry; null if bands of one phase overlap
     int phase_begin[5] = {0, 0, 0, 0, 0};
     // short bands (below the radix-4 split) synthesised inside k_slice_irfft (slice_fft.h: ShortSched); valid when short_n1 > 0

@@ -20,6 +20,15 @@
 #include "common.h"
 #include "dft_tables.h"
 
+#ifndef XSQ_FFT_STAMP
+#define XSQ_FFT_STAMP 0             // diagnostic build: phase time stamps of k_slice_irfft (tools/fft_phases.py)
+#endif
+#ifndef XSQ_FFT_DEPHASE
+#define XSQ_FFT_DEPHASE 0           // s_sleep(127) units (~3.9 us each) by which odd workgroups of the first wave start late
+#endif
+#ifndef XSQ_FFT_DEPHASE_SLOTS
+#define XSQ_FFT_DEPHASE_SLOTS 512   // workgroup slots of the chip for the 512-thread transforms (256 CUs x 2)
+#endif
 #ifndef XSQ_ABLATE
 #define XSQ_ABLATE 0      // diagnostic builds (tools/ablate.sh): 16 no gather, 32 no radix-43, 64 no steps 2/3, 128 no output
 #endif
@@ -196,6 +205,7 @@ struct FftTables {
 // fixed order => bitwise reproducible) from contiguous, independent, coalesced global loads.
 struct GatherSched {
     const int* tgt;        // (sumLg) target bin of each entry, -1 when outside [0, N]
+    const unsigned short* tgt16;   // the same as 16-bit values (0xFFFF = none), padded: entries (2j, 2j + 1) load as one dword
     int begin[5];          // entry range of phase p is [begin[p], begin[p+1])
     int lo[4];             // first entry of phase p that is gathered from Z (= begin[p] unless the short bands run in-kernel)
     int row_len;           // entries per row (sum of band lengths)
@@ -299,7 +309,6 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
     const int row = blockIdx.x;
     const int bc = row / S, s = row - bc * S;
     const float* xr = x + (int64_t)bc * n;
-    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
     const int64_t i0 = (int64_t)(2 * s - 2) * h;
     const int part = tid >> 8, m = tid & 255;            // wave-uniform part
     const float2* tw2 = reinterpret_cast<const float2*>(tw);
@@ -371,6 +380,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
             else dft_small<FFT_R1, -1, 1, 2, PK>(v, put);
         }
     }
+    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];     // (behind the sample loads, not in front of them: see k_slice_irfft)
     __syncthreads();
     fft_steps_2_3<-1, NT, PK>(Z, T.w1, w2s, tid);
     // real post-processing: U[k] = E + G, U[N-k] = conj(E - G), E = (Z[k] + conj Z[N-k])/2,
@@ -407,6 +417,16 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
 // The L-sample segments never go to HBM.  Samples past the last even slice (S even, tail of the last odd
 // slice) have no partner and are stored by the odd launch.  row_off: element offset of packed channel bc in y
 // (the caller's final tensor: the hard concat of separator.py:231 by placement), nullptr = bc * length.
+#if XSQ_FFT_STAMP
+// phase stamps of the inverse transform, diagnostic builds only: s_memrealtime (100 MHz, the same clock on every CU) of
+// thread 0 at: 0 start, 1 band spectra gathered, 2 pre-processed, 3 43-point stage done, 4 steps 2 / 3 done, 5 stores issued
+constexpr int FFT_STAMP_ROWS = 16384;
+__device__ unsigned long long g_fft_stamps[FFT_STAMP_ROWS * 8];
+#define XSQ_STAMP(i) do { if (tid == 0 && blockIdx.x < FFT_STAMP_ROWS) g_fft_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XSQ_STAMP(i) do { } while (0)
+#endif
+
 struct OlaArgs {
     float* y;
     const int64_t* row_off;
@@ -415,7 +435,11 @@ struct OlaArgs {
 };
 
 
-template <int NT, bool PK = false>
+// SHORT: the short bands are synthesised inside this kernel (ShortSched; an A/B switch that measured slower) -- a template
+// parameter, so that the default instantiation carries neither that code nor its registers (as a run-time branch it
+// pushed the gather prologue of the default path over the 128-register cap: spilled loads, each waited for in turn).
+// FAST4: the four-phases-in-flight gather (see below); chosen by the host when the plan's phases fit.
+template <int NT, bool PK = false, bool SHORT = false, bool FAST4 = false>
 __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __restrict__ Zrow, const GatherSched G,
                                                       const FftTables T, const OlaArgs O, const ShortSched SS,
                                                       const ShortIn SI) {
@@ -423,45 +447,75 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
     __shared__ float2 Z[FFT_N + 1];        // bins 0..N while gathering, then the complex sequence
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
+#if XSQ_FFT_DEPHASE > 0
+    // Every row alternates HBM phases (band-spectrum gather, output) with compute phases of fixed lengths, and a launch
+    // is only ~9 rows deep per workgroup slot: all slots start together and STAY together -- the whole chip gathers,
+    // then the whole chip computes with HBM idle.  Half of the first wave of workgroups starts late by about half a
+    // row, once; the slots then run in two groups whose HBM phases face the other group's compute phases.
+    if (blockIdx.x < XSQ_FFT_DEPHASE_SLOTS && (blockIdx.x & 1))
+        for (int i = 0; i < XSQ_FFT_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    XSQ_STAMP(0);
     const int nsl = (O.S + 1 - O.parity) >> 1;              // slices of this parity per channel
     const int bc = blockIdx.x / nsl, s = 2 * (blockIdx.x - bc * nsl) + O.parity;
     const int row = bc * O.S + s;
-    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
+    // (the step-2 twiddles go into LDS AFTER the first gather loads have been issued: in front of them, the table load
+    //  and the wait for it -- the LDS store needs the value -- cost every row one exposed L2 round trip before its first
+    //  request left the CU; in-kernel stamps, tools/fft_phases.py)
     // Gather registers of the long bands: two phases per memory round trip, all loads of a pair of phases issued
     // (unconditionally: clamped entry index, validity kept in k) before any is consumed.
     constexpr int UN = (4864 + NT - 1) / NT;     // covers a whole phase of the Bark-262 plan in one chunk
     const float2* zr = Zrow + (int64_t)row * G.row_len;
     float2 z[2][UN];
     int k[2][UN];
-    auto gather_load = [&](int pp, int off) {
+    auto gather_load1 = [&](int h, int ph, int off) {       // one phase into register set h (compile-time h)
+        const int e0 = G.lo[ph], e1 = G.begin[ph + 1];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int e0 = G.lo[pp + h], e1 = G.begin[pp + h + 1];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int ee = e0 + off + NT * u;
-                const int ec = ee < e1 ? ee : (e1 > e0 ? e1 - 1 : 0);
-                const int kk = G.tgt[ec];
-                k[h][u] = ee < e1 ? kk : -1;
-                z[h][u] = zr[ec];
-            }
+        for (int u = 0; u < UN; ++u) {
+            const int ee = e0 + off + NT * u;
+            const int ec = ee < e1 ? ee : (e1 > e0 ? e1 - 1 : 0);
+            const int kk = G.tgt[ec];
+            k[h][u] = ee < e1 ? kk : -1;
+            z[h][u] = zr[ec];
         }
     };
-    auto gather_accum = [&]() {
+    auto gather_accum1 = [&](int h) {
+        // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
+        float2 acc[UN];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
-            float2 acc[UN];
+        for (int u = 0; u < UN; ++u) acc[u] = Z[k[h][u] >= 0 ? k[h][u] : 0];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) acc[u] = Z[k[h][u] >= 0 ? k[h][u] : 0];
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (k[h][u] >= 0) Z[k[h][u]] = make_float2(acc[u].x + z[h][u].x, acc[u].y + z[h][u].y);
-            __syncthreads();
-        }
+        for (int u = 0; u < UN; ++u)
+            if (k[h][u] >= 0) Z[k[h][u]] = make_float2(acc[u].x + z[h][u].x, acc[u].y + z[h][u].y);
+        __syncthreads();
     };
+    // Fast path (every phase of the plan fits NT * 2 * UP entries -- the Bark-262 plan -- and SHORT is off): the row's
+    // first THREE phases are requested at once and the fourth as soon as the first has been added, two entries per lane
+    // and load (16-byte loads of the spectra, one dword of two 16-bit target bins): 112 KB in flight per row instead of
+    // 75, 40 loads per lane instead of 80 in two dependent batches.  In-kernel stamps (tools/fft_phases.py) had the gather at half of the row's 31 us, waiting: two exposed
+    // round trips at ~10 GB/s per workgroup, the second one behind the first pair's accumulation.  The accumulation
+    // order of a bin is unchanged (phase 0, 1, 2, 3): same bits.
+    constexpr int UP = (4864 / 2 + 1 + NT - 1) / NT;        // entry pairs per lane and phase (5 at 512 threads)
+    float4 zz[3][UP];       // three register sets: phases 0, 1, 2 are requested at the start, phase 3 into set 0 once
+    unsigned kk[3][UP];     // phase 0 has been added (all four at once spill under the 128-register cap)
+    static_assert(!FAST4 || !SHORT, "the four-phase gather is the default path's");
+    constexpr bool fast4 = FAST4;
     const bool do_gather = !(XSQ_ABLATE & 16);
-    if (SS.n1 > 0) {
+    auto load_phase4 = [&](int slot, int ph) {       // slot, ph: compile-time at every call site
+        const int lo = G.lo[ph], e0 = lo & ~1, e1 = G.begin[ph + 1];       // pairs are aligned to even entries of the row
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int ee = e0 + 2 * (tid + NT * u);
+            const int ec = ee < e1 ? ee : e0;
+            unsigned t2 = *reinterpret_cast<const unsigned*>(G.tgt16 + ec);
+            if (!(ee >= lo && ee < e1)) t2 |= 0xFFFFu;                      // first entry of the pair outside the phase
+            if (!(ee + 1 >= lo && ee + 1 < e1)) t2 |= 0xFFFF0000u;           // second one
+            kk[slot][u] = t2;
+            zz[slot][u] = *reinterpret_cast<const float4*>(zr + ec);
+        }
+    };
+    if constexpr (FAST4) if (do_gather) { load_phase4(0, 0); load_phase4(1, 1); load_phase4(2, 2); }
+    if constexpr (SHORT) {
         // ---- short bands in-kernel (see ShortSched) ------------------------------------------------------
         constexpr int U1 = (1280 + NT - 1) / NT, U2 = (768 + NT - 1) / NT, UG = (1280 + NT - 1) / NT;   // 1280 butterflies, 768 small DFTs, 1280 entries per phase
         float2* const scr = Z + SS.sc0;
@@ -491,7 +545,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
             for (int r = 0; r < 3; ++r) tw[u][r] = SS.tw1[3 * ii + r];
         }
         // the long bands' first pair of phases travels in the same memory round trip as the short bands' inputs
-        if (do_gather) gather_load(0, tid);
+        if (do_gather) { gather_load1(0, 0, tid); gather_load1(1, 1, tid); }
         // spectrum slots outside the scratch area start at zero (the scratch area is written in full below)
         for (int k = tid; k <= FFT_N; k += NT)
             if (k < SS.sc0 || k >= SS.sc0 + SS.nent) Z[k] = make_float2(0.f, 0.f);
@@ -564,21 +618,56 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
         }
         for (int e = tid; e < SS.nent; e += NT) scr[e] = make_float2(0.f, 0.f);
     } else {
-        if (do_gather) gather_load(0, tid);
+        if (do_gather && !fast4) { gather_load1(0, 0, tid); gather_load1(1, 1, tid); }
         for (int k = tid; k <= FFT_N; k += NT) Z[k] = make_float2(0.f, 0.f);
     }
+    if (tid < FFT_R2 * FFT_R3) w2s[tid] = T.w2[tid];
     __syncthreads();
     // gather-sum of the band spectra, one phase of mutually disjoint bands at a time; the accumulation stays
-    // phase by phase with a barrier in between, because neighbouring phases overlap in bins
+    // phase by phase with a barrier in between, because neighbouring phases overlap in bins.  Every phase fits one
+    // chunk in the Bark-262 plan: phase p + 2 is requested as soon as phase p has been added and its registers are
+    // free, so its round trip runs beside the accumulation of phase p + 1 instead of behind it.
+    if constexpr (FAST4) { if (do_gather) {
+#if XSQ_FFT_STAMP
+        if (zz[0][0].x == 1.2345e-30f) __builtin_trap();
+        XSQ_STAMP(6);
+#endif
+        auto accum_phase4 = [&](int slot) {
+            // bins of one phase are distinct: read all, add, write all (no read-after-write chain)
+            float2 a0[UP], a1[UP];
 #pragma unroll
-    for (int pp = 0; pp < (do_gather ? 4 : 0); pp += 2) {
-        const int s0 = G.begin[pp + 1] - G.lo[pp], s1 = G.begin[pp + 2] - G.lo[pp + 1];
-        const int span = s0 > s1 ? s0 : s1;             // workgroup-uniform
-        for (int off = 0; off < span; off += NT * UN) {
-            if (off > 0 || pp > 0) gather_load(pp, off + tid);      // (the first chunk of phases 0 / 1 is already in flight)
-            gather_accum();
+            for (int u = 0; u < UP; ++u) {
+                const unsigned k0 = kk[slot][u] & 0xFFFFu, k1 = kk[slot][u] >> 16;
+                a0[u] = Z[k0 != 0xFFFFu ? k0 : 0];
+                a1[u] = Z[k1 != 0xFFFFu ? k1 : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const unsigned k0 = kk[slot][u] & 0xFFFFu, k1 = kk[slot][u] >> 16;
+                if (k0 != 0xFFFFu) Z[k0] = make_float2(a0[u].x + zz[slot][u].x, a0[u].y + zz[slot][u].y);
+                if (k1 != 0xFFFFu) Z[k1] = make_float2(a1[u].x + zz[slot][u].z, a1[u].y + zz[slot][u].w);
+            }
+            __syncthreads();
+        };
+        accum_phase4(0);
+        load_phase4(0, 3);
+        accum_phase4(1);
+#if XSQ_FFT_STAMP
+        XSQ_STAMP(7);
+#endif
+        accum_phase4(2);
+        accum_phase4(0);
+    } } else if (do_gather) {      // other band layouts: chunk by chunk (the first chunks of phases 0 / 1 are in flight)
+        for (int ph = 0; ph < 4; ++ph) {
+            const int span = G.begin[ph + 1] - G.lo[ph];
+            for (int off = 0; off < span; off += NT * UN) {
+                if (ph == 1 && off == 0) { gather_accum1(1); continue; }
+                if (ph != 0 || off > 0) gather_load1(0, ph, off + tid);
+                gather_accum1(0);
+            }
         }
     }
+    XSQ_STAMP(1);
     // real pre-processing in place: Zin[k] = E + i O, Zin[N-k] = conj(E) + i conj(O),
     // E = U[k] + conj U[N-k], O = (U[k] - conj U[N-k]) * conj(W_L^k)   (no 1/2: output = L * irfft)
     constexpr int NPP = (FFT_N / 2 + NT) / NT;             // table values requested together (see k_slice_rfft)
@@ -598,6 +687,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
         if (k != 0) Z[FFT_N - k] = make_float2(E.x + O.y, O.x - E.y);
     }
     __syncthreads();
+    XSQ_STAMP(2);
     {   // 43-point butterflies, in place: every lane reads its column first; with NT = 512 the outputs are split between
         // the two wave groups, which both hold the column (barrier between the reads and the writes of the pair)
         const int part = tid >> 8, m = tid & 255;
@@ -616,7 +706,9 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
         }
     }
     __syncthreads();
+    XSQ_STAMP(3);
     if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1, NT, PK>(Z, T.w1, w2s, tid);
+    XSQ_STAMP(4);
     if (XSQ_ABLATE & 128) return;
     // samples 2nn, 2nn+1 of the segment = Re / Im of sequence element nn; output index i = (2s-2)h + 2nn
     float* const yr = O.y + (O.row_off ? O.row_off[bc] : (int64_t)bc * O.length);
@@ -644,6 +736,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
             if (O.parity) { v.x += prev[it].x; v.y += prev[it].y; }
             y2[nn] = v;
         }
+        XSQ_STAMP(5);
         return;
     }
     // edge slices (first / last of a channel) and odd row offsets: per-sample bounds, 4-byte accesses

@@ -544,6 +544,10 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
         if (ok) {
             XSQ_HIP(hipMalloc(&P->d_tgt, tgt.size() * sizeof(int)));
             XSQ_HIP(hipMemcpy(P->d_tgt, tgt.data(), tgt.size() * sizeof(int), hipMemcpyHostToDevice));
+            std::vector<unsigned short> t16(tgt.size() + 2, 0xFFFFu);
+            for (size_t i = 0; i < tgt.size(); ++i) t16[i] = tgt[i] >= 0 ? (unsigned short)tgt[i] : 0xFFFFu;
+            XSQ_HIP(hipMalloc(&P->d_tgt16, t16.size() * sizeof(unsigned short)));
+            XSQ_HIP(hipMemcpy(P->d_tgt16, t16.data(), t16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             // the device copy of the band table was uploaded before .ent was known
             XSQ_HIP(hipMemcpy(P->d_bands, P->bands.data(), P->bands.size() * sizeof(BandDev), hipMemcpyHostToDevice));
         }
@@ -719,7 +723,7 @@ int xsq_plan_destroy(xsq_plan* P) {
     }
     for (auto& kv : P->tiles) (void)hipFree(kv.second.d_tiles);
     (void)hipFree(P->d_bands4); (void)hipFree(P->d_pool4f); (void)hipFree(P->d_pool4i);
-    (void)hipFree(P->d_T); (void)hipFree(P->d_tgt); (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
+    (void)hipFree(P->d_T); (void)hipFree(P->d_tgt); (void)hipFree(P->d_tgt16); (void)hipFree(P->d_tw); (void)hipFree(P->d_Wf); (void)hipFree(P->d_Wi); (void)hipFree(P->d_bands);
     (void)hipFree(P->d_cov_ptr); (void)hipFree(P->d_cov_band);
     (void)hipFree(P->d_s_item1); (void)hipFree(P->d_s_tw1); (void)hipFree(P->d_s_item2); (void)hipFree(P->d_s_tgt); (void)hipFree(P->d_s_wd);
     delete P;
@@ -733,6 +737,15 @@ int xsq_plan_set_band_radix4(xsq_plan* P, int on) {
     P->band_radix4 = on ? 1 : 0;
     return XSQ_OK;
 }
+
+#if XSQ_FFT_STAMP
+// diagnostic builds only (not declared in the public header): copies the phase stamps of the last inverse launches
+extern "C" int xsq_debug_fft_stamps(unsigned long long* host, int rows) {
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fft_stamps), (size_t)(rows < FFT_STAMP_ROWS ? rows : FFT_STAMP_ROWS) * 64));
+    return XSQ_OK;
+}
+#endif
 
 int xsq_plan_set_packed_fft(xsq_plan* P, int on) {
     XSQ_REQUIRE(P, "xsq_plan_set_packed_fft: null plan");
@@ -919,7 +932,7 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         // inverse slice FFT with the overlap-add fused in: even slices store, odd slices add (slice_fft.h)
         XSQ_PROF("slice_irfft_ola", stream);
         GatherSched G;
-        G.tgt = P->d_tgt; G.row_len = (int)P->sumFT;
+        G.tgt = P->d_tgt; G.tgt16 = P->d_tgt16; G.row_len = (int)P->sumFT;
         for (int i = 0; i < 5; ++i) G.begin[i] = P->phase_begin[i];
         for (int i = 0; i < 4; ++i) G.lo[i] = inl ? P->phase_long[i] : P->phase_begin[i];
         ShortSched SS;
@@ -934,8 +947,15 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
         for (int parity = 0; parity < 2; ++parity) {
             const int nsl = (S + 1 - parity) / 2;
             OlaArgs O{y, row_offsets, S, P->h, parity, length};
-            if (fft_threads(1) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            const bool sh = SS.n1 > 0;
+            bool fast4 = !sh && fft_threads(1) == 512 && G.tgt16 != nullptr && !getenv("XSQ_FFT_GATHER2");
+            for (int ph = 0; ph < 4; ++ph) fast4 = fast4 && (G.begin[ph + 1] - (G.lo[ph] & ~1) <= 2 * 512 * ((4864 / 2 + 1 + 511) / 512));
+            if (fast4 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (fast4) hipLaunchKernelGGL((k_slice_irfft<512, false, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (fft_threads(1) == 512 && sh) hipLaunchKernelGGL((k_slice_irfft<512, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (fft_threads(1) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else if (fft_threads(1) == 512) hipLaunchKernelGGL(k_slice_irfft<512>, dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (sh) hipLaunchKernelGGL((k_slice_irfft<256, false, true>), dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else hipLaunchKernelGGL(k_slice_irfft<256>, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
         }
         XSQ_HIP(hipGetLastError());
