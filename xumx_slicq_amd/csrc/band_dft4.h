@@ -75,21 +75,40 @@ struct Band4Args {
     int split;
 };
 
-constexpr int D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
-#ifndef XSQ_D4_WPE
-#define XSQ_D4_WPE __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef XSQ_D4_STAMP
+#define XSQ_D4_STAMP 0      // diagnostic build: phase stamps of the synthesis launch (tools/band_phases.py)
 #endif
-constexpr int D4H_ROWS = 32, D4H_NCB = 10;
-template <bool FWD>
-__global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
+#if XSQ_D4_STAMP
+// per tile: s_memrealtime (100 MHz) at 0 start, 1 first operands arrived, 2 K loop done, 3 epilogue stores issued; [4] = ncb, [5] = K-steps
+constexpr int D4_STAMP_TILES = 1 << 17;
+__device__ unsigned long long g_d4_stamps[D4_STAMP_TILES * 8];
+#define XSQ_D4S(i) do { if (!FWD && tid == 0 && blockIdx.x < D4_STAMP_TILES) g_d4_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XSQ_D4S(i) do { } while (0)
+#endif
+
+constexpr int D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
+constexpr int D4H_ROWS = 32;
+// NCBMAX = most 16-column blocks a band of this instantiation has.  10 (Lg <= 320): 49 KB of LDS and 80 accumulator
+// registers, three workgroups per CU -- the product configuration.  5 (Lg <= 160): 35 KB and 40 accumulator registers
+// -> FOUR workgroups per CU, an A/B arm (XSQ_D4_SPLIT=1) that measured no faster.  The kernel waits: in-kernel stamps
+// (tools/band_phases.py) put a K-step at 1.8-4.2 us of wall time for 0.24-1.2 us of MFMAs per wave (the next operands
+// arrive after 2-5 us under load) and the prologue at 3.4-8.4 us; a fourth resident workgroup on the narrow bands -- 41 %
+// of the summed tile time -- did not shorten them: the round trips lengthen with the requests in flight.
+template <int NCBMAX> struct D4Cfg { static constexpr int waves = NCBMAX > 5 ? 3 : 4, mpad = NCBMAX > 5 ? D4_MPAD : 40; };
+template <bool FWD, int NCBMAX = 10>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D4Cfg<NCBMAX>::waves, D4Cfg<NCBMAX>::waves)))
+void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
+    constexpr int D4H_NCB = NCBMAX, MPADL = D4Cfg<NCBMAX>::mpad;
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4H_ROWS + 16 * D4H_NCB) * D4_LD];
-    __shared__ __attribute__((aligned(16))) float2 twl[3 * D4_MPAD];      // w^(r t1), r = 1..3, of this tile's band
-    __shared__ __attribute__((aligned(16))) float winl[4 * D4_MPAD];      // INV: dual window wd[q] of this tile's band
+    __shared__ __attribute__((aligned(16))) float2 twl[3 * MPADL];        // w^(r t1), r = 1..3, of this tile's band
+    __shared__ __attribute__((aligned(16))) float winl[4 * MPADL];        // INV: dual window wd[q] of this tile's band
     constexpr int ABUF = 4 * D4H_ROWS * D4_LD, BBUF = 16 * D4H_NCB * D4_LD;
     float* const As0 = lds;                     // [buf][r][row][20]
     float* const Bs0 = lds + 2 * ABUF;          // [buf][col][20]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    XSQ_D4S(0);
     // By value: through a reference into global memory the compiler had to RE-LOAD the fields after every store of the
     // epilogue (they might alias), and each reload's s_waitcnt vmcnt(0) also waited for the store before it -- one HBM
     // round trip per 16-byte store (tools/scan_isa.py counts such loads).
@@ -121,13 +140,16 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
     // DFT matrix slab of a K-step: 16 ncb rows (n) x 16 floats = 64 ncb float4, item i = tid + 256 u: n = i >> 2, k quad i & 3
     const float* bp = a.pool + bd.d_off + (int64_t)(tid >> 2) * bd.ldd + 4 * (tid & 3);
     const int nb4 = 64 * ncb;
-    int bover[3];                                // rows by which item u of this thread lies past the slab (0 inside)
+    constexpr int NBU = (64 * D4H_NCB + 255) / 256;     // float4 items of the matrix slab per thread (3 / 2)
+    int bover[NBU];                              // rows by which item u of this thread lies past the slab (0 inside)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int n = (tid >> 2) + 64 * u; bover[u] = n < 16 * ncb ? 0 : n - (16 * ncb - 1); }
+    for (int u = 0; u < NBU; ++u) { const int n = (tid >> 2) + 64 * u; bover[u] = n < 16 * ncb ? 0 : n - (16 * ncb - 1); }
 
     float2 raw[4];         // INV: quarter a, complex tc;  FWD: spectrum value of quarter a
     float aux[4];          // INV: mask of quarter a;  FWD: window value
-    float4 gb[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 gb[NBU];
+#pragma unroll
+    for (int u = 0; u < NBU; ++u) gb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     int g_t1 = 0;
 
     auto fwd_idx = [&](int tt, int q4, float& cj) {        // spectrum bin of window index tt + q4*m, Hermitian reflection
@@ -154,7 +176,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
             }
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u)         // uniform test; rows past the band's blocks re-read the last row (not stored)
+        for (int u = 0; u < NBU; ++u)       // uniform test; rows past the band's blocks re-read the last row (not stored)
             if (256 * u < nb4) gb[u] = *reinterpret_cast<const float4*>(bp + (int64_t)(64 * u - bover[u]) * bd.ldd + k0);
     };
     auto store_set = [&](int buf) {
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
         *reinterpret_cast<float2*>(Aw + 3 * D4H_ROWS * D4_LD) = z3;
         float* Bw = Bs0 + buf * BBUF + (tid >> 2) * D4_LD + 4 * (tid & 3);
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
+        for (int u = 0; u < NBU; ++u)
             if (tid + 256 * u < nb4) *reinterpret_cast<float4*>(Bw + 64 * u * D4_LD) = gb[u];
     };
 
@@ -208,10 +230,17 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
     load_set(0);
     float w_mu = 0.f, w_sc = 1.f;                // whitening constants of this tile's band (uniform)
     if (FWD && a.xin) { w_mu = a.mean[bd.jband]; w_sc = a.scale[bd.jband]; }
-    for (int i = tid; i < 3 * mpad; i += 256) twl[i] = tw[i];
-    if (!FWD) for (int i = tid; i < Lg; i += 256) winl[i] = win[i];
+    {   // tables of the band into LDS: every value of this thread requested before the first is stored (a load -> store
+        // loop made Lg > 256 two dependent round trips)
+        const float2 tv = tid < 3 * mpad ? tw[tid] : make_float2(0.f, 0.f);
+        float wv0 = 0.f, wv1 = 0.f;
+        if (!FWD) { wv0 = tid < Lg ? win[tid] : 0.f; wv1 = tid + 256 < Lg ? win[tid + 256] : 0.f; }
+        if (tid < 3 * mpad) twl[tid] = tv;
+        if (!FWD) { if (tid < Lg) winl[tid] = wv0; if (tid + 256 < Lg) winl[tid + 256] = wv1; }
+    }
     __syncthreads();             // tables complete (store_set reads the twiddles)
     store_set(0);
+    XSQ_D4S(1);
     __syncthreads();
     int cur = 0;
     auto k_step = [&]() {
@@ -242,6 +271,10 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
         cur ^= 1;
     }
     k_step();
+    XSQ_D4S(2);
+#if XSQ_D4_STAMP
+    if (!FWD && tid == 0 && blockIdx.x < D4_STAMP_TILES) { g_d4_stamps[blockIdx.x * 8 + 4] = ncb; g_d4_stamps[blockIdx.x * 8 + 5] = (K + 15) / 16; }
+#endif
 
     // ---- epilogue.  Register rr of acc[e][cb]: row 16 rh + 4 kq + rr, column l16 = (k' = l16 >> 1, Re / Im) of residue
     // 2 rp + e, i.e. output q = 4 (8 cb + k') + 2 rp + e.  The even lane (Re) finishes rows rr = 0, 1, the odd lane (Im)
@@ -298,6 +331,7 @@ __global__ __launch_bounds__(256) XSQ_D4_WPE void band_dft4_full_kernel(Band4Arg
             }
         }
     }
+    XSQ_D4S(3);
 }
 
 }  // namespace xsq

@@ -280,9 +280,11 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
 // (sample, channel, slice)); their tiles are made neighbours so the mix is fetched once per XCD.  When share is not a
 // multiple of the tile height the last tile of a copy runs into the next copy's first rows and recomputes them
 // (same values, written twice).
-static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0) {
+// cls: 0 = every band (one launch of the 10-block kernel), 1 = bands of more than 5 blocks, 2 = bands of at most 5 blocks
+// (their own instantiation: four workgroups per CU, band_dft4.h)
+static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0, int cls = 0) {
     std::lock_guard<std::mutex> lk(P->mu);
-    auto key = std::make_tuple(3, rows, share);
+    auto key = std::make_tuple(3 + 16 * cls, rows, share);
     auto it = P->tiles.find(key);
     if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
     std::vector<Tile4Dev> t;
@@ -290,6 +292,7 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
     const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
     for (int i = P->nbands4 - 1; i >= 0; --i) {
         const int ncb = (2 * P->bands4_m[i] + 15) / 16;
+        if ((cls == 1 && ncb <= 5) || (cls == 2 && ncb > 5)) continue;
         for (int m0 = 0; m0 < span; m0 += D4H_ROWS)
             for (int k = 0; k < copies; ++k) t.push_back(Tile4Dev{m0 + k * span, ncb, b4[i]});
     }
@@ -301,6 +304,27 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
     }
     P->tiles[key] = tt;
     *out = tt;
+    return XSQ_OK;
+}
+
+// the radix-4 band kernel over every eligible band, one launch of the 10-block instantiation (three workgroups per CU).
+// XSQ_D4_SPLIT=1 (A/B switch, measured no faster: synthesis 0.940-0.948 vs 0.916-0.945 ms, analysis 0.309-0.316 vs
+// 0.291-0.301): the bands of at most five 16-column blocks in their own instantiation -- 35 KB of LDS, 96 registers,
+// four workgroups per CU -- launched behind the wide ones.
+template <bool FWD>
+static int launch_dft4(xsq_plan* P, const Band4Args& a4, int rows, int share, hipStream_t stream) {
+    static const bool split = getenv("XSQ_D4_SPLIT") && atoi(getenv("XSQ_D4_SPLIT")) == 1;
+    TileTable t;
+    int rc;
+    if (!split) {
+        if ((rc = get_dft4_full_tiles(P, rows, &t, share, 0))) return rc;
+        if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 10>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+        return XSQ_OK;
+    }
+    if ((rc = get_dft4_full_tiles(P, rows, &t, share, 1))) return rc;
+    if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 10>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+    if ((rc = get_dft4_full_tiles(P, rows, &t, share, 2))) return rc;
+    if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 5>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
     return XSQ_OK;
 }
 
@@ -738,6 +762,13 @@ int xsq_plan_set_band_radix4(xsq_plan* P, int on) {
     return XSQ_OK;
 }
 
+#if XSQ_D4_STAMP
+extern "C" int xsq_debug_d4_stamps(unsigned long long* host, int tiles) {
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_d4_stamps), (size_t)(tiles < D4_STAMP_TILES ? tiles : D4_STAMP_TILES) * 64));
+    return XSQ_OK;
+}
+#endif
 #if XSQ_FFT_STAMP
 // diagnostic builds only (not declared in the public header): copies the phase stamps of the last inverse launches
 extern "C" int xsq_debug_fft_stamps(unsigned long long* host, int rows) {
@@ -840,12 +871,9 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
     if (rc) return rc;
     BandFwdOp op{U, coef, P->d_bands, P->d_Wf, BC, S, P->nbins, P->L, xin, mean, scale, split};
     if (P->band_radix4 && P->nbands4) {
-        TileTable t4;
-        rc = get_dft4_full_tiles(P, rows, &t4);
-        if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4f, U, coef, BC, S, P->nbins, P->L, 0, nullptr, 0, xin, mean, scale, split};
         XSQ_PROF("band_analysis_dft4", stream);
-        hipLaunchKernelGGL(band_dft4_full_kernel<true>, dim3(t4.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t4.d_tiles, t4.ntiles);
+        if ((rc = launch_dft4<true>(P, a4, rows, 0, stream))) return rc;
     }
     if (tt.ntiles) { XSQ_PROF("band_analysis_gemm", stream);
     hipLaunchKernelGGL((grouped_gemm_kernel<BandFwdOp>), dim3(tt.ntiles), dim3(256), 0, stream, op,
@@ -915,13 +943,10 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     if (rc) return rc;
     BandInvOp op{coef, Z, P->d_bands, P->d_Wi, BC, S, lds_fft(P) ? (int)P->sumFT : 0, mask, BCx};
     if (P->band_radix4 && P->nbands4) {
-        TileTable t4;
-        rc = get_dft4_full_tiles(P, rows, &t4, mask ? BCx * S : 0);
-        if (rc) return rc;
         Band4Args a4{(const Band4Dev*)P->d_bands4, P->d_pool4i, coef, Z, BC, S, P->nbins, P->L,
                      lds_fft(P) ? (int)P->sumFT : 0, mask, BCx, nullptr, nullptr, nullptr, 0};
         XSQ_PROF("band_synthesis_dft4", stream);
-        hipLaunchKernelGGL(band_dft4_full_kernel<false>, dim3(t4.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t4.d_tiles, t4.ntiles);
+        if ((rc = launch_dft4<false>(P, a4, rows, mask ? BCx * S : 0, stream))) return rc;
     }
     // short bands: inside k_slice_irfft when the plan allows it, else dense GEMM + Z round trip
     const bool inl = lds_fft(P) && P->band_radix4 && P->short_inline && P->short_n1 > 0;
