@@ -300,12 +300,22 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements outside the timed region")
     ap.add_argument("--graph", action="store_true",
                     help="track240: replay the step from a captured HIP graph (Separator.forward_graphed)")
+    ap.add_argument("--gather-at-1", action="store_true",
+                    help="testset50 on ONE rank with the exchange machinery on (process group of one rank on nccl, exchange "
+                         "blocks, one-rank all-gather, placement launches): what packing + placement cost without any link")
     ap.add_argument("--no-gather", action="store_true",
                     help="testset50: headline without the all-gather (default: with it; the other one is a variant)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+
+    # stdout carries ONE line, the JSON, and it has to be the last thing on it: libraries write there as well (RCCL
+    # prints a version banner at teardown, gloo its connection notes).  File descriptor 1 is pointed at stderr for the
+    # whole run and the line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -328,6 +338,12 @@ def main():
     dev = torch.device("cuda", local_dev)
 
     import torch.distributed as dist
+    if world == 1 and args.gather_at_1:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -347,9 +363,12 @@ def main():
         result = bench_testset(args, sep, dev, world, rank, dist)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 DTYPES = {"fp32": "f32", "bf16x6": "f32 (conv contractions: exact 3-way bf16 cut, 6 bf16 MFMAs per product, fp32 accumulate)",
@@ -625,7 +644,10 @@ def bench_testset(args, sep, dev, world, rank, dist):
         return cache[key]
 
     gather = not args.no_gather
+    if world == 1 and args.gather_at_1:
+        gather = "always"
     dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack)
+    gather = dmx.gather
     for q in dmx.plan.rounds:
         for p in q[rank]:
             get_chunk(p.item)
@@ -680,7 +702,16 @@ def bench_testset(args, sep, dev, world, rank, dist):
                 del solo
         if world > 1:
             dist.barrier()
-    collective = collective_block(dmx, dist, world, rank, dev, dt / args.steps * 1e3, other_ms, gather) if world > 1 else None
+    if world == 1 and dmx.gather and not args.no_variants:      # --gather-at-1: the same set without the exchange machinery
+        plain = ShardedDemixer(sep, lengths, get_chunk, dev, gather=False, stack=args.stack)
+        for _ in range(max(1, args.warmup)):
+            plain.run()
+        dto, _ = timed_steps(plain.run, args.steps, world, dist, dev)
+        other_ms = dto / args.steps * 1e3
+        variants["no_gather"] = {"what": "the same set, kernels writing straight into the per-track tensors (no exchange blocks, no placement)",
+                                 "value": round(args.steps * total_s / dto, 2), "unit": "x real-time", "ms_per_step": round(other_ms, 3)}
+        del plain
+    collective = collective_block(dmx, dist, world, rank, dev, dt / args.steps * 1e3, other_ms, gather) if (world > 1 or dmx.gather) else None
     if rank != 0:
         return None
     plan = sep.nsgt.nsgt.plan

@@ -89,7 +89,7 @@ def test_place_rows_moves_ragged_rows_bitwise():
         _lib.check(_lib.lib.xsq_place_rows(None, dst.data_ptr(), table.data_ptr(), 1, 4, _lib.stream_ptr()), "xsq_place_rows")
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", gather=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     # gloo: both ranks share device 0 (the functional path of a 1-GPU box); nccl (= RCCL): one rank per device
@@ -110,7 +110,7 @@ def _worker(rank, world, port, q, backend="gloo"):
             tracks = _tracks(dev)
             ref = _reference(sep, tracks)
             get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
-            dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=2)
+            dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=2, gather=gather)
             assert dmx.world == world and dmx.gather
             for step in range(2):
                 out = dmx.run()
@@ -133,14 +133,14 @@ def _worker(rank, world, port, q, backend="gloo"):
         dist.destroy_process_group()
 
 
-def _run_ranks(world, backend):
+def _run_ranks(world, backend, gather=True):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, gather)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
@@ -151,6 +151,14 @@ def _run_ranks(world, backend):
 
 def test_two_ranks_all_gather_and_place_bitwise():
     _run_ranks(2, "gloo")
+
+
+def test_rccl_group_of_one_runs_the_collective_path():
+    """What a 1-GPU box CAN execute of the RCCL branch: a process group of one rank on backend nccl with ``device_id``
+    set, ``ShardedDemixer(gather="always")`` -- communicator creation, the in-place ``all_gather_into_tensor`` issued
+    asynchronously behind the kernels, the place stream's wait on its work handle, ``xsq_place_rows`` -- bitwise equal to
+    the single-process chunk loop, mix-phase and Wiener-EM.  (Several ranks: the test below, wherever >= 2 devices exist.)"""
+    _run_ranks(1, "nccl", gather="always")
 
 
 def test_rccl_ranks_all_gather_and_place_bitwise():

@@ -266,7 +266,10 @@ class ShardedDemixer:
     gather=False : the kernels write this rank's items straight into the result tensors; chunks computed by
                    other ranks stay zero (no data-path collective).
     solo=True    : ignore the process group and run the whole set on this rank (world = 1): the single-GPU
-                   rate on the same workload."""
+                   rate on the same workload.
+    A group of ONE rank exchanges nothing and runs as gather=False -- unless ``gather="always"``: the exchange blocks,
+    the (one-rank) collective and the placement launch then run all the same, which is how a 1-GPU box executes the
+    RCCL branch (tests/test_sharding_gpu.py)."""
 
     def __init__(self, separator, track_lengths: Sequence[int], get_chunk: Callable[[WorkItem], Tensor],
                  device: torch.device, group: Optional[dist.ProcessGroup] = None, gather: bool = True,
@@ -276,8 +279,9 @@ class ShardedDemixer:
         self.world = dist.get_world_size(group) if live else 1
         self.rank = dist.get_rank(group) if live else 0
         self.plan = ShardPlan(track_lengths, separator.chunk_size, self.world, nb_samples, stack)
-        if self.world == 1:
+        if self.world == 1 and gather != "always":
             self.gather = False
+        self.gather = bool(self.gather)
         nb, dt = self.plan.nb, torch.float32
         lens = self.plan.lengths
         # one flat allocation for all tracks: the kernels address it through element offsets
