@@ -7,7 +7,7 @@
 //   L1   Conv2d(2->50,(kf,W),stride(1,hop)) + BN + ReLU      GEMM  M=(b,f1,t1)  K=(ci,df,dt)    N=50
 //   L2   Conv2d(50->51,(kf,4)) + BN + ReLU                   GEMM  M=(b,f2,t2)  K=(df,dt,c1)    N=51
 //   L3   ConvTranspose2d(51->50,(kf,4)) + BN + ReLU          GEMM  M=(b,f3,t3)  K=(df,dt',c2)   N=50
-//   L4   ConvTranspose2d(50->2,(kf,W),stride(1,hop)) + bias  GEMM  M=(b,f4,u)   K=(df,tap,c3)   N=(c,dt<hop)
+//   L4   ConvTranspose2d(50->2,(kf,W),stride(1,hop)) + bias  GEMM  M=(b,f4,u)   K=(df,1-tap,c3) N=(c,dt<hop)
 //        + sigmoid -> mask;  Y[target] = mask * X  (complex)   fused epilogue
 // BatchNorm (eval, eps 1e-5) is folded into the weights (scale) and a per-channel shift.
 // Activations are channels-last with a channel stride of 52 floats (16-byte rows), so every
@@ -363,13 +363,30 @@ struct CdaeL4Op {
         r.p = g.in + (((int64_t)b * g.Fi + f) * g.Ti + t) * CS;
         return r;
     }
+    // k = (df*2 + (1 - tap))*52 + c3: the TWO taps of a row, stored tap 1 first, are ONE contiguous run of 104 floats --
+    // positions u - 1 and u of input row f - df -- so the operand address is "row base - df rows + kk" with no division
+    // and one range test per half (kk < 52: position u - 1 exists, else: position u exists).  The cursor carries kk and
+    // the row offset; the engine asks for k = s_kq, s_kq + 16, ... in order.
+    struct Cursor { int k, kk, df; };
+    __device__ Cursor cursor(const Group& g, int k) const {
+        Cursor c;
+        c.k = k; c.df = k / (2 * CS); c.kk = k - c.df * 2 * CS;
+        return c;
+    }
+    __device__ void advance(const Group& g, Cursor& c) const {
+        c.k += 16; c.kk += 16;
+        if (c.kk >= 2 * CS) { c.kk -= 2 * CS; ++c.df; }
+    }
+    __device__ float4 load_a4(const Group& g, const RowA& r, const Cursor& c) const { return load_at(g, r, c.k, c.df, c.kk); }
     __device__ float4 load_a4(const Group& g, const RowA& r, int k) const {
-        if (r.p == nullptr || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const int df = k / (2 * CS), rem = k - df * 2 * CS;
-        const int tap = rem / CS, c3 = rem - tap * CS;
-        const int fi = r.f - df, ti = r.t - tap;
-        if (fi < 0 || fi >= g.Fi || ti < 0 || ti >= g.Ti) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + tap) * CS + c3);
+        const int df = k / (2 * CS);
+        return load_at(g, r, k, df, k - df * 2 * CS);
+    }
+    __device__ float4 load_at(const Group& g, const RowA& r, int k, int df, int kk) const {
+        const int fi = r.f - df;
+        const bool pos_ok = kk < CS ? r.t >= 1 : r.t < g.Ti;           // tap 1 reads position u - 1, tap 0 position u
+        if (r.p == nullptr || k >= g.K || fi < 0 || fi >= g.Fi || !pos_ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + 1) * CS + kk);
     }
     // mask = sigmoid(acc + bias[c]);  Y[target] = mask * X.  Column n = c*hop + dt with n < 2*hop, so
     // c is a compare.
@@ -729,7 +746,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                                 (float)((double)w[(((size_t)ci * H1 + co) * kf + df) * 4 + dt] * s);
             }
             // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
-            //      k = (df*2 + tap)*52 + c3 ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
+            //      k = (df*2 + (1 - tap))*52 + c3 (tap 1 first: CdaeL4Op) ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
             w = p; p += (size_t)H1 * 2 * kf * W;
             const float* bias = p; p += 2;
             d.w4[t] = alloc((size_t)round_up(W, 64) * d.ld4);    // Wt[n = c*hop + dtlo][k]
@@ -740,7 +757,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                     for (int df = 0; df < kf; ++df)
                         for (int tap = 0; tap < 2; ++tap)
                             for (int dt = 0; dt < hop; ++dt)
-                                pool[d.w4[t] + (size_t)(c * hop + dt) * d.ld4 + (df * 2 + tap) * CS + ci] =
+                                pool[d.w4[t] + (size_t)(c * hop + dt) * d.ld4 + (df * 2 + (1 - tap)) * CS + ci] =
                                     w[(((size_t)ci * 2 + c) * kf + df) * W + dt + tap * hop];
         }
         Mo->blocks.push_back(d);

@@ -688,7 +688,7 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
                     for (int df = 0; df < kf; ++df)
                         for (int tap = 0; tap < 2; ++tap)
                             for (int dt = 0; dt < hop; ++dt)
-                                map[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + tap) * CS + ci] =
+                                map[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + (1 - tap)) * CS + ci] =
                                     (int)(g.p_w4 + (((int64_t)ci * 2 + c) * kf + df) * W + dt + tap * hop);
             map[cb.b4[t]] = (int)g.p_b4;
             map[cb.b4[t] + 1] = (int)(g.p_b4 + 1);
@@ -723,7 +723,7 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
                     for (int df = 0; df < kf; ++df)
                         for (int tap = 0; tap < 2; ++tap)
                             for (int dt = 0; dt < hop; ++dt)
-                                mapb[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + tap) * CS + co] =
+                                mapb[cb.w4[t] + (int64_t)(c * hop + dt) * cb.ld4 + (df * 2 + (1 - tap)) * CS + co] =
                                     (int)(g.p_w1 + (((int64_t)co * 2 + c) * kf + df) * W + dt + tap * hop);
         }
     }

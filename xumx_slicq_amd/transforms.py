@@ -48,6 +48,7 @@ class SliCQEngine:
         # 240 s track than the dense GEMM + workspace round trip it replaces (the kernel is bound by its serial chain of
         # memory / LDS round trips, and the in-kernel stage adds three) -> off by default; XSQ_SHORT_INLINE=1 / set_short_inline
         self._short_inline = os.environ.get("XSQ_SHORT_INLINE", "0") != "0"
+        self._packed_fft = False        # see set_packed_fft
 
     def set_fft_backend(self, backend: int):
         """0 = hand-written LDS slice FFT when the plan allows it (default), 1 = rocFFT."""
