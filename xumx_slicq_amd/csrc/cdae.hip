@@ -341,6 +341,7 @@ struct CdaeL3Op {
 struct CdaeL4Op {
     typedef CdaeGroup Group;
     typedef RowFT RowA;
+    static constexpr bool STAMPED = true;      // (diagnostic builds with XSQ_GEMM_STAMP: tools/gemm_phases.py)
     CdaeArgs a;
     __device__ Group group(int gid) const {
         const CdaeBlockDev& b = a.blocks[gid >> 2];
@@ -887,6 +888,23 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 }
 
 }  // namespace xsq
+
+#if XSQ_GEMM_STAMP
+extern "C" int xsq_debug_occupancy(int* out) {       // the runtime's own count of resident workgroups per CU
+    XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], (grouped_gemm_kernel<CdaeL4Op, 1, 2>), 256, 0));
+    XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], (grouped_gemm_kernel<CdaeL1Op, 1, 1>), 256, 0));
+    XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], (cdae_slab_kernel<true, 3, true>), 512, 0));
+    hipFuncAttributes fa;
+    XSQ_HIP(hipFuncGetAttributes(&fa, (const void*)(grouped_gemm_kernel<CdaeL4Op, 1, 2>)));
+    out[3] = fa.numRegs; out[4] = (int)fa.sharedSizeBytes; out[5] = (int)fa.localSizeBytes; out[6] = fa.maxThreadsPerBlock;
+    return XSQ_OK;
+}
+extern "C" int xsq_debug_gemm_stamps(unsigned long long* host, int tiles) {
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), (size_t)(tiles < GEMM_STAMP_TILES ? tiles : GEMM_STAMP_TILES) * 64));
+    return XSQ_OK;
+}
+#endif
 
 extern "C" {
 

@@ -28,7 +28,20 @@
 #define XSQ_ABLATE 0
 #endif
 
+#ifndef XSQ_GEMM_STAMP
+#define XSQ_GEMM_STAMP 0     // diagnostic build: phase stamps of the tile engine (tools/gemm_phases.py); one copy per translation unit
+#endif
+
 namespace xsq {
+
+#if XSQ_GEMM_STAMP
+// per tile: s_memrealtime (100 MHz) at 0 start, 1 first K-step staged, 2 K loop done, 3 epilogue stores issued; [4] = tile kind, [5] = K-steps
+constexpr int GEMM_STAMP_TILES = 1 << 17;
+static __device__ unsigned long long g_gemm_stamps[GEMM_STAMP_TILES * 8];
+#define XSQ_GS(i) do { if (stamped_of<Op>::value && tid == 0 && blockIdx.x < GEMM_STAMP_TILES) g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XSQ_GS(i) do { } while (0)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -44,6 +57,9 @@ template <class Op> struct aux_of<Op, std::void_t<typename Op::Aux>> { typedef t
 // holds 770 cycles of MFMAs).  The engine asks for the operand of k = s_kq, s_kq + 16, s_kq + 32, ... in that order:
 // `Cursor cursor(g, k)` positions a cursor, `load_a4(g, row, cursor)` loads through it, `advance(g, cursor)` moves it
 // 16 further; the operator keeps the k-dependent part of the address incrementally.
+// operators that carry `static constexpr bool STAMPED = true` are the ones a stamped diagnostic build records
+template <class Op, class = void> struct stamped_of { static constexpr bool value = false; };
+template <class Op> struct stamped_of<Op, std::void_t<decltype(Op::STAMPED)>> { static constexpr bool value = Op::STAMPED; };
 struct NoCursor {};
 template <class Op, class = void> struct cursor_of { typedef NoCursor type; static constexpr bool on = false; };
 template <class Op> struct cursor_of<Op, std::void_t<typename Op::Cursor>> { typedef typename Op::Cursor type; static constexpr bool on = true; };
@@ -93,6 +109,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    XSQ_GS(0);
     const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     // wave-uniform.  XW = 1 operators have N = 52: one tile, always the full width -- a compile-time fact, or the K-step
     // carries both MFMA sequences and 16 accumulator copies where their register assignments meet
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
 
     // prologue: K-step 0 -> LDS buffer 0; K-steps 1 and 2 in flight in register sets 1 and 0
     store_set(0, 0);
+    XSQ_GS(1);
     load_set(1, BK);
     load_set(0, 2 * BK);
     __syncthreads();
@@ -274,6 +292,15 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
         __syncthreads();
     }
 
+    XSQ_GS(2);
+#if XSQ_GEMM_STAMP
+    if (stamped_of<Op>::value && tid == 0 && blockIdx.x < GEMM_STAMP_TILES) {
+        g_gemm_stamps[blockIdx.x * 8 + 4] = kind; g_gemm_stamps[blockIdx.x * 8 + 5] = (K + 15) / 16;
+        // where the workgroup ran: HW_ID (wave slot, SIMD, CU, shader array, shader engine) and XCC_ID
+        g_gemm_stamps[blockIdx.x * 8 + 6] = (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        g_gemm_stamps[blockIdx.x * 8 + 7] = (unsigned)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+    }
+#endif
     // ---- epilogue: accumulator register r of this lane is row row0 + acc_row(r), columns n and n+32 ----
     if (XSQ_ABLATE & 16) {      // diagnostic: no epilogue (keep the accumulators alive)
         float sacc = 0.f;
@@ -290,8 +317,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     }
     if constexpr (XW == 2) {
         if (kind >= 2) op.epilogue16(g, t.m0 + wave * 32, lane, t.n0 + (kind == 3 ? 32 : 0), acc16);
-        if (kind == 2) return;
+        if (kind == 2) { XSQ_GS(3); return; }
         op.epilogue(g, t.m0 + wave * 32 + 4 * lk, t.n0 + lrow, acc0[0], acc1[0], kind == 0);
+        XSQ_GS(3);
         return;
     }
 #pragma unroll
