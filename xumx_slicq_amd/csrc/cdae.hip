@@ -616,18 +616,25 @@ static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     std::vector<int> order(Mo->nblocks);
     for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].kf > Mo->blocks[y].kf; });
-    std::vector<TileDev> t;
+    std::vector<SlabTileDev> t;
     for (int b : order) {
         const CdaeBlockDev& d = Mo->blocks[b];
         const int64_t perb = layer == 2 ? (int64_t)d.F2 * T2 : (int64_t)d.F1 * T1;
-        for (int tgt = 0; tgt < NT; ++tgt)
+        for (int tgt = 0; tgt < NT; ++tgt) {
+            const int64_t off1 = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);   // act1 / act3 of the (block, target)
+            const int64_t off2 = (int64_t)CS * Bn * T2 * (4 * (int64_t)d.cumF2 + (int64_t)tgt * d.F2);   // act2
+            SlabTileDev e;
+            e.kf = d.kf;
+            if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.w_off = d.w2[tgt]; }
+            else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.w_off = d.w3[tgt]; }
             for (int bi = 0; bi < Bn; ++bi)
-                for (int64_t r = 0; r < perb; r += SLAB_ROWS) t.push_back(TileDev{b * 4 + tgt, (int)(bi * perb + r), 0, 0});
+                for (int64_t r = 0; r < perb; r += SLAB_ROWS) { e.m0 = (int)(bi * perb + r); t.push_back(e); }
+        }
     }
-    TileTable tt;
+    TileTable tt;                    // (d_tiles holds SlabTileDev entries for this key: cast at the launch sites)
     tt.ntiles = (int)t.size();
-    XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
-    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc((void**)&tt.d_tiles, t.size() * sizeof(SlabTileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(SlabTileDev), hipMemcpyHostToDevice));
     Mo->tiles[key] = tt;
     *out = tt;
     return XSQ_OK;
@@ -854,9 +861,9 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);      // its own event name: one kernel, one name
-#define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
+#define XSQ_SLAB(TR_, MODE_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, MODE_>), dim3(tt.ntiles), dim3(512), 0, stream, a, (const SlabTileDev*)tt.d_tiles, tt.ntiles)
         const bool exw = !(variant & 64);      // fp32: exact-width columns (MODE 3) unless switched back to MODE 0
-#define XSQ_SLAB_LATE(TR_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, 3, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, tt.d_tiles, tt.ntiles)
+#define XSQ_SLAB_LATE(TR_) hipLaunchKernelGGL((cdae_slab_kernel<TR_, 3, true>), dim3(tt.ntiles), dim3(512), 0, stream, a, (const SlabTileDev*)tt.d_tiles, tt.ntiles)
         const bool late = !(variant & 512);      // fp32 exact-width kernel: next slab fetched in its own slot (no registers held across the MFMA slots: no scratch)
         if (layer == 2) { if (bf3) XSQ_SLAB(false, 1); else if (bf6) XSQ_SLAB(false, 2); else if (exw && late) XSQ_SLAB_LATE(false); else if (exw) XSQ_SLAB(false, 3); else XSQ_SLAB(false, 0); }
         else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw && late) XSQ_SLAB_LATE(true); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
@@ -889,6 +896,15 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 
 }  // namespace xsq
 
+#if XSQ_SLAB_STAMP
+extern "C" int xsq_debug_slab_stamps(unsigned long long* host, int tiles) {
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_slab_stamps), (size_t)(tiles < SLAB_STAMP_TILES ? tiles : SLAB_STAMP_TILES) * 64));
+    int occ = 0;
+    XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (cdae_slab_kernel<true, 3, true>), 512, 0));
+    return occ;
+}
+#endif
 #if XSQ_GEMM_STAMP
 extern "C" int xsq_debug_occupancy(int* out) {       // the runtime's own count of resident workgroups per CU
     XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], (grouped_gemm_kernel<CdaeL4Op, 1, 2>), 256, 0));

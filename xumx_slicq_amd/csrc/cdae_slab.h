@@ -20,6 +20,9 @@
 #include "gemm_tile_bf3.h"
 #include "gemm_tile_bf6.h"
 
+#ifndef XSQ_SLAB_STAMP
+#define XSQ_SLAB_STAMP 0    // diagnostic build: phase stamps of the fp32 slab kernel (tools/slab_phases.py)
+#endif
 #ifndef XSQ_SLAB_PRIO
 #define XSQ_SLAB_PRIO 0     // diagnostic A/B builds: 1 static priority for waves 4..7, 2 priority around every MFMA cluster
 #endif
@@ -56,8 +59,27 @@ constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored cha
 //       across the MFMA slots -- under the 128-VGPR cap of two workgroups per CU those registers were spilled
 //       (96-104 B of scratch per lane, 2.4 GB of HBM traffic per launch against 1.0 GB of activations, r01).  The
 //       round trip is exposed to this workgroup only; the other three waves of the SIMD keep the matrix pipe busy.
+#if XSQ_SLAB_STAMP
+// per tile (layer 3 only): s_memrealtime at 0 start, 1 prologue done (first slab + B tile in LDS), 2 slot loop done, 3 epilogue
+// stores issued; [4] = kf, [5] = summed duration of the slab-fetch slots (slot 7 of every df but the last), [6] HW_ID, [7] XCC_ID
+constexpr int SLAB_STAMP_TILES = 1 << 16;
+static __device__ unsigned long long g_slab_stamps[SLAB_STAMP_TILES * 8];
+#define XSQ_SS(i) do { if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) g_slab_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XSQ_SS(i) do { } while (0)
+#endif
+
+// One tile WITH everything the prologue needs of its (block, target): the kernel used to read the tile, then the block
+// descriptor it points at, then request the slab -- three dependent round trips before the first MFMA, and stamps
+// (tools/slab_phases.py) put the prologue at 8-13 us, 19 % of the summed tile time.  All offsets in floats.
+struct SlabTileDev {
+    int m0, kf, Fo, Fi;
+    int64_t in_off, out_off;       // input / output activations of the (block, target), relative to the layer's arenas
+    int64_t shift_off, w_off;      // shift vector / weight matrix inside the pool
+};
+
 template <bool TRANSPOSED, int MODE, bool LATE = false>
-__global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const TileDev* __restrict__ tiles, int ntiles) {
+__global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const SlabTileDev* __restrict__ tiles, int ntiles) {
     constexpr bool BF3 = MODE == 1, BF6 = MODE == 2, EXW = MODE == 3;
     constexpr bool F32T = MODE == 0 || MODE == 3;                // fp32 B tile / fp32 slab plane
     constexpr int BLD = BF6 ? SLAB_BLD6 : SLAB_BLD;               // words per B tile row
@@ -70,19 +92,16 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
-    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    const CdaeBlockDev& blk = a.blocks[t.group >> 2];
-    const int tgt = t.group & 3;
-    const int kf = blk.kf;
-    const int Fo = TRANSPOSED ? blk.F1 : blk.F2, To = TRANSPOSED ? a.T1 : a.T2;
-    const int Fi = TRANSPOSED ? blk.F2 : blk.F1, Ti = TRANSPOSED ? a.T2 : a.T1;
-    const float* in = TRANSPOSED ? a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)blk.cumF2 + (int64_t)tgt * blk.F2)
-                                 : a.act1 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)blk.cumF1 + (int64_t)tgt * blk.F1);
+    XSQ_SS(0);
+    const SlabTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const int kf = t.kf;
+    const int Fo = t.Fo, To = TRANSPOSED ? a.T1 : a.T2;
+    const int Fi = t.Fi, Ti = TRANSPOSED ? a.T2 : a.T1;
+    const float* in = (TRANSPOSED ? a.act2 : a.act1) + t.in_off;
     CdaeGroup g;
-    g.out = TRANSPOSED ? a.act3 + (int64_t)CS * a.Bn * a.T1 * (4 * (int64_t)blk.cumF1 + (int64_t)tgt * blk.F1)
-                       : a.act2 + (int64_t)CS * a.Bn * a.T2 * (4 * (int64_t)blk.cumF2 + (int64_t)tgt * blk.F2);
-    g.shift = a.pool + (TRANSPOSED ? blk.s3[tgt] : blk.s2[tgt]);
-    const float* Bt = (BF3 ? a.poolB : a.pool) + (TRANSPOSED ? blk.w3[tgt] : blk.w2[tgt]);
+    g.out = (TRANSPOSED ? a.act3 : a.act2) + t.out_off;
+    g.shift = a.pool + t.shift_off;
+    const float* Bt = (BF3 ? a.poolB : a.pool) + t.w_off;
     const int ldb = kf * SLAB_KRUN;
 
     // ---- the tile: rows m0 .. m0 + nrows of batch item b, split into segments (one per (b, f) row) --------
@@ -223,6 +242,10 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
     load_b(0, 0, 2);
     if (kf > 1 && !LATE) load_slab(1);
     __syncthreads();
+    XSQ_SS(1);
+#if XSQ_SLAB_STAMP
+    unsigned long long fetch_t = 0;
+#endif
     for (int df = 0; df < kf; ++df) {
         const bool more = df + 1 < kf;
 #pragma unroll
@@ -317,8 +340,14 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
                 }
             } else if (more) {                 // slot 7: every wave has passed the barrier behind the slab's last reader
                 if constexpr (LATE) {
+#if XSQ_SLAB_STAMP
+                    const unsigned long long f0 = __builtin_amdgcn_s_memrealtime();
+#endif
                     load_slab(df + 1, 0, 4); store_slab(0, 4);
                     load_slab(df + 1, 4, NLD); store_slab(4, NLD);
+#if XSQ_SLAB_STAMP
+                    fetch_t += __builtin_amdgcn_s_memrealtime() - f0;
+#endif
                 } else {
                     store_slab();
                     if (df + 2 < kf) load_slab(df + 2);
@@ -334,6 +363,14 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         }
     }
 #undef XSQ_MF
+    XSQ_SS(2);
+#if XSQ_SLAB_STAMP
+    if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) {
+        g_slab_stamps[blockIdx.x * 8 + 4] = kf; g_slab_stamps[blockIdx.x * 8 + 5] = fetch_t;
+        g_slab_stamps[blockIdx.x * 8 + 6] = (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        g_slab_stamps[blockIdx.x * 8 + 7] = (unsigned)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+    }
+#endif
 
     if (XSQ_SLAB_ABL & 16) {      // every accumulator set of the mode stays live (or its MFMAs would be removed with the epilogue)
         float sacc = acc0[0] + acc0[7];
@@ -347,6 +384,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Til
         //  6.6 KB of them and stores it as whole 16-byte lanes -- relu_shift_epilogue_xw, cdae.hip)
         static_assert(8 * 32 * CS * 4 <= 2 * PLANE * 2, "epilogue images do not fit the slab planes");
         relu_shift_epilogue_xw(g, t.m0 + wave * 32, lane, acc0, acc16, accv, NV, slabF + wave * 32 * CS);
+        XSQ_SS(3);
         return;
     }
     relu_shift_epilogue(g, t.m0 + wave * 32 + 4 * lk, lrow, acc0, acc1, false, BF3);
