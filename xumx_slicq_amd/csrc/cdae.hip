@@ -857,7 +857,11 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     const bool xw = !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && layer <= 3 && !(variant & 128);   // fp32 inference: no column padding
     if (!(variant & 4) && (layer == 2 || layer == 3) && (layer == 2 ? a.T2 : a.T1) >= 86 && !a.raw && !a.xin8 && !a.gx8 &&
         (bf3 || bf6 || !(variant & 8))) {
-        // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h)
+        // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h); they address a (block, target)'s
+        // input through 32-bit float offsets
+        for (const CdaeBlockDev& d : Mo->blocks)
+            XSQ_REQUIRE((int64_t)CS * a.Bn * a.T1 * d.F1 < ((int64_t)1 << 31), "xsq_cdae_forward: B=%d S=%d overflows the 32-bit "
+                        "offsets of a block's activations; split the batch", a.Bn, a.S);
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);      // its own event name: one kernel, one name

@@ -81,6 +81,10 @@ struct SlabTileDev {
 template <bool TRANSPOSED, int MODE, bool LATE = false>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const SlabTileDev* __restrict__ tiles, int ntiles) {
     constexpr bool BF3 = MODE == 1, BF6 = MODE == 2, EXW = MODE == 3;
+#ifndef XSQ_SLAB_EARLY2
+#define XSQ_SLAB_EARLY2 1
+#endif
+    constexpr bool EARLY2 = XSQ_SLAB_EARLY2 != 0;
     constexpr bool F32T = MODE == 0 || MODE == 3;                // fp32 B tile / fp32 slab plane
     constexpr int BLD = BF6 ? SLAB_BLD6 : SLAB_BLD;               // words per B tile row
     constexpr int PLANE = SLAB_POS * CS + 64;                    // bf16 elements per plane (a multiple of 8)
@@ -98,17 +102,13 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     const int Fo = t.Fo, To = TRANSPOSED ? a.T1 : a.T2;
     const int Fi = t.Fi, Ti = TRANSPOSED ? a.T2 : a.T1;
     const float* in = (TRANSPOSED ? a.act2 : a.act1) + t.in_off;
-    CdaeGroup g;
-    g.out = (TRANSPOSED ? a.act3 : a.act2) + t.out_off;
-    g.shift = a.pool + t.shift_off;
     const float* Bt = (BF3 ? a.poolB : a.pool) + t.w_off;
     const int ldb = kf * SLAB_KRUN;
 
     // ---- the tile: rows m0 .. m0 + nrows of batch item b, split into segments (one per (b, f) row) --------
     const int perb = Fo * To;
     const int b = t.m0 / perb;
-    const int mend = min((b + 1) * perb, t.m0 + SLAB_ROWS);
-    g.M = mend;                                          // the epilogue's row bound
+    const int mend = min((b + 1) * perb, t.m0 + SLAB_ROWS);     // the epilogue's row bound
     const int nrows = mend - t.m0;
     const int r0 = t.m0 - b * perb;
     const int f0 = r0 / To, t0 = r0 - f0 * To;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
                 const int len = seg_start(i + 1 < SLAB_MAXSEG ? i + 1 : i) - seg_start(i);   // rows of the segment
                 const int rows_i = (i + 1 < SLAB_MAXSEG) ? len : nrows - seg_start(i);
                 if (!(XSQ_SLAB_ABL & 8) && f < Fo && j < rows_i + 3 && fi >= 0 && fi < Fi && p >= 0 && p < Ti)
-                    v = *reinterpret_cast<const float4*>(in + (((int64_t)b * Fi + fi) * Ti + p) * CS + 4 * c4);
+                    v = *reinterpret_cast<const float4*>(in + (unsigned)(((b * Fi + fi) * Ti + p) * CS + 4 * c4));   // 32-bit offset from the uniform base: < 2^31 floats per (block, target) (xsq_cdae_forward checks), no 64-bit lane pointer to hold (it was spilled across the slots)
             }
             sa[q] = v;
         }
@@ -251,6 +251,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             if (ks < NKS) {
+                // LATE: two of the next slab's seven 16-byte loads per lane leave one slot early (slot 6 holds half a K-step:
+                // its fragment registers leave room), so that slot 7 is ONE request -> store round trip instead of two
+                if constexpr (LATE && EARLY2) { if (ks == NKS - 1 && more) load_slab(df + 1, 0, XSQ_SLAB_EARLY2 == 1 ? 2 : XSQ_SLAB_EARLY2); }
                 const unsigned* Bb = Bs + (ks & 1) * SLAB_BN * BLD;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -343,8 +346,11 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 #if XSQ_SLAB_STAMP
                     const unsigned long long f0 = __builtin_amdgcn_s_memrealtime();
 #endif
-                    load_slab(df + 1, 0, 4); store_slab(0, 4);
-                    load_slab(df + 1, 4, NLD); store_slab(4, NLD);
+                    if constexpr (EARLY2) { load_slab(df + 1, XSQ_SLAB_EARLY2 == 1 ? 2 : XSQ_SLAB_EARLY2, NLD); store_slab(0, NLD); }
+                    else {
+                        load_slab(df + 1, 0, 4); store_slab(0, 4);
+                        load_slab(df + 1, 4, NLD); store_slab(4, NLD);
+                    }
 #if XSQ_SLAB_STAMP
                     fetch_t += __builtin_amdgcn_s_memrealtime() - f0;
 #endif
@@ -372,6 +378,12 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     }
 #endif
 
+    // (the epilogue's pointers are formed HERE, from the tile entry: formed in the prologue they were held -- spilled, 12 B
+    //  of scratch per lane -- across the whole slot loop)
+    CdaeGroup g;
+    g.out = (TRANSPOSED ? a.act3 : a.act2) + t.out_off;
+    g.shift = a.pool + t.shift_off;
+    g.M = mend;
     if (XSQ_SLAB_ABL & 16) {      // every accumulator set of the mode stays live (or its MFMAs would be removed with the epilogue)
         float sacc = acc0[0] + acc0[7];
         if constexpr (EXW) sacc += acc16[0][1] + acc16[1][2] + accv[0] + accv[1] + accv[2] + accv[3];
