@@ -24,11 +24,13 @@ for _ in range(3):
     sep(x)
 torch.cuda.synchronize()
 ntiles = 1 << 16
-buf = np.zeros((ntiles, 8), dtype=np.uint64)
+raw = np.zeros(ntiles * 12, dtype=np.uint64)
+buf = raw[:ntiles * 8].reshape(ntiles, 8)
+buf2 = raw[ntiles * 8:].reshape(ntiles, 4)
 fn = _lib.lib.xsq_debug_slab_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int]
-occ = fn(buf.ctypes.data, ntiles)
+occ = fn(raw.ctypes.data, ntiles)
 ok = buf[:, 3] > 0
 b = buf[ok].astype(np.int64)
 us = (b[:, :4] - b[:, 0].min()) / 100.0
@@ -40,8 +42,8 @@ for c in sorted(set(kf.tolist())):
     d = np.diff(us[m], axis=1)
     print("  %2d  %5d  %8.2f  %9.2f  %18.2f  %8.2f  %6.2f | %6.2f" % (c, m.sum(), np.median(d[:, 0]), np.median(d[:, 1]), np.median(fetch[m]), np.median(d[:, 2]),
           np.median(us[m][:, 3] - us[m][:, 0]), c * 13 * (8 * 64 + 8 * 32) / 2100.0))
-hw, xcc = b[:, 6], b[:, 7] & 0xF
-cu_key = (xcc << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 8) | ((hw >> 8) & 0xF)
+hw = b[:, 6]
+cu_key = (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 8) | ((hw >> 8) & 0xF)
 res, gaps = [], []
 for key in list(set(cu_key.tolist()))[:64]:
     m = cu_key == key
@@ -52,8 +54,15 @@ for key in list(set(cu_key.tolist()))[:64]:
         nxt = st[st > e_]
         if len(nxt):
             gaps.append(nxt[0] - e_)
-print("  resident workgroups per CU at a start: mean %.2f, max %d; end of a workgroup -> next start on its CU: median %.2f us, p90 %.2f us"
-      % (np.mean(res), np.max(res), np.median(gaps), np.percentile(gaps, 90)))
+# (the CU key lacks the XCC id in this build -- its stamp slot holds the "lane setup done" time -- so eight CUs share a key)
+print("  resident workgroups per group of 8 same-numbered CUs at a start: mean %.2f, max %d" % (np.mean(res), np.max(res)))
 tot = (us[:, 3] - us[:, 0]).sum()
 print("  of the summed tile time: prologue %.3f, slot loop %.3f (slab-fetch slots %.3f), epilogue %.3f"
       % ((us[:, 1] - us[:, 0]).sum() / tot, (us[:, 2] - us[:, 1]).sum() / tot, fetch.sum() / tot, (us[:, 3] - us[:, 2]).sum() / tot))
+p2 = buf2[ok].astype(np.int64)
+for c in sorted(set(kf.tolist())):
+    m = kf == c
+    t00 = b[m][:, 0]
+    print("  kf %d prologue detail (us from the start): tile entry read %.2f, lane setup done %.2f, slab + B loads issued %.2f, first slab data %.2f, LDS stores done %.2f, barrier passed %.2f"
+          % (c, np.median((p2[m][:, 0] - t00) / 100.0), np.median((b[m][:, 7] - t00) / 100.0), *[np.median((p2[m][:, i] - t00) / 100.0) for i in range(1, 4)],
+             np.median((b[m][:, 1] - t00) / 100.0)))

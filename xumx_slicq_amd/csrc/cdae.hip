@@ -627,8 +627,13 @@ static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             e.kf = d.kf;
             if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.w_off = d.w2[tgt]; }
             else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.w_off = d.w3[tgt]; }
+            const int To = layer == 2 ? T2 : T1;
+            e.pad = 0;
             for (int bi = 0; bi < Bn; ++bi)
-                for (int64_t r = 0; r < perb; r += SLAB_ROWS) { e.m0 = (int)(bi * perb + r); t.push_back(e); }
+                for (int64_t r = 0; r < perb; r += SLAB_ROWS) {
+                    e.m0 = (int)(bi * perb + r); e.b = bi; e.f0 = (int)(r / To); e.t0 = (int)(r % To);
+                    t.push_back(e);
+                }
         }
     }
     TileTable tt;                    // (d_tiles holds SlabTileDev entries for this key: cast at the launch sites)
@@ -904,6 +909,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
 extern "C" int xsq_debug_slab_stamps(unsigned long long* host, int tiles) {
     XSQ_HIP(hipDeviceSynchronize());
     XSQ_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_slab_stamps), (size_t)(tiles < SLAB_STAMP_TILES ? tiles : SLAB_STAMP_TILES) * 64));
+    XSQ_HIP(hipMemcpyFromSymbol(host + (size_t)SLAB_STAMP_TILES * 8, HIP_SYMBOL(g_slab_stamps2), (size_t)SLAB_STAMP_TILES * 32));
     int occ = 0;
     XSQ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (cdae_slab_kernel<true, 3, true>), 512, 0));
     return occ;

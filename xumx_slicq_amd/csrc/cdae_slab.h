@@ -20,6 +20,9 @@
 #include "gemm_tile_bf3.h"
 #include "gemm_tile_bf6.h"
 
+#ifndef XSQ_SLAB_PROLOGUE_PRIO
+#define XSQ_SLAB_PROLOGUE_PRIO 0
+#endif
 #ifndef XSQ_SLAB_STAMP
 #define XSQ_SLAB_STAMP 0    // diagnostic build: phase stamps of the fp32 slab kernel (tools/slab_phases.py)
 #endif
@@ -64,6 +67,7 @@ constexpr int SLAB_BN = CS;                    // B tile rows: the 52 stored cha
 // stores issued; [4] = kf, [5] = summed duration of the slab-fetch slots (slot 7 of every df but the last), [6] HW_ID, [7] XCC_ID
 constexpr int SLAB_STAMP_TILES = 1 << 16;
 static __device__ unsigned long long g_slab_stamps[SLAB_STAMP_TILES * 8];
+static __device__ unsigned long long g_slab_stamps2[SLAB_STAMP_TILES * 4];    // prologue detail: 0 tile entry read, 1 slab loads issued, 2 slab data arrived, 3 LDS stores done
 #define XSQ_SS(i) do { if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) g_slab_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define XSQ_SS(i) do { } while (0)
@@ -72,11 +76,13 @@ static __device__ unsigned long long g_slab_stamps[SLAB_STAMP_TILES * 8];
 // One tile WITH everything the prologue needs of its (block, target): the kernel used to read the tile, then the block
 // descriptor it points at, then request the slab -- three dependent round trips before the first MFMA, and stamps
 // (tools/slab_phases.py) put the prologue at 8-13 us, 19 % of the summed tile time.  All offsets in floats.
-struct SlabTileDev {
+struct SlabTileDev {               // 64 bytes: one scalar load
     int m0, kf, Fo, Fi;
     int64_t in_off, out_off;       // input / output activations of the (block, target), relative to the layer's arenas
     int64_t shift_off, w_off;      // shift vector / weight matrix inside the pool
+    int b, f0, t0, pad;            // batch item, first output row (f0, t0) of the tile: m0 = b * Fo * To + f0 * To + t0
 };
+static_assert(sizeof(SlabTileDev) == 64, "SlabTileDev is meant to be one 64-byte scalar load");
 
 template <bool TRANSPOSED, int MODE, bool LATE = false>
 __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const SlabTileDev* __restrict__ tiles, int ntiles) {
@@ -97,8 +103,25 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
     XSQ_SS(0);
+#if XSQ_SLAB_PROLOGUE_PRIO
+    // A new workgroup's waves are the YOUNGEST on their SIMDs: beside the resident workgroup's MFMA stream they get the
+    // leftover vector-issue slots, and the few hundred instructions in front of the first slab request took 5-10 us
+    // (stamps).  Raised priority until the prologue's requests are out.
+    __builtin_amdgcn_s_setprio(XSQ_SLAB_PROLOGUE_PRIO);
+#endif
     const SlabTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    // every field in a scalar register HERE: left alone, the compiler fetched the entry in three pieces at three places
+    // of the prologue, each behind its own s_waitcnt -- three dependent round trips in front of the first slab request
+    asm volatile("" :: "s"(t.m0), "s"(t.kf), "s"(t.Fo), "s"(t.Fi), "s"(t.in_off), "s"(t.out_off), "s"(t.shift_off), "s"(t.w_off),
+                 "s"(t.b), "s"(t.f0), "s"(t.t0));
     const int kf = t.kf;
+#if XSQ_SLAB_STAMP
+#define XSQ_SS2(i) do { if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) g_slab_stamps2[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    if (kf == 12345) __builtin_trap();
+    XSQ_SS2(0);
+#else
+#define XSQ_SS2(i) do { } while (0)
+#endif
     const int Fo = t.Fo, To = TRANSPOSED ? a.T1 : a.T2;
     const int Fi = t.Fi, Ti = TRANSPOSED ? a.T2 : a.T1;
     const float* in = (TRANSPOSED ? a.act2 : a.act1) + t.in_off;
@@ -107,11 +130,10 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 
     // ---- the tile: rows m0 .. m0 + nrows of batch item b, split into segments (one per (b, f) row) --------
     const int perb = Fo * To;
-    const int b = t.m0 / perb;
+    const int b = t.b;                                          // (host-side: the two divisions cost the prologue ~100 instructions)
     const int mend = min((b + 1) * perb, t.m0 + SLAB_ROWS);     // the epilogue's row bound
     const int nrows = mend - t.m0;
-    const int r0 = t.m0 - b * perb;
-    const int f0 = r0 / To, t0 = r0 - f0 * To;
+    const int f0 = t.f0, t0 = t.t0;
     // segment i: output rows [seg_r[i], seg_r[i+1]) of the tile, f = f0 + i, first t = (i ? 0 : t0),
     // slab positions start at seg_r[i] + 3 i
     // (position j of a segment is input position  ts - PAD + j,  PAD = 3 for the transposed layer)
@@ -125,40 +147,61 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     const int a_base = (myrow + 3 * my_seg) * CS + 8 * lk;          // + k of the fragment
 
     // ---- staging assignments ------------------------------------------------------------------------------
-    constexpr int NLD = (SLAB_POS * (CS / 4) + 511) / 512;           // float4 loads per thread and slab (7)
+    // Slab staging.  Lane = (position lane p0 = tid / 13 of 39, channel quad c4 = tid % 13) over 507 of the 512 threads;
+    // load q of a lane is slab position p0 + 39 q -- no division per load (the first form divided tid + 512 q by 13 seven
+    // times per slab and searched the segment with min() chains per element: stamps put the prologue's address
+    // arithmetic at 5-10 us per tile, the slab data itself arrived 0.6-0.9 us after the request).  Per segment i the
+    // uniform quantities are formed once per slab: first slab position A_i, float offset G_i of that position in the
+    // (block, target)'s input, and the range [lo_i, hi_i) of in-segment positions j that exist.
+    constexpr int SLAB_PL = 512 / (CS / 4);                         // position lanes (39)
+    constexpr int NLD = (SLAB_POS + SLAB_PL - 1) / SLAB_PL;          // float4 loads per thread and slab (7)
+    static_assert(NLD == 7, "slab staging: seven loads per lane");
+    const int s_p0 = tid / (CS / 4), s_c4 = tid - s_p0 * (CS / 4);
+    const bool s_on = tid < SLAB_PL * (CS / 4);
     float4 sa[NLD];
 
     auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
-        const int total = (nrows + 3 * SLAB_MAXSEG) * (CS / 4);
+        int A[SLAB_MAXSEG], G[SLAB_MAXSEG], lo[SLAB_MAXSEG], hi[SLAB_MAXSEG];      // uniform (scalar registers)
+#pragma unroll
+        for (int i = 0; i < SLAB_MAXSEG; ++i) {
+            const int st = seg_start(i);
+            const int rows_i = (i + 1 < SLAB_MAXSEG ? seg_start(i + 1) : nrows) - st;      // output rows of the segment
+            const int f = f0 + i, ts = i ? 0 : t0;
+            const int fi = TRANSPOSED ? f - df : f + df;
+            const int first = ts - (TRANSPOSED ? 3 : 0);                                    // input position of j = 0
+            const bool ok = !(XSQ_SLAB_ABL & 8) && f < Fo && fi >= 0 && fi < Fi && rows_i > 0;
+            A[i] = st + 3 * i;
+            G[i] = ((b * Fi + fi) * Ti + first) * CS;
+            lo[i] = ok ? (first < 0 ? -first : 0) : 1;                                      // j with 0 <= first + j < Ti and j < rows_i + 3
+            hi[i] = ok ? min(rows_i + 3, Ti - first) : 0;
+        }
 #pragma unroll
         for (int q = q0; q < q1; ++q) {
-            const int e = tid + 512 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < total) {
-                const int pos = e / (CS / 4), c4 = e - pos * (CS / 4);
-                // which segment holds slab position pos?  segment i starts at seg_start(i) + 3 i
-                int i = 0;
+            const int pos = s_p0 + SLAB_PL * q;
+            int i = 0;
 #pragma unroll
-                for (int s = 1; s < SLAB_MAXSEG; ++s) i += (pos >= seg_start(s) + 3 * s) ? 1 : 0;
-                const int j = pos - (seg_start(i) + 3 * i);              // position inside the segment
-                const int f = f0 + i, ts = i ? 0 : t0;
-                const int fi = TRANSPOSED ? f - df : f + df;
-                const int p = ts - (TRANSPOSED ? 3 : 0) + j;
-                const int len = seg_start(i + 1 < SLAB_MAXSEG ? i + 1 : i) - seg_start(i);   // rows of the segment
-                const int rows_i = (i + 1 < SLAB_MAXSEG) ? len : nrows - seg_start(i);
-                if (!(XSQ_SLAB_ABL & 8) && f < Fo && j < rows_i + 3 && fi >= 0 && fi < Fi && p >= 0 && p < Ti)
-                    v = *reinterpret_cast<const float4*>(in + (unsigned)(((b * Fi + fi) * Ti + p) * CS + 4 * c4));   // 32-bit offset from the uniform base: < 2^31 floats per (block, target) (xsq_cdae_forward checks), no 64-bit lane pointer to hold (it was spilled across the slots)
-            }
+            for (int sI = 1; sI < SLAB_MAXSEG; ++sI) i += pos >= A[sI] ? 1 : 0;
+            int Ai = A[0], Gi = G[0], li = lo[0], hI = hi[0];
+#pragma unroll
+            for (int sI = 1; sI < SLAB_MAXSEG; ++sI)
+                if (i == sI) { Ai = A[sI]; Gi = G[sI]; li = lo[sI]; hI = hi[sI]; }
+            const int j = pos - Ai;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // 32-bit offset from the uniform base: < 2^31 floats per (block, target) (cdae_launch_layer checks); a 64-bit
+            // lane pointer here was spilled across the slot loop
+            if (s_on && j >= li && j < hI) v = *reinterpret_cast<const float4*>(in + (unsigned)(Gi + j * CS + 4 * s_c4));
             sa[q] = v;
         }
     };
     auto store_slab = [&](int q0 = 0, int q1 = NLD) {
 #pragma unroll
         for (int q = q0; q < q1; ++q) {
-            const int e = tid + 512 * q;
+            const int pos = s_p0 + SLAB_PL * q;
+            const int e = pos * (CS / 4) + s_c4;
+            const bool on = s_on && pos < SLAB_POS;
             if (!BF3) {
-                if (e < SLAB_POS * (CS / 4)) *reinterpret_cast<float4*>(&slabF[4 * e]) = sa[q];
-            } else if (e < SLAB_POS * (CS / 4)) {
+                if (on) *reinterpret_cast<float4*>(&slabF[4 * e]) = sa[q];
+            } else if (on) {
                 const unsigned e0 = __builtin_bit_cast(unsigned, sa[q].x), e1 = __builtin_bit_cast(unsigned, sa[q].y);
                 const unsigned e2 = __builtin_bit_cast(unsigned, sa[q].z), e3 = __builtin_bit_cast(unsigned, sa[q].w);
                 *reinterpret_cast<uint2*>(&slabH[4 * e]) = make_uint2(__builtin_amdgcn_perm(e1, e0, 0x07060302u), __builtin_amdgcn_perm(e3, e2, 0x07060302u));
@@ -234,13 +277,26 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 #if XSQ_SLAB_PRIO == 1       // diagnostic A/B: static priority for the second-dispatched half of the workgroup
     if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
+#if XSQ_SLAB_STAMP
+    if (a_base == -12345 || a16_base[0] == -12345 || a16_base[1] == -12345 || s_p0 == -12345) __builtin_trap();    // per-lane setup complete
+    if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) g_slab_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
     load_slab(0);
     load_b(0, 0, 0);
+    XSQ_SS2(1);
+#if XSQ_SLAB_STAMP
+    if (sa[0].x == 1.2345e-30f) __builtin_trap();
+    XSQ_SS2(2);
+#endif
     store_slab();
     store_b(0, 0);
+    XSQ_SS2(3);
     load_b(1, 0, 1);
     load_b(0, 0, 2);
     if (kf > 1 && !LATE) load_slab(1);
+#if XSQ_SLAB_PROLOGUE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     XSQ_SS(1);
 #if XSQ_SLAB_STAMP
@@ -374,7 +430,6 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) {
         g_slab_stamps[blockIdx.x * 8 + 4] = kf; g_slab_stamps[blockIdx.x * 8 + 5] = fetch_t;
         g_slab_stamps[blockIdx.x * 8 + 6] = (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-        g_slab_stamps[blockIdx.x * 8 + 7] = (unsigned)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
     }
 #endif
 
