@@ -26,8 +26,9 @@ glob.glob = newest
 def short(n):
     import re
     n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")    # profiles before r03e
-    n = n.replace("void xsq::band_dft4_full_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_full_kernel<true>", "band_dft4<forward>")
-    n = re.sub(r"void xsq::k_slice_(i?rfft)<\d+(?:, (?:true|false))?>", r"k_slice_\1", n)
+    n = re.sub(r"void xsq::band_dft4_full_kernel<false(?:, \d+)?>", "band_dft4<inverse>", n)
+    n = re.sub(r"void xsq::band_dft4_full_kernel<true(?:, \d+)?>", "band_dft4<forward>", n)
+    n = re.sub(r"void xsq::k_slice_(i?rfft)<\d+(?:, (?:true|false))*>", r"k_slice_\1", n)
     m = re.match(r"void xsq::cdae_slab_kernel<(true|false), (\d)(?:, (?:true|false))?>", n)
     if m:
         return {"0": "slab", "3": "slab", "1": "slab_bf3", "2": "slab_bf6"}[m.group(2)] + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
