@@ -37,7 +37,7 @@ ncb, ks = b[:, 4], b[:, 5]
 print("layer-4 launch: %d tiles stamped, span %.1f us" % (ok.sum(), us[:, 3].max()))
 print(" kind  K-steps  tiles  prologue  K loop  epilogue   total | per K-step  MFMA per K-step (us at 2.1 GHz)")
 tot = {}
-mf = {0: 16 * 64, 1: 8 * 64, 3: 8 * 64 + 8 * 32, 2: 8 * 32}
+mf = {0: 16 * 64 if os.environ.get('XSQ_STAMPED_LAYER', '4') == '4' else 8 * 64 + 8 * 32, 1: 8 * 64, 3: 8 * 64 + 8 * 32, 2: 8 * 32}      # layer 1 (XW = 1): 32 + 16 + vector columns
 for c, k in sorted(set(zip(ncb.tolist(), ks.tolist()))):
     m = (ncb == c) & (ks == k)
     d = np.diff(us[m], axis=1)

@@ -19,7 +19,7 @@ from xumx_slicq_amd.synth import synth_audio  # noqa: E402
 
 sep = seeded_separator(realtime=False, wiener=False)
 sep.overlap_tail = False
-x = synth_audio(4 * 2_621_440, seed=1).cuda()
+x = synth_audio(int(os.environ.get("XSQ_STAMP_CHUNKS", "4")) * 2_621_440, seed=1).cuda()
 for _ in range(3):
     sep(x)
 torch.cuda.synchronize()
@@ -63,6 +63,6 @@ p2 = buf2[ok].astype(np.int64)
 for c in sorted(set(kf.tolist())):
     m = kf == c
     t00 = b[m][:, 0]
-    print("  kf %d prologue detail (us from the start): tile entry read %.2f, lane setup done %.2f, slab + B loads issued %.2f, first slab data %.2f, LDS stores done %.2f, barrier passed %.2f"
+    print("  kf %d prologue detail (us from the start): request 0 of the slab issued %.2f, lane setup done %.2f, all requests issued %.2f, first slab data %.2f, request 3 issued %.2f, barrier passed %.2f"
           % (c, np.median((p2[m][:, 0] - t00) / 100.0), np.median((b[m][:, 7] - t00) / 100.0), *[np.median((p2[m][:, i] - t00) / 100.0) for i in range(1, 4)],
              np.median((b[m][:, 1] - t00) / 100.0)))

@@ -179,6 +179,7 @@ __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int r
 struct CdaeL1Op {
     typedef CdaeGroup Group;
     typedef RowFT RowA;
+    static constexpr bool STAMPED = XSQ_GEMM_STAMP == 2;      // (diagnostic builds with XSQ_GEMM_STAMP=2: tools/gemm_phases.py)
     CdaeArgs a;
     __device__ Group group(int gid) const {
         const CdaeBlockDev& b = a.blocks[gid >> 2];
@@ -341,7 +342,7 @@ struct CdaeL3Op {
 struct CdaeL4Op {
     typedef CdaeGroup Group;
     typedef RowFT RowA;
-    static constexpr bool STAMPED = true;      // (diagnostic builds with XSQ_GEMM_STAMP: tools/gemm_phases.py)
+    static constexpr bool STAMPED = XSQ_GEMM_STAMP == 1;      // (diagnostic builds with XSQ_GEMM_STAMP=1: tools/gemm_phases.py)
     CdaeArgs a;
     __device__ Group group(int gid) const {
         const CdaeBlockDev& b = a.blocks[gid >> 2];

@@ -118,7 +118,6 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 #if XSQ_SLAB_STAMP
 #define XSQ_SS2(i) do { if (TRANSPOSED && tid == 0 && blockIdx.x < SLAB_STAMP_TILES) g_slab_stamps2[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     if (kf == 12345) __builtin_trap();
-    XSQ_SS2(0);
 #else
 #define XSQ_SS2(i) do { } while (0)
 #endif
@@ -159,6 +158,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     const int s_p0 = tid / (CS / 4), s_c4 = tid - s_p0 * (CS / 4);
     const bool s_on = tid < SLAB_PL * (CS / 4);
     float4 sa[NLD];
+#if XSQ_SLAB_STAMP
+    bool stamp_loads = true;
+#endif
 
     auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
         int A[SLAB_MAXSEG], G[SLAB_MAXSEG], lo[SLAB_MAXSEG], hi[SLAB_MAXSEG];      // uniform (scalar registers)
@@ -191,6 +193,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
             // lane pointer here was spilled across the slot loop
             if (s_on && j >= li && j < hI) v = *reinterpret_cast<const float4*>(in + (unsigned)(Gi + j * CS + 4 * s_c4));
             sa[q] = v;
+#if XSQ_SLAB_STAMP
+            if (stamp_loads && (q == 0 || q == 3)) { XSQ_SS2(q == 0 ? 0 : 3); }      // (reuses two prologue-detail slots: request 0 / request 3 issued)
+#endif
         }
     };
     auto store_slab = [&](int q0 = 0, int q1 = NLD) {
@@ -290,7 +295,9 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
 #endif
     store_slab();
     store_b(0, 0);
-    XSQ_SS2(3);
+#if XSQ_SLAB_STAMP
+    stamp_loads = false;
+#endif
     load_b(1, 0, 1);
     load_b(0, 0, 2);
     if (kf > 1 && !LATE) load_slab(1);

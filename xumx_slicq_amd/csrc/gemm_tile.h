@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     }
     if constexpr (XW == 1) {
         // (the K loop ended on a barrier: the staging buffers are free, each wave takes 32 x 52 floats of them)
-        if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv, lds + wave * 32 * 52); return; }
+        if (wide) { op.epilogue_xw(g, t.m0 + wave * 32, lane, acc0[0], acc16, accv, lds + wave * 32 * 52); XSQ_GS(3); return; }
     }
     if constexpr (XW == 2) {
         if (kind >= 2) op.epilogue16(g, t.m0 + wave * 32, lane, t.n0 + (kind == 3 ? 32 : 0), acc16);
