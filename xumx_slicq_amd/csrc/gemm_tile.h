@@ -94,27 +94,25 @@ __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (
 // TileDev.narrow = 0: 64 columns (two 32x32 blocks), 1: 32, 3: 48 (32x32 block + 16x16x4 blocks), 2: 16 (16x16x4
 // blocks only); the operator supplies epilogue16 for the 16-column blocks.  Padding N to 32/64 cost 38 % there.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <class Op, int MT = 1, int XW = 0>
-__global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
-                                                            int ntiles) {
-    static_assert(XW == 0 || MT == 1, "exact-width columns: MT = 1 only");
-    static_assert(XW != 1 || 4 * 32 * 52 <= 2 * (GEMM_BM + GEMM_BN) * GEMM_LD, "XW = 1 epilogue image does not fit the staging buffers");
+// One tile.  KIND >= 0 (XW = 2, layer 4): the tile's width class is a COMPILE-TIME fact of this instantiation -- the kernel
+// switches once, outside everything.  With the class a run-time value the K loop carried the MFMA sequences of all four
+// classes and, where their accumulator assignments met, 70-90 v_accvgpr_write / v_accvgpr_mov / v_mov per K-step: more
+// than half of its vector instructions (round 3, read off the ISA), in a kernel whose K-steps are bound by exactly those
+// (a wave that is not issuing MFMAs gets few vector issue slots beside the ones that are).
+template <class Op, int MT, int XW, int KIND>
+__device__ __forceinline__ void gemm_tile_body(const Op& op, const TileDev t, float* const lds) {
     constexpr int BM = GEMM_BM * MT, BN = GEMM_BN, BK = GEMM_BK, LD = GEMM_LD;
     constexpr int RA = BM / 64;     // A rows staged per thread
-
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LD];
     float* const As0 = lds;
     float* const Bs0 = lds + 2 * BM * LD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    XSQ_GS(0);
-    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     // wave-uniform.  XW = 1 operators have N = 52: one tile, always the full width -- a compile-time fact, or the K-step
     // carries both MFMA sequences and 16 accumulator copies where their register assignments meet
-    const bool wide = XW == 1 ? true : t.narrow == 0;
-    const int kind = XW == 2 ? t.narrow : (wide ? 0 : 1);
+    const bool wide = XW == 1 ? true : (KIND >= 0 ? KIND == 0 : t.narrow == 0);
+    const int kind = KIND >= 0 ? KIND : (XW == 2 ? t.narrow : (wide ? 0 : 1));
     const typename Op::Group g = op.group(t.group);
     const int K = (XSQ_ABLATE & 32) ? 16 : g.K;      // bit 5: one K-step only (epilogue cost in isolation)
 
@@ -278,18 +276,41 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
     load_set(0, 2 * BK);
     __syncthreads();
 
-    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-        // even K-step: compute buffer 0; set 1 (K-step k0+16) -> buffer 1; reload set 1 with k0+48
-        mfma_step(0);
-        if (k0 + BK < K) store_set(1, 1);
-        load_set(1, k0 + 3 * BK);
-        __syncthreads();
-        if (k0 + BK >= K) break;
-        // odd K-step: compute buffer 1; set 0 (K-step k0+32) -> buffer 0; reload set 0 with k0+64
-        mfma_step(1);
-        if (k0 + 2 * BK < K) store_set(0, 0);
-        load_set(0, k0 + 4 * BK);
-        __syncthreads();
+    if constexpr (KIND >= 0) {
+        // K-steps in pairs (buffer / register-set parity static), an odd last step behind the loop.  (One loop with a
+        // break between its two halves gave the accumulators two exit paths: the compiler copied all of them -- 32-64
+        // v_accvgpr_write / v_accvgpr_mov per iteration -- where the paths met.)  The other operators keep the loop
+        // below: in this form the masked band synthesis operator needs 136 registers (three workgroups per CU).
+        const int nk = (K + BK - 1) / BK;
+        int k0 = 0;
+        for (int pr = 0; pr < nk / 2; ++pr, k0 += 2 * BK) {
+            mfma_step(0);
+            store_set(1, 1);
+            load_set(1, k0 + 3 * BK);
+            __syncthreads();
+            mfma_step(1);
+            if (k0 + 2 * BK < K) store_set(0, 0);
+            load_set(0, k0 + 4 * BK);
+            __syncthreads();
+        }
+        if (nk & 1) {
+            mfma_step(0);
+            __syncthreads();        // (the epilogues reuse the staging buffers)
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+            // even K-step: compute buffer 0; set 1 (K-step k0+16) -> buffer 1; reload set 1 with k0+48
+            mfma_step(0);
+            if (k0 + BK < K) store_set(1, 1);
+            load_set(1, k0 + 3 * BK);
+            __syncthreads();
+            if (k0 + BK >= K) break;
+            // odd K-step: compute buffer 1; set 0 (K-step k0+32) -> buffer 0; reload set 0 with k0+64
+            mfma_step(1);
+            if (k0 + 2 * BK < K) store_set(0, 0);
+            load_set(0, k0 + 4 * BK);
+            __syncthreads();
+        }
     }
 
     XSQ_GS(2);
@@ -325,6 +346,29 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev*
 #pragma unroll
     for (int i = 0; i < MT; ++i)
         op.epilogue(g, t.m0 + (wave * MT + i) * 32 + 4 * lk, t.n0 + lrow, acc0[i], acc1[i], wide);
+}
+
+template <class Op, int MT = 1, int XW = 0>
+__global__ __launch_bounds__(256) void grouped_gemm_kernel(Op op, const TileDev* __restrict__ tiles,
+                                                            int ntiles) {
+    static_assert(XW == 0 || MT == 1, "exact-width columns: MT = 1 only");
+    static_assert(XW != 1 || 4 * 32 * 52 <= 2 * (GEMM_BM + GEMM_BN) * GEMM_LD, "XW = 1 epilogue image does not fit the staging buffers");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (GEMM_BM * MT + GEMM_BN) * GEMM_LD];
+#if XSQ_GEMM_STAMP
+    const int tid = threadIdx.x;
+#endif
+    XSQ_GS(0);
+    const TileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    if constexpr (XW == 2) {
+        switch (t.narrow) {          // workgroup-uniform
+            case 0: gemm_tile_body<Op, MT, XW, 0>(op, t, lds); break;
+            case 1: gemm_tile_body<Op, MT, XW, 1>(op, t, lds); break;
+            case 2: gemm_tile_body<Op, MT, XW, 2>(op, t, lds); break;
+            default: gemm_tile_body<Op, MT, XW, 3>(op, t, lds); break;
+        }
+    } else {
+        gemm_tile_body<Op, MT, XW, -1>(op, t, lds);
+    }
 }
 
 }  // namespace xsq
