@@ -45,6 +45,9 @@ for c in sorted(set(ncb)):
           np.median(us[m][:, 3] - us[m][:, 0]), np.median(d[:, 1]) / max(k - 1, 1), 8 * c * 32 / 2100.0))
     tot[int(c)] = float((us[m][:, 3] - us[m][:, 0]).sum())
 s = sum(tot.values())
+dall = np.diff(us, axis=1)
+print("  share of the summed tile time by phase: prologue %.3f, K loop %.3f, epilogue %.3f; summed %.0f us over %.1f us = %.0f tiles resident on average"
+      % (*(dall.sum(axis=0) / dall.sum()), dall.sum(), us[:, 3].max(), dall.sum() / us[:, 3].max()))
 print("  share of the summed tile time by ncb:", {c: round(v / s, 3) for c, v in tot.items()})
 for when in np.linspace(0.2, 0.8, 4) * us[:, 3].max():
     run = (us[:, 0] <= when) & (us[:, 3] > when)

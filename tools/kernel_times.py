@@ -8,7 +8,11 @@ from xumx_slicq_amd.synth import synth_audio
 dev = torch.device("cuda", 0)
 sep = seeded_separator(realtime=False, wiener=False, device=dev)
 sep.xumx_model.set_precision(os.environ.get("PREC", "fp32"))
-x = synth_audio(10_584_000, seed=20260101).to(dev)
+if os.environ.get("NO_TAIL"):       # four full chunks, one stacked pass, nothing on the side stream: clean per-kernel times
+    sep.overlap_tail = False
+    x = synth_audio(4 * 2_621_440, seed=20260101).to(dev)
+else:
+    x = synth_audio(10_584_000, seed=20260101).to(dev)
 for _ in range(2): out = sep(x)
 torch.cuda.synchronize()
 _lib.profile_enable(True); _lib.profile_reset()

@@ -86,37 +86,72 @@ __device__ unsigned long long g_d4_stamps[D4_STAMP_TILES * 8];
 #else
 #define XSQ_D4S(i) do { } while (0)
 #endif
+#ifndef XSQ_D4_ABL
+#define XSQ_D4_ABL 0        // diagnostic build (timings only, results wrong): 1 no MFMAs, 2 no operand loads inside the K loop, 4 no epilogue stores
+#endif
 
 constexpr int D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
 constexpr int D4H_ROWS = 32;
+
+// Vector issue.  On gfx950 an fp32 MFMA runs at exactly the rate of the SIMD's packed-fp32 vector ALU, and measured it does
+// not overlap with the vector instructions of the SIMD's other waves: a K-step of this kernel takes the SUM of its MFMA
+// cycles (256 per 16-column block and wave) and 4 cycles per other vector instruction, times the three resident waves
+// (round-4 ablations: no MFMAs -10 %, no K-loop loads -5 %, both -46 %; K-step 0.56 + 0.41 ncb us; tools/valu_mfma.py
+// counts the two from the assembly).  The round-3 form spent 108 vector instructions per K-step and 63 per 16-column
+// block of the epilogue -- as many issue cycles as the MFMAs of a 4-block band -- two thirds of them address arithmetic:
+// 64-bit pointer sums per load, clamps, selects around loads and stores.  Here every operand and result goes through a
+// BUFFER descriptor: the per-thread offset is formed once per tile, the K-step / quarter / column-block displacement is a
+// scalar offset, rows past the end and columns past the band are switched off by an out-of-range offset (loads return 0,
+// stores are dropped) instead of clamps and predicates.
+typedef unsigned d4_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned d4_u32x2 __attribute__((ext_vector_type(2)));
+// every range below is < 2^30 bytes (checked where the launch is built): a row switch, a column switch or both added to
+// an in-range offset stay out of range without wrapping
+constexpr unsigned D4_OOB = 0x80000000u, D4_OOB_COL = 0x40000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t d4_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 d4_ld2(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ float d4_ld1(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ float4 d4_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ void d4_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(d4_u32x4, v), r, (int)vo, so, 0);
+}
+__device__ __forceinline__ void d4_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(d4_u32x2, v), r, (int)vo, so, 0);
+}
+
 // NCBMAX = most 16-column blocks a band of this instantiation has.  10 (Lg <= 320): 49 KB of LDS and 80 accumulator
 // registers, three workgroups per CU -- the product configuration.  5 (Lg <= 160): 35 KB and 40 accumulator registers
-// -> FOUR workgroups per CU, an A/B arm (XSQ_D4_SPLIT=1) that measured no faster.  The kernel waits: in-kernel stamps
-// (tools/band_phases.py) put a K-step at 1.8-4.2 us of wall time for 0.24-1.2 us of MFMAs per wave (the next operands
-// arrive after 2-5 us under load) and the prologue at 3.4-8.4 us; a fourth resident workgroup on the narrow bands -- 41 %
-// of the summed tile time -- did not shorten them: the round trips lengthen with the requests in flight.
+// -> FOUR workgroups per CU, an A/B arm (XSQ_D4_SPLIT=1) that measured no faster.
 template <int NCBMAX> struct D4Cfg { static constexpr int waves = NCBMAX > 5 ? 3 : 4, mpad = NCBMAX > 5 ? D4_MPAD : 40; };
-template <bool FWD, int NCBMAX = 10>
+// MASKED (synthesis only): the coefficients are mask * mix, formed on the way in (Band4Args.mask).
+template <bool FWD, int NCBMAX = 10, bool MASKED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D4Cfg<NCBMAX>::waves, D4Cfg<NCBMAX>::waves)))
 void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
+    static_assert(!(FWD && MASKED), "the mask product belongs to the synthesis");
     constexpr int D4H_NCB = NCBMAX, MPADL = D4Cfg<NCBMAX>::mpad;
     __shared__ __attribute__((aligned(16))) float lds[2 * (4 * D4H_ROWS + 16 * D4H_NCB) * D4_LD];
     __shared__ __attribute__((aligned(16))) float2 twl[3 * MPADL];        // w^(r t1), r = 1..3, of this tile's band
-    __shared__ __attribute__((aligned(16))) float winl[4 * MPADL];        // INV: dual window wd[q] of this tile's band
+    __shared__ __attribute__((aligned(16))) float winl[4 * MPADL];        // window of this tile's band: g'[q] (FWD) / wd[q] (INV)
     constexpr int ABUF = 4 * D4H_ROWS * D4_LD, BBUF = 16 * D4H_NCB * D4_LD;
     float* const As0 = lds;                     // [buf][r][row][20]
     float* const Bs0 = lds + 2 * ABUF;          // [buf][col][20]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     XSQ_D4S(0);
-    // By value: through a reference into global memory the compiler had to RE-LOAD the fields after every store of the
-    // epilogue (they might alias), and each reload's s_waitcnt vmcnt(0) also waited for the store before it -- one HBM
-    // round trip per 16-byte store (tools/scan_isa.py counts such loads).
-    const Tile4Dev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    const Tile4Dev t = tiles[xcd_remap(blockIdx.x, ntiles)];     // by value: one batched scalar load
     const int ncb = t.ncb;                      // 16-column blocks of the band, 1..10 (uniform)
     const Band4Dev bd = t.bd;
     const int m_ = bd.m, Lg = bd.Lg, K = 2 * m_, M = a.BC * a.S;
     const int64_t BCS = (int64_t)a.BC * a.S;
+    const int mpad = (m_ + 7) & ~7;
 
     // ---- staging assignment: row s_row, complex t1 = K-step base + s_t ---------------------------
     const int s_row = tid >> 3, s_t = tid & 7;
@@ -124,64 +159,69 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     const bool row_ok = row < M;
     const int rowc = row_ok ? row : M - 1;
     const int bc = rowc / a.S, sl = rowc - bc * a.S;
-    const float* const xbase = a.src;
-    const float* const mbase = a.mask;
-    const bool masked = !FWD && a.mask != nullptr;
-    int xoff, moff = 0;
-    if (FWD) xoff = rowc * 2 * a.nbins;
-    else if (!masked) xoff = (int)(2 * (BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + sl) * Lg));
-    else {
-        moff = (int)(BCS * bd.cum + (((int64_t)bc * bd.F + bd.f) * a.S + sl) * Lg);
-        xoff = (int)(2 * ((int64_t)a.BCx * a.S * bd.cum + (((int64_t)(bc % a.BCx) * bd.F + bd.f) * a.S + sl) * Lg));
+    constexpr bool masked = MASKED;
+    // FWD: a band whose window leaves [0, L/2] reads Hermitian reflections (the lowest and the highest bands): pointer path
+    const bool reflect = FWD && (bd.bin0 < 0 || bd.bin0 + Lg - 1 > a.L / 2);
+    // operand descriptors and this thread's offsets inside them (bytes)
+    __amdgpu_buffer_rsrc_t rx, rm = d4_rsrc(a.src, 0);
+    unsigned vx, vm = D4_OOB;
+    const unsigned blk = (unsigned)(bd.F * Lg) * (unsigned)a.S;          // elements of one channel in the band's block
+    if (FWD) {                                   // spectrum rows of this tile: x[q] sits at bin bin0 + (q + Lg/2) mod Lg
+        rx = d4_rsrc(a.src + 2 * ((int64_t)t.m0 * a.nbins), 8u * D4H_ROWS * a.nbins);
+        vx = row_ok ? 8u * (unsigned)(s_row * a.nbins + bd.bin0 + s_t) : D4_OOB;
+    } else if (!masked) {
+        rx = d4_rsrc(a.src + 2 * (BCS * bd.cum), 8u * a.BC * blk);
+        vx = row_ok ? 8u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
+    } else {
+        rx = d4_rsrc(a.src + 2 * ((int64_t)a.BCx * a.S * bd.cum), 8u * a.BCx * blk);
+        rm = d4_rsrc(a.mask + BCS * bd.cum, 4u * a.BC * blk);
+        vx = row_ok ? 8u * (unsigned)((((bc % a.BCx) * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
+        vm = row_ok ? 4u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
     }
-    const float* win = a.pool + bd.win_off;
-    const int mpad = (m_ + 7) & ~7;
-    const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
-    // DFT matrix slab of a K-step: 16 ncb rows (n) x 16 floats = 64 ncb float4, item i = tid + 256 u: n = i >> 2, k quad i & 3
-    const float* bp = a.pool + bd.d_off + (int64_t)(tid >> 2) * bd.ldd + 4 * (tid & 3);
+    const float* const xrow = a.src + (int64_t)rowc * 2 * a.nbins;       // FWD, reflecting bands only
+    // DFT matrix slab of a K-step: 16 ncb rows (n) x 16 floats = 64 ncb float4, item i = tid + 256 u: n = i >> 2, k quad i & 3.
+    // The pool holds round_up(2m, 64) rows (zero past 2m), so every item of a requested group lies inside it.
+    const __amdgpu_buffer_rsrc_t rb = d4_rsrc(a.pool + bd.d_off, 4u * (unsigned)(((K + 63) & ~63) * bd.ldd));
+    const unsigned vb = 4u * (unsigned)((tid >> 2) * bd.ldd + 4 * (tid & 3));
+    const int sb64 = 4 * 64 * bd.ldd;            // 64 rows further down
     const int nb4 = 64 * ncb;
     constexpr int NBU = (64 * D4H_NCB + 255) / 256;     // float4 items of the matrix slab per thread (3 / 2)
-    int bover[NBU];                              // rows by which item u of this thread lies past the slab (0 inside)
-#pragma unroll
-    for (int u = 0; u < NBU; ++u) { const int n = (tid >> 2) + 64 * u; bover[u] = n < 16 * ncb ? 0 : n - (16 * ncb - 1); }
 
-    float2 raw[4];         // INV: quarter a, complex tc;  FWD: spectrum value of quarter a
-    float aux[4];          // INV: mask of quarter a;  FWD: window value
+    float2 raw[4];         // quarter a, complex t1 (FWD: spectrum value of the quarter)
+    float aux[4];          // INV: mask of quarter a
     float4 gb[NBU];
 #pragma unroll
     for (int u = 0; u < NBU; ++u) gb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int g_t1 = 0;
 
-    auto fwd_idx = [&](int tt, int q4, float& cj) {        // spectrum bin of window index tt + q4*m, Hermitian reflection
-        int idx = bd.bin0 + tt + ((q4 + 2) & 3) * m_;
-        cj = 1.f;
-        if (idx < 0) { idx = -idx; cj = -1.f; }
-        else if (idx > a.L / 2) { idx = a.L - idx; cj = -1.f; }
-        return idx;
-    };
-    // load_set only issues loads (clamped addresses, nothing consumed); products, selects and butterflies in store_set
+    // load_set only issues loads; products, selects and butterflies in store_set.  The matrix slab (L2) is requested first.
     auto load_set = [&](int k0) {
-        const int t1 = (k0 >> 1) + s_t;
-        g_t1 = t1;
-        const int tc = t1 < m_ ? t1 : m_ - 1;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            if (!FWD) {
-                raw[q4] = *reinterpret_cast<const float2*>(xbase + (xoff + 2 * (tc + q4 * m_)));
-                if (masked) aux[q4] = mbase[moff + tc + q4 * m_];
-            } else {
-                float cj;
-                aux[q4] = win[tc + q4 * m_];
-                raw[q4] = *reinterpret_cast<const float2*>(xbase + (xoff + 2 * fwd_idx(tc, q4, cj)));
+        for (int u = 0; u < NBU; ++u)       // uniform test
+            if (256 * u < nb4) gb[u] = d4_ld4(rb, vb, u * sb64 + 4 * k0);
+        if (!FWD) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                raw[q4] = d4_ld2(rx, vx, 4 * k0 + 8 * q4 * m_);
+                if (masked) aux[q4] = d4_ld1(rm, vm, 2 * k0 + 4 * q4 * m_);
+            }
+        } else if (!reflect) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) raw[q4] = d4_ld2(rx, vx, 4 * k0 + 8 * ((q4 + 2) & 3) * m_);
+        } else {
+            const int t1 = (k0 >> 1) + s_t, tc = t1 < m_ ? t1 : m_ - 1;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int idx = bd.bin0 + tc + ((q4 + 2) & 3) * m_;
+                if (idx < 0) idx = -idx;
+                else if (idx > a.L / 2) idx = a.L - idx;
+                raw[q4] = *reinterpret_cast<const float2*>(xrow + 2 * idx);
             }
         }
-#pragma unroll
-        for (int u = 0; u < NBU; ++u)       // uniform test; rows past the band's blocks re-read the last row (not stored)
-            if (256 * u < nb4) gb[u] = *reinterpret_cast<const float4*>(bp + (int64_t)(64 * u - bover[u]) * bd.ldd + k0);
     };
-    auto store_set = [&](int buf) {
-        const int t1 = g_t1;
-        const bool ok = row_ok && t1 < m_;
+    // LDS addresses of this thread's staging stores and of the twiddle / window reads (floats)
+    const int a_st = s_row * D4_LD + 2 * s_t, b_st = (tid >> 2) * D4_LD + 4 * (tid & 3);
+    auto store_set = [&](int buf, int k0) {
+        const int t1 = (k0 >> 1) + s_t;          // < mpad always (mpad = 8 * K-steps)
         float2 x[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -189,14 +229,22 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
             if (!FWD) {
                 if (masked) { v.x *= aux[q4]; v.y *= aux[q4]; }
             } else {
-                float cj;
-                (void)fwd_idx(t1 < m_ ? t1 : m_ - 1, q4, cj);
-                v = make_float2(v.x * aux[q4], cj * v.y * aux[q4]);
+                const float g = winl[t1 + q4 * m_];          // window value (0 past the band: table zero-filled)
+                float cj = 1.f;
+                if (reflect) {
+                    const int idx = bd.bin0 + (t1 < m_ ? t1 : m_ - 1) + ((q4 + 2) & 3) * m_;
+                    cj = (idx < 0 || idx > a.L / 2) ? -1.f : 1.f;
+                }
+                v = make_float2(v.x * g, cj * v.y * g);
             }
-            x[q4] = ok ? v : make_float2(0.f, 0.f);
+            x[q4] = v;
         }
-        const int tl = t1 < mpad ? t1 : 0;       // table is zero past m; t1 >= mpad only on rows that are zero anyway
-        const float2 w1 = twl[tl], w2 = twl[mpad + tl], w3 = twl[2 * mpad + tl];
+        if (k0 + 16 > K) {                       // the band's last, partial K-step: complex t1 >= m belong to the next quarter
+            const bool ok = t1 < m_;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) x[q4] = ok ? x[q4] : make_float2(0.f, 0.f);
+        }
+        const float2 w1 = twl[t1], w2 = twl[mpad + t1], w3 = twl[2 * mpad + t1];
         const float2 s0 = make_float2(x[0].x + x[2].x, x[0].y + x[2].y), s1 = make_float2(x[1].x + x[3].x, x[1].y + x[3].y);
         const float2 d0 = make_float2(x[0].x - x[2].x, x[0].y - x[2].y), d1 = make_float2(x[1].x - x[3].x, x[1].y - x[3].y);
         const float2 y0 = make_float2(s0.x + s1.x, s0.y + s1.y);
@@ -207,12 +255,12 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
         const float2 z1 = make_float2(y1.x * w1.x - y1.y * w1.y, y1.x * w1.y + y1.y * w1.x);
         const float2 z2 = make_float2(y2.x * w2.x - y2.y * w2.y, y2.x * w2.y + y2.y * w2.x);
         const float2 z3 = make_float2(y3.x * w3.x - y3.y * w3.y, y3.x * w3.y + y3.y * w3.x);
-        float* Aw = As0 + buf * ABUF + s_row * D4_LD + 2 * s_t;
+        float* Aw = As0 + buf * ABUF + a_st;
         *reinterpret_cast<float2*>(Aw) = y0;
         *reinterpret_cast<float2*>(Aw + D4H_ROWS * D4_LD) = z1;
         *reinterpret_cast<float2*>(Aw + 2 * D4H_ROWS * D4_LD) = z2;
         *reinterpret_cast<float2*>(Aw + 3 * D4H_ROWS * D4_LD) = z3;
-        float* Bw = Bs0 + buf * BBUF + (tid >> 2) * D4_LD + 4 * (tid & 3);
+        float* Bw = Bs0 + buf * BBUF + b_st;
 #pragma unroll
         for (int u = 0; u < NBU; ++u)
             if (tid + 256 * u < nb4) *reinterpret_cast<float4*>(Bw + 64 * u * D4_LD) = gb[u];
@@ -230,28 +278,37 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     load_set(0);
     float w_mu = 0.f, w_sc = 1.f;                // whitening constants of this tile's band (uniform)
     if (FWD && a.xin) { w_mu = a.mean[bd.jband]; w_sc = a.scale[bd.jband]; }
-    {   // tables of the band into LDS: every value of this thread requested before the first is stored (a load -> store
-        // loop made Lg > 256 two dependent round trips)
+    {   // tables of the band into LDS: every value of this thread requested before the first is stored
+        const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
+        const float* win = a.pool + bd.win_off;
         const float2 tv = tid < 3 * mpad ? tw[tid] : make_float2(0.f, 0.f);
-        float wv0 = 0.f, wv1 = 0.f;
-        if (!FWD) { wv0 = tid < Lg ? win[tid] : 0.f; wv1 = tid + 256 < Lg ? win[tid + 256] : 0.f; }
+        const float wv0 = tid < Lg ? win[tid] : 0.f, wv1 = tid + 256 < Lg ? win[tid + 256] : 0.f;
         if (tid < 3 * mpad) twl[tid] = tv;
-        if (!FWD) { if (tid < Lg) winl[tid] = wv0; if (tid + 256 < Lg) winl[tid + 256] = wv1; }
+        winl[tid] = wv0;                          // zero past Lg: the FWD staging reads up to 4 mpad - 1
+        if (tid + 256 < 4 * MPADL) winl[tid + 256] = wv1;
     }
     __syncthreads();             // tables complete (store_set reads the twiddles)
-    store_set(0);
+    store_set(0, 0);
     XSQ_D4S(1);
     __syncthreads();
     int cur = 0;
+    const int a_rd = (2 * rp * D4H_ROWS + 16 * rh + l16) * D4_LD + 4 * kq, b_rd = l16 * D4_LD + 4 * kq;
     auto k_step = [&]() {
-        const float* As = As0 + cur * ABUF + (2 * rp * D4H_ROWS + 16 * rh + l16) * D4_LD + 4 * kq;
-        const float* Bs = Bs0 + cur * BBUF + l16 * D4_LD + 4 * kq;
+        const float* As = As0 + cur * ABUF + a_rd;
+        const float* Bs = Bs0 + cur * BBUF + b_rd;
         const float4 a0 = *reinterpret_cast<const float4*>(As);
         const float4 a1 = *reinterpret_cast<const float4*>(As + D4H_ROWS * D4_LD);
+        float4 bf[2];                             // fragment of block cb in bf[cb & 1]; the next block's is read under this block's MFMAs
+        bf[0] = *reinterpret_cast<const float4*>(Bs);
 #pragma unroll
         for (int cb = 0; cb < D4H_NCB; ++cb) {
             if (cb >= ncb) continue;              // (not break: the compiler refuses to unroll the multi-exit loop and moves acc to scratch)
-            const float4 b = *reinterpret_cast<const float4*>(Bs + 16 * cb * D4_LD);
+            if (cb + 1 < D4H_NCB && cb + 1 < ncb) bf[(cb + 1) & 1] = *reinterpret_cast<const float4*>(Bs + 16 * (cb + 1) * D4_LD);
+            const float4 b = bf[cb & 1];
+#if XSQ_D4_ABL & 1
+            asm volatile("" :: "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(a0.x), "v"(a0.w), "v"(a1.x), "v"(a1.w));
+            continue;
+#endif
             acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[0][cb], 0, 0, 0);
             acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[1][cb], 0, 0, 0);
             acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[0][cb], 0, 0, 0);
@@ -264,9 +321,9 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     };
     int k0 = 0;
     for (; k0 + 16 < K; k0 += 16) {
-        load_set(k0 + 16);
+        if (!(XSQ_D4_ABL & 2)) load_set(k0 + 16);
         k_step();
-        store_set(cur ^ 1);
+        store_set(cur ^ 1, k0 + 16);
         __syncthreads();
         cur ^= 1;
     }
@@ -278,58 +335,72 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
 
     // ---- epilogue.  Register rr of acc[e][cb]: row 16 rh + 4 kq + rr, column l16 = (k' = l16 >> 1, Re / Im) of residue
     // 2 rp + e, i.e. output q = 4 (8 cb + k') + 2 rp + e.  The even lane (Re) finishes rows rr = 0, 1, the odd lane (Im)
-    // rows rr = 2, 3: each sends the partner what it holds of the partner's rows and receives the missing half.
-    auto swap1 = [](float v) {                   // value of lane l ^ 1 (DPP quad_perm [1, 0, 3, 2])
+    // rows rr = 2, 3: each takes from its partner (DPP quad_perm [1, 0, 3, 2], folded into the select) the other half of
+    // its rows.  One 16-byte buffer store per row and block; the block's displacement (32 q = 256 bytes) is the scalar
+    // offset, so a lane's offsets are formed once: row offset + position, switched out of range for rows past M and for
+    // columns past the band.
+    auto swap1 = [](float v) {                   // value of lane l ^ 1
         return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     };
-    const int part = lane & 1;
-    float* rowp[2];
-    bool rok[2];
+    const bool part = lane & 1;
+    const bool rowmajor = !FWD && a.row_len;     // phase-ordered rows of row_len complex (slice_fft.h) instead of the arena
+    // (one descriptor from scalar selects: two descriptors joined by a branch became a per-lane value and every store a
+    // readfirstlane loop)
+    const float* const dbase = rowmajor ? a.dst + 2 * ((int64_t)t.m0 * a.row_len + bd.ent) : a.dst + 2 * (BCS * bd.cum);
+    const unsigned dbytes = rowmajor ? 8u * (unsigned)(D4H_ROWS * a.row_len) : 8u * a.BC * blk;
+    const __amdgpu_buffer_rsrc_t rd = d4_rsrc(dbase, dbytes);
+    const __amdgpu_buffer_rsrc_t rxin = d4_rsrc(FWD && a.xin ? a.xin + BCS * bd.cum : a.dst, FWD && a.xin ? 4u * a.BC * blk : 0u);
+    unsigned vrow[2];                            // byte offset of (row, q = 0) inside rd
+    {
+        const int r0 = 16 * rh + 4 * kq + 2 * (int)part;
 #pragma unroll
-    for (int sx = 0; sx < 2; ++sx) {
-        const int mrow = t.m0 + 16 * rh + 4 * kq + 2 * part + sx;
-        rok[sx] = mrow < M;
-        const int mr = rok[sx] ? mrow : 0;
-        if (!FWD && a.row_len) {
-            rowp[sx] = a.dst + 2 * ((int64_t)mr * a.row_len + bd.ent);
-        } else {
-            const int rb = mr / a.S, rs = mr - rb * a.S;
-            rowp[sx] = a.dst + 2 * (BCS * bd.cum + (((int64_t)rb * bd.F + bd.f) * a.S + rs) * Lg);
+        for (int sx = 0; sx < 2; ++sx) {
+            const int mr = t.m0 + r0 + sx, mc = mr < M ? mr : 0;
+            unsigned o = 8u * (unsigned)((r0 + sx) * a.row_len);
+            if (!rowmajor) {
+                const int rb_ = mc / a.S, rs = mc - rb_ * a.S;
+                o = 8u * (unsigned)(((rb_ * bd.F + bd.f) * a.S + rs) * Lg);
+            }
+            vrow[sx] = mr < M ? o : D4_OOB;
         }
     }
-    float* const xin = FWD ? a.xin : nullptr;
     const bool split = a.split;
+    // q of this lane in block 0 and the byte offset of its position; block cb adds 32 q (the position wraps at Lg once)
+    const int q0 = 4 * (l16 >> 1) + 2 * rp;
+    unsigned p8 = 8u * (unsigned)q0;
+    if (!FWD) { p8 += 16u * (unsigned)m_; if (p8 >= 8u * (unsigned)Lg) p8 -= 8u * (unsigned)Lg; }    // spectrum position p = (q + Lg/2) mod Lg
 #pragma unroll
     for (int cb = 0; cb < D4H_NCB; ++cb) {
         if (cb >= ncb) continue;
-        const int k = 8 * cb + (l16 >> 1);
-        const int q = 4 * k + 2 * rp;
-        const bool on = k < m_;
-        int pos = q;
         float w0 = 1.f, w1 = 1.f;
         if (!FWD) {
-            const float2 w = *reinterpret_cast<const float2*>(&winl[on ? q : 0]);
+            const float2 w = *reinterpret_cast<const float2*>(&winl[q0 + 32 * cb]);      // (table is zero past Lg)
             w0 = w.x; w1 = w.y;
-            pos = q + 2 * m_;                    // spectrum position p = (q + Lg/2) mod Lg
-            if (pos >= Lg) pos -= Lg;
         }
+        unsigned qoff = p8;
+        if (cb + 1 == ncb) qoff = q0 + 32 * cb < Lg ? p8 : D4_OOB_COL;       // columns past the band: only in its last block
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
-            // even lane: keeps Re of row sx, sends Re of row 2 + sx;  odd lane: keeps Im of row 2 + sx, sends Im of row sx
-            const float g0 = swap1(part ? acc[0][cb][sx] : acc[0][cb][2 + sx]);
-            const float g1 = swap1(part ? acc[1][cb][sx] : acc[1][cb][2 + sx]);
-            float4 v = part ? make_float4(g0, acc[0][cb][2 + sx], g1, acc[1][cb][2 + sx])
-                            : make_float4(acc[0][cb][sx], g0, acc[1][cb][sx], g1);
+            // even lane: keeps Re of row sx, takes Im of row sx;  odd lane: keeps Im of row 2 + sx, takes Re of row 2 + sx
+            // (both exchanges run on every lane -- a DPP move under a lane condition becomes a branch -- and are selected)
+            const float x0 = swap1(acc[0][cb][2 + sx]), y0 = swap1(acc[0][cb][sx]);
+            const float x1 = swap1(acc[1][cb][2 + sx]), y1 = swap1(acc[1][cb][sx]);
+            float4 v;
+            v.x = part ? x0 : acc[0][cb][sx];
+            v.y = part ? acc[0][cb][2 + sx] : y0;
+            v.z = part ? x1 : acc[1][cb][sx];
+            v.w = part ? acc[1][cb][2 + sx] : y1;
             v.x *= w0; v.y *= w0; v.z *= w1; v.w *= w1;
-            if (!on || !rok[sx]) continue;
-            float* const d = rowp[sx] + 2 * pos;
-            *reinterpret_cast<float4*>(d) = v;
-            if (FWD && xin) {
+            const unsigned vo = vrow[sx] + qoff;         // either switch alone or both together stay past every range
+            if (!(XSQ_D4_ABL & 4)) d4_st4(v, rd, vo, 0);
+            if (FWD && a.xin) {
                 float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
                 if (split) bf3_words2(o.x, o.y, o.x, o.y);
-                *reinterpret_cast<float2*>(xin + ((d - a.dst) >> 1)) = o;
+                d4_st2(o, rxin, (vo >> 1) | (vo & D4_OOB), 0);
             }
         }
+        const unsigned pn = p8 + 256u, pw = pn - 8u * (unsigned)Lg;         // (wraps to a huge value while pn < 8 Lg)
+        p8 = FWD ? pn : (pn < pw ? pn : pw);
     }
     XSQ_D4S(3);
 }

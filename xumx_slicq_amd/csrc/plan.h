@@ -41,6 +41,7 @@ struct xsq_plan {
     float* d_pool4i = nullptr;      //                                     synthesis direction
     int nbands4 = 0;
     std::vector<unsigned char> bands4_host;    // host copy of the Band4Dev table (the tile entries carry their band's descriptor)
+    int64_t d4_max_block = 0;                  // largest F * Lg of a radix-4 band's arena block (buffer ranges of band_dft4.h)
     std::vector<int> bands4_m, bands4_small;   // host copies: m of each eligible band; indices of the other bands
     int fft_backend = 0;            // 0: hand-written LDS FFT when L == 18060, else rocFFT; 1: always rocFFT
     float2* d_T = nullptr;          // twiddles of the hand-written slice FFT: w1 (43*210) | w2 (14*15) | wl (L/2+1)

@@ -314,17 +314,31 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
 template <bool FWD>
 static int launch_dft4(xsq_plan* P, const Band4Args& a4, int rows, int share, hipStream_t stream) {
     static const bool split = getenv("XSQ_D4_SPLIT") && atoi(getenv("XSQ_D4_SPLIT")) == 1;
+    // the kernel reaches operands and results through buffer descriptors per band block / tile with 32-bit byte offsets
+    // and switches lanes off with offsets of 2^30 and 2^31 (band_dft4.h): every such range stays below 2^30 bytes
+    XSQ_REQUIRE((int64_t)8 * rows * P->d4_max_block < (1ll << 30) && (int64_t)8 * D4H_ROWS * std::max<int64_t>(P->nbins, a4.row_len) < (1ll << 30),
+                "band transform: %d rows x %lld coefficients of a band block exceed 2^30 bytes; split the call (fewer stacked chunks)",
+                rows, (long long)P->d4_max_block);
+    const bool masked = !FWD && a4.mask != nullptr;
     TileTable t;
     int rc;
+    auto launch = [&](auto ncbmax) {
+        constexpr int N = decltype(ncbmax)::value;
+        if (!t.ntiles) return;
+        if constexpr (!FWD) {
+            if (masked) { hipLaunchKernelGGL((band_dft4_full_kernel<false, N, true>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles); return; }
+        }
+        hipLaunchKernelGGL((band_dft4_full_kernel<FWD, N, false>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+    };
     if (!split) {
         if ((rc = get_dft4_full_tiles(P, rows, &t, share, 0))) return rc;
-        if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 10>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+        launch(std::integral_constant<int, 10>{});
         return XSQ_OK;
     }
     if ((rc = get_dft4_full_tiles(P, rows, &t, share, 1))) return rc;
-    if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 10>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+    launch(std::integral_constant<int, 10>{});
     if ((rc = get_dft4_full_tiles(P, rows, &t, share, 2))) return rc;
-    if (t.ntiles) hipLaunchKernelGGL((band_dft4_full_kernel<FWD, 5>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+    launch(std::integral_constant<int, 5>{});
     return XSQ_OK;
 }
 
@@ -633,6 +647,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
             }
             b4.push_back(d);
             P->bands4_m.push_back(m);
+            P->d4_max_block = std::max<int64_t>(P->d4_max_block, (int64_t)b.F * b.Lg);
         }
         P->nbands4 = (int)b4.size();
         P->bands4_host.assign(reinterpret_cast<const unsigned char*>(b4.data()),
