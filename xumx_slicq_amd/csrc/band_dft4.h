@@ -103,30 +103,6 @@ constexpr int D4H_ROWS = 32;
 // BUFFER descriptor: the per-thread offset is formed once per tile, the K-step / quarter / column-block displacement is a
 // scalar offset, rows past the end and columns past the band are switched off by an out-of-range offset (loads return 0,
 // stores are dropped) instead of clamps and predicates.
-typedef unsigned d4_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned d4_u32x2 __attribute__((ext_vector_type(2)));
-// every range below is < 2^30 bytes (checked where the launch is built): a row switch, a column switch or both added to
-// an in-range offset stay out of range without wrapping
-constexpr unsigned D4_OOB = 0x80000000u, D4_OOB_COL = 0x40000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t d4_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float2 d4_ld2(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
-    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)vo, so, 0));
-}
-__device__ __forceinline__ float d4_ld1(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)vo, so, 0));
-}
-__device__ __forceinline__ float4 d4_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
-}
-__device__ __forceinline__ void d4_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(d4_u32x4, v), r, (int)vo, so, 0);
-}
-__device__ __forceinline__ void d4_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(d4_u32x2, v), r, (int)vo, so, 0);
-}
-
 // NCBMAX = most 16-column blocks a band of this instantiation has.  10 (Lg <= 320): 49 KB of LDS and 80 accumulator
 // registers, three workgroups per CU -- the product configuration.  5 (Lg <= 160): 35 KB and 40 accumulator registers
 // -> FOUR workgroups per CU, an A/B arm (XSQ_D4_SPLIT=1) that measured no faster.
@@ -163,25 +139,25 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     // FWD: a band whose window leaves [0, L/2] reads Hermitian reflections (the lowest and the highest bands): pointer path
     const bool reflect = FWD && (bd.bin0 < 0 || bd.bin0 + Lg - 1 > a.L / 2);
     // operand descriptors and this thread's offsets inside them (bytes)
-    __amdgpu_buffer_rsrc_t rx, rm = d4_rsrc(a.src, 0);
-    unsigned vx, vm = D4_OOB;
+    __amdgpu_buffer_rsrc_t rx, rm = buf_rsrc(a.src, 0);
+    unsigned vx, vm = BUF_OOB;
     const unsigned blk = (unsigned)(bd.F * Lg) * (unsigned)a.S;          // elements of one channel in the band's block
     if (FWD) {                                   // spectrum rows of this tile: x[q] sits at bin bin0 + (q + Lg/2) mod Lg
-        rx = d4_rsrc(a.src + 2 * ((int64_t)t.m0 * a.nbins), 8u * D4H_ROWS * a.nbins);
-        vx = row_ok ? 8u * (unsigned)(s_row * a.nbins + bd.bin0 + s_t) : D4_OOB;
+        rx = buf_rsrc(a.src + 2 * ((int64_t)t.m0 * a.nbins), 8u * D4H_ROWS * a.nbins);
+        vx = row_ok ? 8u * (unsigned)(s_row * a.nbins + bd.bin0 + s_t) : BUF_OOB;
     } else if (!masked) {
-        rx = d4_rsrc(a.src + 2 * (BCS * bd.cum), 8u * a.BC * blk);
-        vx = row_ok ? 8u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
+        rx = buf_rsrc(a.src + 2 * (BCS * bd.cum), 8u * a.BC * blk);
+        vx = row_ok ? 8u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : BUF_OOB;
     } else {
-        rx = d4_rsrc(a.src + 2 * ((int64_t)a.BCx * a.S * bd.cum), 8u * a.BCx * blk);
-        rm = d4_rsrc(a.mask + BCS * bd.cum, 4u * a.BC * blk);
-        vx = row_ok ? 8u * (unsigned)((((bc % a.BCx) * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
-        vm = row_ok ? 4u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : D4_OOB;
+        rx = buf_rsrc(a.src + 2 * ((int64_t)a.BCx * a.S * bd.cum), 8u * a.BCx * blk);
+        rm = buf_rsrc(a.mask + BCS * bd.cum, 4u * a.BC * blk);
+        vx = row_ok ? 8u * (unsigned)((((bc % a.BCx) * bd.F + bd.f) * a.S + sl) * Lg + s_t) : BUF_OOB;
+        vm = row_ok ? 4u * (unsigned)(((bc * bd.F + bd.f) * a.S + sl) * Lg + s_t) : BUF_OOB;
     }
     const float* const xrow = a.src + (int64_t)rowc * 2 * a.nbins;       // FWD, reflecting bands only
     // DFT matrix slab of a K-step: 16 ncb rows (n) x 16 floats = 64 ncb float4, item i = tid + 256 u: n = i >> 2, k quad i & 3.
     // The pool holds round_up(2m, 64) rows (zero past 2m), so every item of a requested group lies inside it.
-    const __amdgpu_buffer_rsrc_t rb = d4_rsrc(a.pool + bd.d_off, 4u * (unsigned)(((K + 63) & ~63) * bd.ldd));
+    const __amdgpu_buffer_rsrc_t rb = buf_rsrc(a.pool + bd.d_off, 4u * (unsigned)(((K + 63) & ~63) * bd.ldd));
     const unsigned vb = 4u * (unsigned)((tid >> 2) * bd.ldd + 4 * (tid & 3));
     const int sb64 = 4 * 64 * bd.ldd;            // 64 rows further down
     const int nb4 = 64 * ncb;
@@ -197,16 +173,16 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     auto load_set = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NBU; ++u)       // uniform test
-            if (256 * u < nb4) gb[u] = d4_ld4(rb, vb, u * sb64 + 4 * k0);
+            if (256 * u < nb4) gb[u] = buf_ld4(rb, vb, u * sb64 + 4 * k0);
         if (!FWD) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                raw[q4] = d4_ld2(rx, vx, 4 * k0 + 8 * q4 * m_);
-                if (masked) aux[q4] = d4_ld1(rm, vm, 2 * k0 + 4 * q4 * m_);
+                raw[q4] = buf_ld2(rx, vx, 4 * k0 + 8 * q4 * m_);
+                if (masked) aux[q4] = buf_ld1(rm, vm, 2 * k0 + 4 * q4 * m_);
             }
         } else if (!reflect) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) raw[q4] = d4_ld2(rx, vx, 4 * k0 + 8 * ((q4 + 2) & 3) * m_);
+            for (int q4 = 0; q4 < 4; ++q4) raw[q4] = buf_ld2(rx, vx, 4 * k0 + 8 * ((q4 + 2) & 3) * m_);
         } else {
             const int t1 = (k0 >> 1) + s_t, tc = t1 < m_ ? t1 : m_ - 1;
 #pragma unroll
@@ -348,8 +324,8 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     // readfirstlane loop)
     const float* const dbase = rowmajor ? a.dst + 2 * ((int64_t)t.m0 * a.row_len + bd.ent) : a.dst + 2 * (BCS * bd.cum);
     const unsigned dbytes = rowmajor ? 8u * (unsigned)(D4H_ROWS * a.row_len) : 8u * a.BC * blk;
-    const __amdgpu_buffer_rsrc_t rd = d4_rsrc(dbase, dbytes);
-    const __amdgpu_buffer_rsrc_t rxin = d4_rsrc(FWD && a.xin ? a.xin + BCS * bd.cum : a.dst, FWD && a.xin ? 4u * a.BC * blk : 0u);
+    const __amdgpu_buffer_rsrc_t rd = buf_rsrc(dbase, dbytes);
+    const __amdgpu_buffer_rsrc_t rxin = buf_rsrc(FWD && a.xin ? a.xin + BCS * bd.cum : a.dst, FWD && a.xin ? 4u * a.BC * blk : 0u);
     unsigned vrow[2];                            // byte offset of (row, q = 0) inside rd
     {
         const int r0 = 16 * rh + 4 * kq + 2 * (int)part;
@@ -361,7 +337,7 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
                 const int rb_ = mc / a.S, rs = mc - rb_ * a.S;
                 o = 8u * (unsigned)(((rb_ * bd.F + bd.f) * a.S + rs) * Lg);
             }
-            vrow[sx] = mr < M ? o : D4_OOB;
+            vrow[sx] = mr < M ? o : BUF_OOB;
         }
     }
     const bool split = a.split;
@@ -378,7 +354,7 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
             w0 = w.x; w1 = w.y;
         }
         unsigned qoff = p8;
-        if (cb + 1 == ncb) qoff = q0 + 32 * cb < Lg ? p8 : D4_OOB_COL;       // columns past the band: only in its last block
+        if (cb + 1 == ncb) qoff = q0 + 32 * cb < Lg ? p8 : BUF_OOB_COL;       // columns past the band: only in its last block
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
             // even lane: keeps Re of row sx, takes Im of row sx;  odd lane: keeps Im of row 2 + sx, takes Re of row 2 + sx
@@ -392,11 +368,11 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
             v.w = part ? acc[1][cb][2 + sx] : y1;
             v.x *= w0; v.y *= w0; v.z *= w1; v.w *= w1;
             const unsigned vo = vrow[sx] + qoff;         // either switch alone or both together stay past every range
-            if (!(XSQ_D4_ABL & 4)) d4_st4(v, rd, vo, 0);
+            if (!(XSQ_D4_ABL & 4)) buf_st4(v, rd, vo, 0);
             if (FWD && a.xin) {
                 float2 o = make_float2(whiten_mag(v.x, v.y, w_mu, w_sc), whiten_mag(v.z, v.w, w_mu, w_sc));
                 if (split) bf3_words2(o.x, o.y, o.x, o.y);
-                d4_st2(o, rxin, (vo >> 1) | (vo & D4_OOB), 0);
+                buf_st2(o, rxin, (vo >> 1) | (vo & (BUF_OOB | BUF_OOB_COL)), 0);
             }
         }
         const unsigned pn = p8 + 256u, pw = pn - 8u * (unsigned)Lg;         // (wraps to a huge value while pn < 8 Lg)

@@ -91,6 +91,7 @@ struct CdaeGroup {
 struct RowFT {
     const float* p;   // row base pointer (may be out of range for transposed convs; checked per load)
     int f, t;         // row's frequency / time coordinate
+    unsigned vo;      // layers 1 and 4: byte offset of the row base inside the group's input (buffer loads), BUF_OOB past M
 };
 
 __device__ inline void split_row(int m, int Fo, int To, int& b, int& f, int& t) {
@@ -195,13 +196,14 @@ struct CdaeL1Op {
         return g;
     }
     __device__ RowA row_a(const Group& g, int m) const {
-        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0; r.vo = BUF_OOB;
         if (m >= g.M) return r;
         int b, f, t;
         split_row(m, g.Fo, g.To, b, f, t);
         r.f = f;
         r.t = t * g.hop - ((a.causal && !a.xin8) ? g.T - 1 : 0);   // first input sample of the window
         r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
+        r.vo = 4u * (unsigned)((b * 2 * g.F + f) * g.Ti + r.t);    // (non-causal: r.t >= 0; the group's input is < 2^30 bytes, launch check)
         return r;
     }
     // k = (ci*kf + df)*T + dt.  The cursor keeps dt, df and the element offset (ci*F + df)*Ti of the segment; a step of
@@ -229,14 +231,15 @@ struct CdaeL1Op {
         return load_at(g, r, k, (ci * g.F + df) * g.Ti, dt);
     }
     __device__ float4 load_at(const Group& g, const RowA& r, int k, int off, int dt) const {
+        if (!a.causal) {
+            // one 16-byte buffer load (dword aligned is enough): row offset + cursor, rows past M and k past K switched
+            // out of range -- no pointer sums, zero fills or exec-masked branches in the K loop
+            const unsigned vo = r.vo + 4u * (unsigned)(off + dt);
+            return buf_ld4(buf_rsrc(g.in, 0x40000000u), k < g.K ? vo : BUF_OOB, 0);
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r.p == nullptr || k >= g.K) return v;
         const float* p = r.p + (off + dt);
-        if (!a.causal) {                                       // 8-byte aligned: hop even, dt % 4 == 0
-            const float2 lo = *reinterpret_cast<const float2*>(p);
-            const float2 hi = *reinterpret_cast<const float2*>(p + 2);
-            return make_float4(lo.x, lo.y, hi.x, hi.y);
-        }
         const int t0 = r.t + dt;     // causal: zero left padding of W-1 samples (forward) / cropped right edge (xin8)
         if (t0 >= 0 && t0 < g.Ti) v.x = p[0];
         if (t0 + 1 >= 0 && t0 + 1 < g.Ti) v.y = p[1];
@@ -357,12 +360,13 @@ struct CdaeL4Op {
         return g;
     }
     __device__ RowA row_a(const Group& g, int m) const {
-        RowA r; r.p = nullptr; r.f = 0; r.t = 0;
+        RowA r; r.p = nullptr; r.f = 0; r.t = 0; r.vo = BUF_OOB;
         if (m >= g.M) return r;
         int b, f, t;
         split_row(m, g.Fo, g.To, b, f, t);
         r.f = f; r.t = t;
         r.p = g.in + (((int64_t)b * g.Fi + f) * g.Ti + t) * CS;
+        r.vo = 4u * (unsigned)(((b * g.Fi + f) * g.Ti + t) * CS);  // (f, t may lie past the input: such loads are switched off below)
         return r;
     }
     // k = (df*2 + (1 - tap))*52 + c3: the TWO taps of a row, stored tap 1 first, are ONE contiguous run of 104 floats --
@@ -387,8 +391,11 @@ struct CdaeL4Op {
     __device__ float4 load_at(const Group& g, const RowA& r, int k, int df, int kk) const {
         const int fi = r.f - df;
         const bool pos_ok = kk < CS ? r.t >= 1 : r.t < g.Ti;           // tap 1 reads position u - 1, tap 0 position u
-        if (r.p == nullptr || k >= g.K || fi < 0 || fi >= g.Fi || !pos_ok) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(r.p - ((int64_t)df * g.Ti + 1) * CS + kk);
+        const bool ok = k < g.K && (unsigned)fi < (unsigned)g.Fi && pos_ok;
+        // buffer load: a row past M keeps its switch through the backward displacement (common.h); everything else that
+        // must read as zero is switched off here -- no zero fill, no exec-masked branch, no 64-bit address
+        const unsigned vo = r.vo + 4u * (unsigned)(kk - (df * g.Ti + 1) * CS);
+        return buf_ld4(buf_rsrc(g.in, 0x40000000u), ok ? vo : BUF_OOB, 0);
     }
     // mask = sigmoid(acc + bias[c]);  Y[target] = mask * X.  Column n = c*hop + dt with n < 2*hop, so
     // c is a compare.
@@ -846,6 +853,12 @@ int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const
 
 int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name) {
     TileTable tt;
+    // layers 1 and 4 read their operand rows through buffer descriptors with 32-bit byte offsets and out-of-range switches
+    // (common.h): a block's input -- its whitened magnitudes, its layer-3 activations of one target -- stays below 2^30 bytes
+    if (layer == 1 || layer == 4)
+        for (const CdaeBlockDev& d : Mo->blocks)
+            XSQ_REQUIRE((layer == 1 ? (int64_t)4 * 2 * a.Bn * d.F * a.S * d.T : (int64_t)4 * CS * a.Bn * a.T1 * d.F1) < ((int64_t)1 << 30),
+                        "xsq_cdae_forward: B=%d S=%d: a block's layer-%d input exceeds 2^30 bytes; split the batch", a.Bn, a.S, layer);
     if (layer == 4 && !a.gx8)
         for (const CdaeBlockDev& d : Mo->blocks)
             XSQ_REQUIRE((int64_t)2 * a.Bn * d.F * a.S * d.T < ((int64_t)1 << 31),

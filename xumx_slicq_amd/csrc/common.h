@@ -48,6 +48,34 @@ __device__ __forceinline__ float whiten_mag(float re, float im, float mu, float 
     return (sqrtf(fmaf(re, re, im * im)) + mu) * sc;
 }
 
+// ---- buffer addressing (gfx950).  A load or store through a buffer descriptor takes a 32-bit per-lane byte offset and a
+// scalar offset; past the descriptor's range a load returns 0 and a store is dropped.  The fp32 MFMA kernels use it to
+// keep address arithmetic, clamps, zero fills and predicates out of their K loops: on this part those vector instructions
+// are not hidden behind the MFMAs of the SIMD's other waves (band_dft4.h, "Vector issue").  Every range is kept below 2^30
+// bytes where the launch is built: BUF_OOB (a row switched off) still lies past it after a backward displacement of up to
+// 2^30, BUF_OOB_COL (a column switched off) after being added to an in-range offset, and so does their sum.
+typedef unsigned buf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned buf_u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0x80000000u, BUF_OOB_COL = 0x40000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
+}
+__device__ __forceinline__ void buf_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u32x2, v), r, (int)vo, so, 0);
+}
+__device__ __forceinline__ void buf_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_u32x4, v), r, (int)vo, so, 0);
+}
+
 struct TileDev;
 // tiles of one group: 128-row x 64-column tiles, plus a 32-column tile when the N tail is <= 32
 template <class Vec>

@@ -122,7 +122,10 @@ __device__ __forceinline__ void gemm_tile_body(const Op& op, const TileDev t, fl
     typename Op::RowA ra[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) ra[i] = op.row_a(g, t.m0 + s_row + 64 * i);
-    const float* bp = g.B + (int64_t)(t.n0 + s_row) * g.ldb + s_kq;   // Bt[n][k]
+    // Bt[n][k] through a buffer descriptor: per-thread byte offset once, the K-step as the scalar offset (no vector
+    // address arithmetic inside the K loop; the matrix is padded to whole tiles, so no range is needed)
+    const __amdgpu_buffer_rsrc_t rB = buf_rsrc(g.B, 0x7FFFFFFFu);
+    const unsigned bvo = 4u * (unsigned)((t.n0 + s_row) * g.ldb + s_kq);
     const bool b_on = wide || s_row < (XW == 2 ? (kind == 1 ? 32 : kind == 3 ? 48 : 16) : 32);
 
     // Global loads run TWO K-steps ahead of the MFMAs (two register sets, loop unrolled by two so
@@ -145,7 +148,7 @@ __device__ __forceinline__ void gemm_tile_body(const Op& op, const TileDev t, fl
                     else ga[set][i] = op.load_a4(g, ra[i], k + s_kq);
                     if constexpr (aux_of<Op>::on) gx[set][i] = op.load_aux(g, ra[i], k + s_kq);
                 }
-            if (b_on && (!(XSQ_ABLATE & 4) || k == 0)) gb[set] = *reinterpret_cast<const float4*>(bp + k);
+            if (b_on && (!(XSQ_ABLATE & 4) || k == 0)) gb[set] = buf_ld4(rB, bvo, 4 * k);
             if constexpr (cursor_of<Op>::on) op.advance(g, kc);
         }
     };
