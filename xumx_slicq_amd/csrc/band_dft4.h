@@ -4,7 +4,7 @@
 //   X[4k + r] = sum_{t1 < m}  y_r[t1] * exp(-+2 pi i k t1 / m),
 //   y_r[t1]   = w^(r t1) * sum_{a < 4} x[t1 + a m] * (-+i)^(r a)          (r = 0..3)
 // i.e. four length-m DFTs that share ONE m x m matrix: 4x fewer MFMA flops than the dense Lg x Lg
-// product of the generic engine (gemm_tile.h), which keeps the bands with Lg < 48 (3 % of the flops).
+// product of the generic engine (gemm_tile.h), which keeps the bands with Lg < 24.
 // The four quarters x[t1 + a m] are contiguous in memory, so the butterflies cost 8 independent 8-byte
 // loads per lane and K-step and happen in registers on the way into LDS.
 //

@@ -35,7 +35,7 @@ struct xsq_plan {
     std::vector<xsq::BandDev> bands;
     std::vector<xsq::BlockHost> blocks;
     // device tables
-    int band_radix4 = 1;            // 1: bands with Lg >= 48 (XSQ_D4_MIN_LG_DEFAULT) run on the radix-4 kernel (band_dft4.h), 0: all on the dense GEMM
+    int band_radix4 = 1;            // 1: bands with Lg >= 24 (XSQ_D4_MIN_LG_DEFAULT) run on the radix-4 kernel (band_dft4.h), 0: all on the dense GEMM
     void* d_bands4 = nullptr;       // Band4Dev table of the eligible bands
     float* d_pool4f = nullptr;      // DFT_m matrices, twiddles, windows: analysis direction
     float* d_pool4i = nullptr;      //                                     synthesis direction

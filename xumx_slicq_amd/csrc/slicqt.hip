@@ -396,9 +396,10 @@ static int run_fft(const FftPlan& f, void* in, void* out, void* work, hipStream_
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 // Bands at least this long take the radix-4 kernel, shorter ones the dense engine.  Measured with the full-width kernel
-// (r03o, sum of the four band kernels): 64 -> 1.53 ms, 48 -> 1.485, 32 -> 1.49, 16 -> 1.53.
+// (r03o, sum of the four band kernels): 64 -> 1.53 ms, 48 -> 1.485, 32 -> 1.49, 16 -> 1.53; again with the buffer-addressed
+// kernel (r4f, four full chunks): 48 -> 1.285 ms, 40 -> 1.272, 32 -> 1.280, 24 -> 1.252, 16 -> 1.304.
 #ifndef XSQ_D4_MIN_LG_DEFAULT
-#define XSQ_D4_MIN_LG_DEFAULT 48
+#define XSQ_D4_MIN_LG_DEFAULT 24
 #endif
 #ifndef XSQ_FFT_NT_FWD
 #define XSQ_FFT_NT_FWD 512
