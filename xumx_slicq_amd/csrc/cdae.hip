@@ -879,7 +879,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         // slab kernels: the tile's distinct input positions held once in LDS (cdae_slab.h); they address a (block, target)'s
         // input through 32-bit float offsets
         for (const CdaeBlockDev& d : Mo->blocks)
-            XSQ_REQUIRE((int64_t)CS * a.Bn * a.T1 * d.F1 < ((int64_t)1 << 31), "xsq_cdae_forward: B=%d S=%d overflows the 32-bit "
+            XSQ_REQUIRE((int64_t)4 * CS * a.Bn * a.T1 * d.F1 < ((int64_t)1 << 30), "xsq_cdae_forward: B=%d S=%d overflows the 32-bit "
                         "offsets of a block's activations; split the batch", a.Bn, a.S);
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;

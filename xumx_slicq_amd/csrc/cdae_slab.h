@@ -162,23 +162,31 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     bool stamp_loads = true;
 #endif
 
-    auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
+    // What of a load does not depend on the frequency tap df is formed ONCE per tile: the segment of its slab position
+    // (one-hot, 4 bits per load), whether the position exists inside the segment, and its byte offset in the (block,
+    // target)'s input at df = 0 -- or BUF_OOB.  A tap then costs a load five vector instructions (segment bit against the
+    // tap's mask of existing input rows, select, displacement) instead of ~30 (segment search, four selects per segment
+    // bound, range test, zero fill under an exec mask, address): 210 of the ~520 non-MFMA vector instructions of a tap,
+    // which on this part are not hidden behind the MFMAs (band_dft4.h, "Vector issue").  Buffer loads return the zeros.
+    static_assert(SLAB_MAXSEG <= 4, "one-hot segment code: four bits per load");
+    const __amdgpu_buffer_rsrc_t rin = buf_rsrc(in, 0x40000000u);      // (a (block, target)'s input is < 2^30 bytes: cdae_launch_layer)
+    unsigned s_vo[NLD], s_seg = 0;
+    {
         int A[SLAB_MAXSEG], G[SLAB_MAXSEG], lo[SLAB_MAXSEG], hi[SLAB_MAXSEG];      // uniform (scalar registers)
 #pragma unroll
         for (int i = 0; i < SLAB_MAXSEG; ++i) {
             const int st = seg_start(i);
             const int rows_i = (i + 1 < SLAB_MAXSEG ? seg_start(i + 1) : nrows) - st;      // output rows of the segment
             const int f = f0 + i, ts = i ? 0 : t0;
-            const int fi = TRANSPOSED ? f - df : f + df;
             const int first = ts - (TRANSPOSED ? 3 : 0);                                    // input position of j = 0
-            const bool ok = !(XSQ_SLAB_ABL & 8) && f < Fo && fi >= 0 && fi < Fi && rows_i > 0;
+            const bool ok = !(XSQ_SLAB_ABL & 8) && f < Fo && rows_i > 0;
             A[i] = st + 3 * i;
-            G[i] = ((b * Fi + fi) * Ti + first) * CS;
+            G[i] = ((b * Fi + f) * Ti + first) * CS;                                        // input row f (df = 0)
             lo[i] = ok ? (first < 0 ? -first : 0) : 1;                                      // j with 0 <= first + j < Ti and j < rows_i + 3
             hi[i] = ok ? min(rows_i + 3, Ti - first) : 0;
         }
 #pragma unroll
-        for (int q = q0; q < q1; ++q) {
+        for (int q = 0; q < NLD; ++q) {
             const int pos = s_p0 + SLAB_PL * q;
             int i = 0;
 #pragma unroll
@@ -188,11 +196,22 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
             for (int sI = 1; sI < SLAB_MAXSEG; ++sI)
                 if (i == sI) { Ai = A[sI]; Gi = G[sI]; li = lo[sI]; hI = hi[sI]; }
             const int j = pos - Ai;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            // 32-bit offset from the uniform base: < 2^31 floats per (block, target) (cdae_launch_layer checks); a 64-bit
-            // lane pointer here was spilled across the slot loop
-            if (s_on && j >= li && j < hI) v = *reinterpret_cast<const float4*>(in + (unsigned)(Gi + j * CS + 4 * s_c4));
-            sa[q] = v;
+            s_vo[q] = (s_on && j >= li && j < hI) ? 4u * (unsigned)(Gi + j * CS + 4 * s_c4) : BUF_OOB;
+            s_seg |= 1u << (4 * q + i);
+        }
+    }
+    auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
+        unsigned okm = 0;                         // segments whose input row f -+ df exists (uniform)
+#pragma unroll
+        for (int i = 0; i < SLAB_MAXSEG; ++i) {
+            const int fi = TRANSPOSED ? f0 + i - df : f0 + i + df;
+            okm |= (fi >= 0 && fi < Fi) ? 1u << i : 0u;
+        }
+        const unsigned delta = 4u * (unsigned)((TRANSPOSED ? -df : df) * Ti * CS);      // (a switched-off offset stays past the range: |delta| << 2^30)
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+            const bool on = ((s_seg >> (4 * q)) & okm) != 0;
+            sa[q] = buf_ld4(rin, on ? s_vo[q] + delta : BUF_OOB, 0);
 #if XSQ_SLAB_STAMP
             if (stamp_loads && (q == 0 || q == 3)) { XSQ_SS2(q == 0 ? 0 : 3); }      // (reuses two prologue-detail slots: request 0 / request 3 issued)
 #endif
