@@ -82,9 +82,9 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
         # rocFFT fallback path (other plans)
         add("slice_window", "hbm", 2 * B * n * 4 + r2 * L * 4)
         add("rfft_L", "hbm", r2 * L * 4 + r2 * nbins * 8)
-        # per-band DFTs: bands with Lg >= 48 (XSQ_D4_MIN_LG_DEFAULT, csrc/slicqt.hip) on the radix-4 kernel (2*M*Lg^2 flops: four m-point DFTs),
+        # per-band DFTs: bands with Lg >= 24 (XSQ_D4_MIN_LG_DEFAULT, csrc/slicqt.hip) on the radix-4 kernel (2*M*Lg^2 flops: four m-point DFTs),
         # the short ones on the dense GEMM (8*M*Lg^2)
-        split = int(os.environ.get("XSQ_D4_MIN_LG", 48))
+        split = int(os.environ.get("XSQ_D4_MIN_LG", 24))
         long_, short_ = Lg[Lg >= split], Lg[Lg < split]
         add("band_analysis_dft4", "mfma", r2 * 2 * int((long_ * long_).sum()))
         add("band_analysis_gemm", "mfma", r2 * 8 * int((short_ * short_).sum()))
