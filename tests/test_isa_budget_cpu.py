@@ -1,0 +1,57 @@
+"""Vector-instruction budget of the radix-4 band kernel, read off the gfx950 assembly (hipcc cross-compiles without a GPU).
+
+On this part an fp32 MFMA and the other waves' vector instructions take turns on a SIMD ("Vector
+issue"): the kernel's K-step costs its MFMA cycles PLUS ~4 cycles per other vector instruction, so those are a budget.
+tools/valu_mfma.py counts them per MFMA loop; this test holds the counts the buffer-addressed kernel reached (108 -> 55 per
+K-step of the masked synthesis) and that the instantiations stay free of scratch and inside three workgroups per CU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+SRC = """#include "band_dft4.h"
+using namespace xsq;
+template __global__ void xsq::band_dft4_full_kernel<true, 10, false>(Band4Args, const Tile4Dev*, int);
+template __global__ void xsq::band_dft4_full_kernel<false, 10, true>(Band4Args, const Tile4Dev*, int);
+template __global__ void xsq::band_dft4_full_kernel<false, 10, false>(Band4Args, const Tile4Dev*, int);
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_band_kernel_vector_instruction_budget(tmp_path):
+    src, asm = tmp_path / "d4only.hip", tmp_path / "d4only.s"
+    src.write_text(SRC)
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "xumx_slicq_amd", "csrc"), "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                    str(src), "-o", str(asm)], check=True, capture_output=True, timeout=600)
+    text = asm.read_text()
+    # registers / scratch from the kernel descriptors' metadata
+    meta = re.findall(r"\.name:\s+(\S+)\s+\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", text, flags=re.S)
+    assert len(meta) == 3, meta
+    for name, scratch, vgprs in meta:
+        assert int(scratch) == 0, (name, scratch)
+        assert int(vgprs) <= 168, (name, vgprs)          # three waves per SIMD (amdgpu_waves_per_eu(3, 3))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_mfma.py"), str(asm)], check=True,
+                         capture_output=True, text=True, timeout=120).stdout
+    rows = {}
+    cur = None
+    for line in out.splitlines():
+        if line.startswith("void "):
+            cur = line
+        m = re.search(r"MFMA\s+(\d+) cycles \(\s*(\d+)\), other vector\s+(\d+)", line)
+        if m and cur:
+            rows.setdefault(cur, []).append(tuple(int(x) for x in m.groups()))
+    inv_masked = [v for k, v in rows.items() if "<false, 10, true>" in k][0]
+    inv_plain = [v for k, v in rows.items() if "<false, 10, false>" in k][0]
+    fwd = [v for k, v in rows.items() if "<true, 10, false>" in k][0]
+    # the K loop: 80 MFMAs (ten 16-column blocks x 8) = 2560 cycles; other vector instructions per K-step
+    for loops, budget in ((inv_masked, 64), (inv_plain, 56), (fwd, 140)):      # (fwd: sum over its two exclusive load paths)
+        k_loop = min(loops, key=lambda r: r[2])
+        assert k_loop[0] == 2560 and k_loop[1] == 80, loops
+        assert k_loop[2] <= budget, (loops, budget)
+    assert "v_pk_" not in text          # no packed-fp32 ops (Makefile NOPK; -fno-slp-vectorize stands in for it here)
