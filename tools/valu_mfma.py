@@ -13,8 +13,8 @@ import re
 import subprocess
 import sys
 
-PASSES = {"32x32x2": 16, "16x16x4": 8, "32x32x1": 16, "16x16x1": 8, "4x4x1": 2, "32x32x16": 16, "16x16x32": 8,
-          "32x32x8": 16, "16x16x16": 8, "32x32x4": 16}       # passes of 4 cycles
+PASSES = {"32x32x2": 16, "16x16x4": 8, "32x32x1": 16, "16x16x1": 8, "4x4x1": 2,       # fp32
+          "32x32x16": 8, "16x16x32": 4, "32x32x8": 8, "16x16x16": 4, "32x32x4": 16}   # bf16 / f16 (gfx950); passes of 4 cycles
 
 
 def mfma_cycles(op):
