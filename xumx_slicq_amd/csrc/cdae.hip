@@ -442,6 +442,26 @@ struct CdaeL4Op {
         if (slab0 + 32 <= g.M && perb >= 32) {
             const int obase = row0 * g.hop + b0 * FST, ocut = next_b - row0;     // row r: obase + acc_row(r)*hop (+ FST past the batch boundary)
             auto off = [&](int r) { return obase + acc_row(r) * g.hop + (acc_row(r) >= ocut ? FST : 0); };
+            if (!a.Y && next_b >= slab0 + 32) {
+                // masks only, no batch boundary inside the slab (all but one slab in Fo * To / 32): buffer stores with the
+                // row's displacement as the SCALAR offset -- per element the sigmoid's five instructions and nothing else
+                // (the pointer form below spent six more on the element's address; beside fp32 MFMAs they are not hidden).
+                // Same arithmetic as below: bitwise the same masks.
+                const int s0 = __builtin_amdgcn_readfirstlane(slab0);       // (wave-uniform by construction; the descriptor wants scalars)
+                const int b0u = __builtin_amdgcn_readfirstlane(b0);
+                const __amdgpu_buffer_rsrc_t rm = buf_rsrc(Mk + (int64_t)s0 * g.hop + (int64_t)b0u * FST, 0x40000000u);   // (launch check: < 2^30 bytes)
+                const unsigned lane_off = 4u * (unsigned)((row0 - slab0) * g.hop);
+                const unsigned va = v0 ? lane_off + 4u * (unsigned)offa : BUF_OOB, vb = v1 ? lane_off + 4u * (unsigned)offb : BUF_OOB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_amdgcn_rcpf(1.f + __expf(-(a0[r] + ba)))), rm, (int)va, 4 * acc_row(r) * g.hop, 0);
+                if (wide) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_amdgcn_rcpf(1.f + __expf(-(a1[r] + bb)))), rm, (int)vb, 4 * acc_row(r) * g.hop, 0);
+                }
+                return;
+            }
             if (!a.Y) {      // masks only (the inverse transform multiplies by the mix on its way in)
                 if (v0) {
 #pragma unroll
@@ -854,10 +874,11 @@ int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const
 int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t stream, const char* prof_name) {
     TileTable tt;
     // layers 1 and 4 read their operand rows through buffer descriptors with 32-bit byte offsets and out-of-range switches
-    // (common.h): a block's input -- its whitened magnitudes, its layer-3 activations of one target -- stays below 2^30 bytes
+    // (common.h), layer 4 stores its masks that way: a block's whitened magnitudes / masks of one target and its layer-3
+    // activations stay below 2^30 bytes
     if (layer == 1 || layer == 4)
         for (const CdaeBlockDev& d : Mo->blocks)
-            XSQ_REQUIRE((layer == 1 ? (int64_t)4 * 2 * a.Bn * d.F * a.S * d.T : (int64_t)4 * CS * a.Bn * a.T1 * d.F1) < ((int64_t)1 << 30),
+            XSQ_REQUIRE(std::max((int64_t)4 * 2 * a.Bn * d.F * a.S * d.T, layer == 4 ? (int64_t)4 * CS * a.Bn * a.T1 * d.F1 : 0) < ((int64_t)1 << 30),
                         "xsq_cdae_forward: B=%d S=%d: a block's layer-%d input exceeds 2^30 bytes; split the batch", a.Bn, a.S, layer);
     if (layer == 4 && !a.gx8)
         for (const CdaeBlockDev& d : Mo->blocks)
