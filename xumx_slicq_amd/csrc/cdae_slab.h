@@ -171,33 +171,29 @@ __global__ __launch_bounds__(512, 4) void cdae_slab_kernel(CdaeArgs a, const Sla
     static_assert(SLAB_MAXSEG <= 4, "one-hot segment code: four bits per load");
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(in, 0x40000000u);      // (a (block, target)'s input is < 2^30 bytes: cdae_launch_layer)
     unsigned s_vo[NLD], s_seg = 0;
-    {
-        int A[SLAB_MAXSEG], G[SLAB_MAXSEG], lo[SLAB_MAXSEG], hi[SLAB_MAXSEG];      // uniform (scalar registers)
 #pragma unroll
-        for (int i = 0; i < SLAB_MAXSEG; ++i) {
-            const int st = seg_start(i);
-            const int rows_i = (i + 1 < SLAB_MAXSEG ? seg_start(i + 1) : nrows) - st;      // output rows of the segment
-            const int f = f0 + i, ts = i ? 0 : t0;
-            const int first = ts - (TRANSPOSED ? 3 : 0);                                    // input position of j = 0
-            const bool ok = !(XSQ_SLAB_ABL & 8) && f < Fo && rows_i > 0;
-            A[i] = st + 3 * i;
-            G[i] = ((b * Fi + f) * Ti + first) * CS;                                        // input row f (df = 0)
-            lo[i] = ok ? (first < 0 ? -first : 0) : 1;                                      // j with 0 <= first + j < Ti and j < rows_i + 3
-            hi[i] = ok ? min(rows_i + 3, Ti - first) : 0;
-        }
+    for (int q = 0; q < NLD; ++q) s_vo[q] = BUF_OOB;
+    // Segment by segment, empty segments skipped by a scalar branch (To >= 256: a tile touches one or two (b, f) rows): per
+    // segment and load an unsigned range test, an offset and two selects.  (Load by load with a segment search and a four-way
+    // select of the segment's constants this block was 175 of the prologue's 320 vector instructions.)
+#pragma unroll
+    for (int i = 0; i < SLAB_MAXSEG; ++i) {
+        const int st = seg_start(i);
+        const int rows_i = (i + 1 < SLAB_MAXSEG ? seg_start(i + 1) : nrows) - st;      // output rows of the segment
+        const int f = f0 + i, ts = i ? 0 : t0;
+        const int first = ts - (TRANSPOSED ? 3 : 0);                                    // input position of j = 0
+        if ((XSQ_SLAB_ABL & 8) || f >= Fo || rows_i <= 0) continue;                      // (uniform)
+        const int A = st + 3 * i;                                                       // first slab position of the segment
+        const int G = ((b * Fi + f) * Ti + first) * CS;                                 // float offset of that position, input row f (df = 0)
+        const int lo = first < 0 ? -first : 0, hi = min(rows_i + 3, Ti - first);        // j with 0 <= first + j < Ti and j < rows_i + 3
+        const int j0 = s_p0 - A;
+        const unsigned base = 4u * (unsigned)(G + j0 * CS + 4 * s_c4);
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int pos = s_p0 + SLAB_PL * q;
-            int i = 0;
-#pragma unroll
-            for (int sI = 1; sI < SLAB_MAXSEG; ++sI) i += pos >= A[sI] ? 1 : 0;
-            int Ai = A[0], Gi = G[0], li = lo[0], hI = hi[0];
-#pragma unroll
-            for (int sI = 1; sI < SLAB_MAXSEG; ++sI)
-                if (i == sI) { Ai = A[sI]; Gi = G[sI]; li = lo[sI]; hI = hi[sI]; }
-            const int j = pos - Ai;
-            s_vo[q] = (s_on && j >= li && j < hI) ? 4u * (unsigned)(Gi + j * CS + 4 * s_c4) : BUF_OOB;
-            s_seg |= 1u << (4 * q + i);
+            const int j = j0 + SLAB_PL * q;
+            const bool in = s_on && (unsigned)(j - lo) < (unsigned)(hi - lo);
+            s_vo[q] = in ? base + 4u * (unsigned)(SLAB_PL * q * CS) : s_vo[q];
+            s_seg |= in ? 1u << (4 * q + i) : 0u;
         }
     }
     auto load_slab = [&](int df, int q0 = 0, int q1 = NLD) {
