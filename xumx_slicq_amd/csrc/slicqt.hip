@@ -307,6 +307,17 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
     return XSQ_OK;
 }
 
+// The radix-4 band kernel reaches operands and results through buffer descriptors per band block / tile with 32-bit byte
+// offsets and switches lanes off with offsets of 2^30 and 2^31 (band_dft4.h, common.h): every such range stays below 2^30
+// bytes.  Checked where a transform call enters, before anything is launched.
+static int d4_ranges_ok(const xsq_plan* P, int64_t rows, const char* who) {
+    if (!(P->band_radix4 && P->nbands4)) return XSQ_OK;
+    XSQ_REQUIRE(8 * rows * P->d4_max_block < (1ll << 30) && (int64_t)8 * D4H_ROWS * std::max<int64_t>(P->nbins, P->sumFT) < (1ll << 30),
+                "%s: %lld rows x %lld coefficients of a band block exceed 2^30 bytes; split the call (fewer stacked chunks)",
+                who, (long long)rows, (long long)P->d4_max_block);
+    return XSQ_OK;
+}
+
 // the radix-4 band kernel over every eligible band, one launch of the 10-block instantiation (three workgroups per CU).
 // XSQ_D4_SPLIT=1 (A/B switch, measured no faster: synthesis 0.940-0.948 vs 0.916-0.945 ms, analysis 0.309-0.316 vs
 // 0.291-0.301): the bands of at most five 16-column blocks in their own instantiation -- 35 KB of LDS, 96 registers,
@@ -314,11 +325,6 @@ static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share 
 template <bool FWD>
 static int launch_dft4(xsq_plan* P, const Band4Args& a4, int rows, int share, hipStream_t stream) {
     static const bool split = getenv("XSQ_D4_SPLIT") && atoi(getenv("XSQ_D4_SPLIT")) == 1;
-    // the kernel reaches operands and results through buffer descriptors per band block / tile with 32-bit byte offsets
-    // and switches lanes off with offsets of 2^30 and 2^31 (band_dft4.h): every such range stays below 2^30 bytes
-    XSQ_REQUIRE((int64_t)8 * rows * P->d4_max_block < (1ll << 30) && (int64_t)8 * D4H_ROWS * std::max<int64_t>(P->nbins, a4.row_len) < (1ll << 30),
-                "band transform: %d rows x %lld coefficients of a band block exceed 2^30 bytes; split the call (fewer stacked chunks)",
-                rows, (long long)P->d4_max_block);
     const bool masked = !FWD && a4.mask != nullptr;
     TileTable t;
     int rc;
@@ -858,6 +864,7 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
     // band_dft4.h addresses the slice spectra and the arena through 32-bit float offsets
     XSQ_REQUIRE((int64_t)2 * BC * S * (P->sumFT > P->nbins ? P->sumFT : P->nbins) < (1ll << 31),
                 "xsq_slicqt_forward: BC*S=%lld rows exceed 2^31 floats of coefficients; split the call", (long long)BC * S);
+    if (int rcg = d4_ranges_ok(P, (int64_t)BC * S, "xsq_slicqt_forward")) return rcg;
     FftPlan f;
     int rc = lds_fft(P) ? XSQ_OK : get_fft(P, 0, rows, &f);
     if (rc) return rc;
@@ -939,6 +946,7 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
     // the band kernels carry arena offsets in 32 bits (band_dft4.h: xoff / moff; the mix arena is the smaller one)
     XSQ_REQUIRE((int64_t)2 * BC * S * P->sumFT < (1ll << 31), "xsq_slicqt_inverse: the coefficient arena of BC*S=%lld rows "
                 "exceeds 2^31 floats; split the call (fewer stacked chunks)", (long long)BC * S);
+    if (int rcg = d4_ranges_ok(P, (int64_t)BC * S, "xsq_slicqt_inverse")) return rcg;
     hipStream_t stream = (hipStream_t)stream_;
     const int rows = BC * S;
     FftPlan f;
