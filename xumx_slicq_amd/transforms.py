@@ -75,7 +75,7 @@ class SliCQEngine:
             _lib.check(_lib.lib.xsq_plan_set_packed_fft(h, int(on)), "xsq_plan_set_packed_fft")
 
     def set_short_inline(self, on: bool):
-        """False (default): bands with Lg < 48 on the dense GEMM with a round trip through the workspace; True: the inverse
+        """False (default): bands with Lg < 24 on the dense GEMM with a round trip through the workspace; True: the inverse
         transform synthesises them inside the slice-FFT kernel (A/B switch, same results to fp32 rounding; measured slower)."""
         self._short_inline = bool(on)
         for h in self._handles.values():
