@@ -96,7 +96,7 @@ constexpr int D4H_ROWS = 32;
 // Vector issue.  On gfx950 an fp32 MFMA runs at exactly the rate of the SIMD's packed-fp32 vector ALU, and measured it does
 // not overlap with the vector instructions of the SIMD's other waves: a K-step of this kernel takes the SUM of its MFMA
 // cycles (256 per 16-column block and wave) and 4 cycles per other vector instruction, times the three resident waves
-// (round-4 ablations: no MFMAs -10 %, no K-loop loads -5 %, both -46 %; K-step 0.56 + 0.41 ncb us; tools/valu_mfma.py
+// (ablations r4a, profiles/r05_ab_runs.txt: no MFMAs -10 %, no K-loop loads -5 %, both -46 %; K-step 0.56 + 0.41 ncb us; tools/valu_mfma.py
 // counts the two from the assembly).  The round-3 form spent 108 vector instructions per K-step and 63 per 16-column
 // block of the epilogue -- as many issue cycles as the MFMAs of a 4-block band -- two thirds of them address arithmetic:
 // 64-bit pointer sums per load, clamps, selects around loads and stores.  Here every operand and result goes through a
