@@ -586,9 +586,9 @@ static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 
 
 static int kf_of(int F) { return F < 10 ? 1 : (F < 20 ? 3 : 5); }   // model.py:112-117
 
-static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int mt23 = L23_MT, bool n16 = false) {
+static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int mt23 = L23_MT, bool n16 = false, bool tgt_outer = false) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(layer + 16 * mt23 + (n16 ? 128 : 0), Bn, S);
+    auto key = std::make_tuple(layer + 16 * mt23 + (n16 ? 128 : 0) + (tgt_outer ? 256 : 0), Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
@@ -614,13 +614,24 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
         if (layer == 1 || layer == 4 || layer == 6) {
             // the four targets read the same input (L1: whitened magnitude) / the same mix X (L4 epilogue):
             // keep their tiles of one (row, column) patch adjacent so the re-reads hit the XCD's L2
-            for (int64_t m0 = 0; m0 < M; m0 += 128)
-                for (int n0 = 0; n0 < N; n0 += 64)
-                    for (int tgt = 0; tgt < NT; ++tgt) {
-                        const int rem = N - n0;      // n16 (layer 4, fp32 inference): widths 16 / 32 / 48 / 64, see gemm_tile.h XW = 2
-                        const int kind = n16 ? (rem <= 16 ? 2 : rem <= 32 ? 1 : rem <= 48 ? 3 : 0) : (rem <= 32 ? 1 : 0);
-                        t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, kind});
-                    }
+            auto push = [&](int64_t m0, int n0, int tgt) {
+                const int rem = N - n0;      // n16 (layer 4, fp32 inference): widths 16 / 32 / 48 / 64, see gemm_tile.h XW = 2
+                const int kind = n16 ? (rem <= 16 ? 2 : rem <= 32 ? 1 : rem <= 48 ? 3 : 0) : (rem <= 32 ? 1 : 0);
+                t.push_back(TileDev{b * 4 + tgt, (int)m0, n0, kind});
+            };
+            if (tgt_outer) {
+                // layer 4 storing masks only: the targets share nothing (each reads its own layer-3 activations), while
+                // the column tiles of a row block share its operand rows and neighbouring row blocks share rows through the
+                // frequency taps: one (block, target) after the other (r4t: 0.689 -> 0.675 ms; target innermost and
+                // column tiles adjacent per target measured 0.694)
+                for (int tgt = 0; tgt < NT; ++tgt)
+                    for (int64_t m0 = 0; m0 < M; m0 += 128)
+                        for (int n0 = 0; n0 < N; n0 += 64) push(m0, n0, tgt);
+            } else {
+                for (int64_t m0 = 0; m0 < M; m0 += 128)
+                    for (int n0 = 0; n0 < N; n0 += 64)
+                        for (int tgt = 0; tgt < NT; ++tgt) push(m0, n0, tgt);
+            }
         } else {
             for (int tgt = 0; tgt < NT; ++tgt) push_group_tiles(t, b * 4 + tgt, M, N, 128 * mt23);
         }
@@ -916,7 +927,8 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity
-    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23, n16);
+    const bool tgt_outer = layer == 4 && !a.Y && !a.gx8;        // masks only (the separator's path, also with Wiener-EM from the masks)
+    int rc = get_cdae_tiles(Mo, layer, a.Bn, a.S, &tt, mt23, n16, tgt_outer);
     if (rc) return rc;
 #define XSQ_LAUNCH(OP, MT_, XW_)                                                                                    \
     do {                                                                                                            \
