@@ -167,13 +167,13 @@ __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int r
         }
     }
     __builtin_amdgcn_wave_barrier();          // same wave, LDS operations complete in order: no workgroup barrier needed
-    const int nvalid = (g.M - rowb < 32 ? g.M - rowb : 32) * (CS / 4);       // float4 slots of the rows that exist
-    float* out = g.out + (int64_t)rowb * CS;
+    const int nvalid = max(0, min(g.M - rowb, 32)) * (CS / 4);               // float4 slots of the rows that exist (none for a wave past M)
+    // buffer stores: the descriptor ends behind the last row that exists (and behind the image's 416 slots) -- no
+    // predicate per store
+    const __amdgpu_buffer_rsrc_t ro = buf_rsrc(g.out + (int64_t)__builtin_amdgcn_readfirstlane(rowb) * CS, 16u * (unsigned)__builtin_amdgcn_readfirstlane(nvalid));
 #pragma unroll
-    for (int i = 0; i < (XW_TILE / 4 + 63) / 64; ++i) {
-        const int e = lane + 64 * i;
-        if (e < nvalid) *reinterpret_cast<float4*>(out + 4 * e) = *reinterpret_cast<const float4*>(img + 4 * e);
-    }
+    for (int i = 0; i < (XW_TILE / 4 + 63) / 64; ++i)
+        buf_st4(*reinterpret_cast<const float4*>(img + 4 * (lane + 64 * i)), ro, 16u * (unsigned)lane, 1024 * i);      // (the range check covers lane + scalar offset: tools/probe/buf_range.hip)
 }
 
 // ---- layer 1 -----------------------------------------------------------------------------

@@ -49,7 +49,8 @@ __device__ __forceinline__ float whiten_mag(float re, float im, float mu, float 
 }
 
 // ---- buffer addressing (gfx950).  A load or store through a buffer descriptor takes a 32-bit per-lane byte offset and a
-// scalar offset; past the descriptor's range a load returns 0 and a store is dropped.  The fp32 MFMA kernels use it to
+// scalar offset; past the descriptor's range -- lane offset + scalar offset + immediate against num_records, probed with
+// tools/probe/buf_range.hip -- a load returns 0 and a store is dropped.  The fp32 MFMA kernels use it to
 // keep address arithmetic, clamps, zero fills and predicates out of their K loops: on this part those vector instructions
 // are not hidden behind the MFMAs of the SIMD's other waves (band_dft4.h, "Vector issue").  Every range is kept below 2^30
 // bytes where the launch is built: BUF_OOB (a row switched off) still lies past it after a backward displacement of up to
