@@ -159,9 +159,10 @@ def pmc_traffic(kernel, tag=None):
 
 def rocprof_launch_ms(kernel, tag=None):
     """Average launch duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
-    (profiles/*_kernel_stats.csv, newest): the figure a reader recomputes the roofline fraction from.  It reads ~10 % longer
-    than the event time of the timed region (the traced run serialises the launches and runs three steps from cold), so the
-    bench line carries both instead of letting them disagree silently.  None without a committed summary."""
+    (profiles/*_kernel_stats.csv, newest; tools/collect_profiles.sh traces it with the driver's --steps 20 --warmup 5): the
+    figure a reader recomputes the roofline fraction from.  The bench line carries it beside the event time of the timed
+    region instead of letting the two disagree silently (a 3 + 1 step trace, as the sets before r06z were, times its
+    launches from cold and reads 10-15 % long).  None without a committed summary."""
     import csv
     import glob
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv"))
