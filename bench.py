@@ -291,20 +291,36 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def timed_steps(step, steps, world, dist, dev):
+def timed_steps(step, steps, world, dist, dev, split=None):
+    """K steps between barrier + synchronize, max over ranks.  `split` (a dict) receives what tells a GPU-bound step
+    from a host-bound one: two HIP events per step on the launch stream (before its first launch, after its last one)
+    -> `gpu_span_ms` (mean / max over the steps: first launch to last completion, gaps included), and the wall time
+    the host needed to ENQUEUE the K steps (`host_enqueue_ms` per step, read before the final synchronize).  GPU-bound:
+    host_enqueue << ms_per_step ~ gpu_span; host-bound: host_enqueue ~ ms_per_step > the sum of the kernels."""
     import torch
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if split is not None else None
     t0 = time.perf_counter()
     out = None
-    for _ in range(steps):
+    for i in range(steps):
+        if ev:
+            ev[i][0].record()
         out = step()
+        if ev:
+            ev[i][1].record()
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if ev:
+        spans = [a.elapsed_time(b) for a, b in ev]
+        split.update({"gpu_span_ms": {"mean": round(sum(spans) / len(spans), 4), "max": round(max(spans), 4), "min": round(min(spans), 4)},
+                      "host_enqueue_ms": round(t_enq / steps * 1e3, 4),
+                      "gpu_total_ms": round(ev[0][0].elapsed_time(ev[-1][1]) / steps, 4)})
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -451,7 +467,8 @@ def bench_track(args, sep, dev, world, rank, dist):
     dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
     _lib.profile_filter(dom)
     _lib.profile_reset()
-    dt, out = timed_steps(step, args.steps, world, dist, dev)
+    split = {}
+    dt, out = timed_steps(step, args.steps, world, dist, dev, split)
     prof = _lib.profile_read()          # the dominant kernel only, over the timed region
     _lib.profile_enable(False)
     _lib.profile_filter(None)
@@ -488,6 +505,11 @@ def bench_track(args, sep, dev, world, rank, dist):
                                "(10,584,000 samples, 5 chunks) per GPU, %s, seeded synthetic weights"
                                % (2 if args.wiener else 1, "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
                    "parallelism": "one track per rank, %d rank(s), no data-path collective" % world},
+        "gpu_span_ms": split.get("gpu_span_ms"), "host_enqueue_ms": split.get("host_enqueue_ms"),
+        "gpu_total_ms": split.get("gpu_total_ms"),
+        "timing_note": "ms_per_step: wall clock over the K steps incl. the final synchronize; gpu_span_ms: HIP events around each step on "
+                       "the launch stream (first launch -> last completion); gpu_total_ms: first event to last event / K; host_enqueue_ms: "
+                       "host wall time to issue one step (one C call, xsq_separator_forward).  host_enqueue << ms_per_step = GPU-bound",
         "roofline": roofline,
         "roofline_hbm": hbm,
         "roofline_mfma": mfma,
@@ -501,6 +523,19 @@ def bench_track(args, sep, dev, world, rank, dist):
     return result
 
 
+def _timed_loop(fn, steps):
+    """(seconds per step, host enqueue seconds per step, last result) of `steps` back-to-back calls."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = fn()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, t_enq / steps, out
+
+
 def variant_graph(args, sep, track, out):
     """The same step replayed from a captured HIP graph (Separator.forward_graphed): no host-side launch work,
     bitwise the eager result."""
@@ -509,15 +544,11 @@ def variant_graph(args, sep, track, out):
         g = sep.forward_graphed(track)
     torch.cuda.synchronize()
     same = bool(torch.equal(g, out))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sep.forward_graphed(track)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, enq, _ = _timed_loop(lambda: sep.forward_graphed(track), args.steps)
     sep.drop_graphs()
-    return {"what": "the headline step as one HIP graph replay (Separator.forward_graphed)",
-            "value": round(args.steps * TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time",
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "bitwise_equal_to_eager": same}
+    return {"what": "the headline step as one HIP graph replay (Separator.forward_graphed; incl. the 85 MB copy of the input into the graph's static buffer)",
+            "value": round(TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time",
+            "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms": round(enq * 1e3, 4), "bitwise_equal_to_eager": same}
 
 
 def variant_precisions(args, sep, step, out):
@@ -532,16 +563,11 @@ def variant_precisions(args, sep, step, out):
         sep.xumx_model.set_precision(prec)
         for _ in range(max(1, args.warmup)):
             step()
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(args.steps):
-            vout = step()
-        torch.cuda.synchronize()
-        tv = time.perf_counter() - tv
+        tv, enq, vout = _timed_loop(step, args.steps)
         d = (vout - ref_out).double()
         variants[prec] = {
             "what": what[prec],
-            "value": round(args.steps * TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv / args.steps * 1e3, 3),
+            "value": round(TRACK_SAMPLES / FS / tv, 2), "ms_per_step": round(tv * 1e3, 3), "host_enqueue_ms": round(enq * 1e3, 4),
             "stems_vs_fp32": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max()),
                               "bar": "1e-4 rms / 1e-3 max-abs (BASELINE.json north_star)"}}
         del vout, d
@@ -568,12 +594,8 @@ def variant_wiener(args, dev, track, plan, my_items):
     dom = max(prof_all, key=lambda k: prof_all[k][0])
     _lib.profile_filter(dom)
     _lib.profile_reset()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt1, enq, _ = _timed_loop(step, args.steps)
+    dt = dt1 * args.steps
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     _lib.profile_filter(None)
@@ -581,7 +603,7 @@ def variant_wiener(args, dev, track, plan, my_items):
     hbm, _ = roofline_tables(work, prof_all, 1, True)
     return {"what": "BASELINE configs[2]: offline model + norbert Wiener-EM (niter=1), same 240 s track, fp32",
             "value": round(args.steps * TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time",
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "host_enqueue_ms": round(enq * 1e3, 4),
             "roofline": dominant_roofline(dom, prof, work, args.steps, dt, "fp32", True),
             "roofline_hbm": [h for h in hbm if h["kernel"].startswith("wiener")],
             "kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}}

@@ -106,6 +106,15 @@ int xsq_slicqt_forward_xin(xsq_plan* plan, const float* x, int BC, int64_t n, fl
                            const float* mean, const float* scale, int split,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same transform reading packed channel r at x + x_row_offsets[r] (DEVICE array of BC int64 element offsets; NULL =
+ * r * n): the chunks of a (nb_samples, 2, N) track that Separator.forward stacks along the batch axis are read where
+ * they lie (the reference slices views too, separator.py:153-158) instead of through a packing copy.  n = samples that
+ * exist per row, n_pad >= n = the length the slice count is taken from: the zero padding of a short last chunk to
+ * sllen/2 + 1 samples (separator.py:162-168) without materialising the zeros (the kernels read zeros outside [0, n)). */
+int xsq_slicqt_forward_rows(xsq_plan* plan, const float* x, const int64_t* x_row_offsets, int BC, int64_t n,
+                            int64_t n_pad, float* coef, float* xin, const float* mean, const float* scale, int split,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- inverse sliCQT -----------------------------------------------------------
  * Replaces INSGT_SL.forward (transforms.py:154-178) -> NSGT_sliced.backward
  * (nsgt/slicq.py:198-230): per-band FFT, dual-window multiply and overlap-add into the
@@ -275,6 +284,46 @@ int64_t xsq_train_step_count(xsq_train* t, int64_t set);
 /* Arithmetic of the GEMM-shaped forward / data-gradient kernels of the step: 0 fp32 MFMA (default), 2 bf16x6 (see
  * xsq_model_set_precision; the reference trains these layers under bf16 autocast, training.py:473-476).          */
 int xsq_train_set_precision(xsq_train* t, int mode);
+
+/* ---- the whole call: Separator.forward (separator.py:133-232) behind ONE entry point ----------------------------
+ * The reference's chunk loop -- per chunk of <= chunk_size samples: zero-pad to sllen/2 + 1 (162-168), sliCQT (170),
+ * Unmix with mix-phase or Wiener-EM (172-219), isliCQT to the chunk's length (221-227), hard concat (229-231) -- issued
+ * from native code so that the host enqueues a 240 s track in ~0.1 ms instead of walking ~40 Python / ctypes calls and
+ * ~300 tensor views per step (which left the eager step host-bound on slow hosts).
+ *
+ * xsq_demixer: per-plan cache of the row-offset tables of a call shape (device arrays, built on first use) and the
+ *   fork / join events of the tail stream.  Not owned: the plan must outlive it.  The model is passed per call (its
+ *   handle is rebuilt when parameters change).
+ * xsq_demix_pass: ONE pass over B = items * group equal-length work items (chunks of any tracks; `group` = nb_samples
+ *   of an item, the scope of the Wiener window maximum):
+ *     xsq_slicqt_forward_rows (+ whitened magnitude) -> xsq_cdae_forward_xin (masks only)
+ *       -> wiener == 0: xsq_slicqt_inverse_masked          (mix-phase, the estimate mask * X formed on the way in)
+ *          wiener == 1: xsq_wiener_em_masked -> xsq_slicqt_inverse_rows
+ *   x_rows: DEVICE int64[2B] element offsets of the input rows (NULL: contiguous (B, 2, n)); out_rows: DEVICE
+ *   int64[8B] element offsets of packed channel (target, item, c) in `out`; n = samples per item, n_pad as above.
+ * xsq_separator_forward: audio (nb, 2, N) -> out (4, nb, 2, N), both DEVICE fp32 contiguous.  Full chunks are stacked
+ *   along the batch axis, at most max_stack (chunk, sample) pairs per pass and never more rows than one launch
+ *   addresses (a batch too large for one pass is split over the samples; with Wiener-EM a split batch would change
+ *   the window maximum's scope and is refused); the remaining chunks run one by one, on `tail_stream` beside the
+ *   stacked passes when overlap_tail != 0 and tail_stream != stream (forked / joined with events: capturable in a
+ *   HIP graph).  workspace / tail_workspace: xsq_separator_workspace bytes each (the tail one may be NULL when nothing
+ *   runs on the tail stream).  Same bits as the chunk-by-chunk loop.                                              */
+typedef struct xsq_demixer xsq_demixer;
+int xsq_demixer_create(xsq_demixer** out, xsq_plan* plan);
+int xsq_demixer_destroy(xsq_demixer* d);
+size_t xsq_demix_pass_workspace(xsq_demixer* d, const xsq_model* model, int B, int64_t n_pad, int wiener);   /* 0 on error */
+int xsq_demix_pass(xsq_demixer* d, xsq_model* model, const float* x, const int64_t* x_rows, int B, int64_t n,
+                   int64_t n_pad, int group, int wiener, float* out, const int64_t* out_rows,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int xsq_separator_workspace(xsq_demixer* d, const xsq_model* model, int nb, int64_t N, int64_t chunk_size, int max_stack,
+                            int wiener, size_t* main_bytes, size_t* tail_bytes);
+int xsq_separator_forward(xsq_demixer* d, xsq_model* model, const float* audio, int nb, int64_t N, int64_t chunk_size,
+                          int max_stack, int wiener, int overlap_tail, float* out, void* workspace,
+                          size_t workspace_bytes, void* tail_workspace, size_t tail_workspace_bytes, void* stream,
+                          void* tail_stream);
+/* Test hook: cap on B * S (stacked items x slices) of one pass, normally what the 32-bit arena offsets of the band
+ * kernels allow (7168); a smaller value forces the batch split on small shapes.  <= 0 restores the default.        */
+int xsq_demixer_set_max_rows(xsq_demixer* d, int max_item_slices);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------
  * When enabled, every kernel launch of the library is bracketed by hipEvents recorded on

@@ -657,3 +657,50 @@ def test_packed_slice_fft_follows_the_contraction_mode(seps):
         del sep.packed_fft
         sep(x)
         assert not eng._packed_fft
+
+
+@pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener", "realtime"])
+def test_native_forward_is_bitwise_the_python_schedule(seps, name):
+    """Separator.forward as ONE C call (xsq_separator_forward: input rows read in place, zero padding as a slice
+    count, tail on the side stream) against the same schedule issued through the module API (``native = False``),
+    on an odd track length (rows of odd alignment), nb_samples = 2, stacked passes + a single chunk + a short tail."""
+    sep = seps[name]
+    N = 50000 * 5 + 4321
+    x = synth_audio(N, seed=91, nb_samples=2).cuda()
+    x[1] *= 3.0
+    try:
+        sep.chunk_size, sep.max_stack = 50000, 4
+        sep.native = False
+        a = sep(x)
+        sep.native = True
+        b = sep(x)
+        c = sep(x[:, :, :777])                  # one chunk shorter than sllen/2 + 1
+        sep.native = False
+        d = sep(x[:, :, :777])
+    finally:
+        sep.native, sep.chunk_size, sep.max_stack = True, 2621440, 8
+    assert a.shape == b.shape == (4, 2, 2, N) and c.shape == d.shape == (4, 2, 2, 777)
+    assert torch.equal(a, b) and torch.equal(c, d)
+
+
+def test_batch_larger_than_one_pass_is_split_over_the_samples(seps):
+    """separator.py:133-232 takes any nb_samples; a pass addresses at most 7168 item-slices (32-bit arena offsets), so a
+    larger batch runs as several passes over sample ranges.  Scaled down through ``max_item_slices``: nb = 5 at S = 8
+    with a cap of 20 item-slices -> passes of 2 + 2 + 1 samples; mix-phase results are bitwise those of the whole batch,
+    Wiener-EM (window maximum over the batch, norbert/__init__.py:257) refuses the split loudly."""
+    from xumx_slicq_amd import _lib
+    sep = seps["offline_phasemix"]
+    x = synth_audio(60000 * 2 + 30000, seed=93, nb_samples=5).cuda()
+    try:
+        sep.chunk_size = 60000
+        a = sep(x)
+        sep.max_item_slices = 20
+        b = sep(x)
+        sepw = seps["offline_wiener"]
+        sepw.chunk_size, sepw.max_item_slices = 60000, 20
+        with pytest.raises(_lib.XsqError, match="Wiener"):
+            sepw(x)
+    finally:
+        sep.chunk_size, sep.max_item_slices = 2621440, 0
+        seps["offline_wiener"].chunk_size, seps["offline_wiener"].max_item_slices = 2621440, 0
+    assert torch.equal(a, b)

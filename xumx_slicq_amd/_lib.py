@@ -55,6 +55,7 @@ _SIGS = {
     "xsq_slicqt_forward_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int64]),
     "xsq_slicqt_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_forward_xin": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "xsq_slicqt_forward_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -83,6 +84,13 @@ _SIGS = {
     "xsq_train_step_count": (C.c_int64, [_vp, C.c_int64]),
     "xsq_train_set_precision": (C.c_int, [_vp, C.c_int]),
     "xsq_place_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
+    "xsq_demixer_create": (C.c_int, [C.POINTER(_vp), _vp]),
+    "xsq_demixer_destroy": (C.c_int, [_vp]),
+    "xsq_demixer_set_max_rows": (C.c_int, [_vp, C.c_int]),
+    "xsq_demix_pass_workspace": (C.c_size_t, [_vp, _vp, C.c_int, C.c_int64, C.c_int]),
+    "xsq_demix_pass": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "xsq_separator_workspace": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "xsq_separator_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),
     "xsq_profile_filter": (C.c_int, [C.c_char_p]),

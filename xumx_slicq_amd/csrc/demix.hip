@@ -1,0 +1,294 @@
+// The chunk loop of Separator.forward (/root/reference/xumx_slicq_v2/separator.py:133-232) issued from native code:
+// one C call enqueues every launch of a track -- stacked full chunks on the caller's stream, the short tail chunk on a
+// side stream beside them -- through row-offset tables cached per call shape.  No kernels of its own: it sequences
+// the entry points of slicqt.hip / cdae.hip / wiener.hip (include/xumx_slicq_hip.h, "the whole call").
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cdae_api.h"
+#include "common.h"
+#include "plan.h"
+#include "xumx_slicq_hip.h"
+
+using namespace xsq;
+
+namespace {
+
+// what the 32-bit float offsets of the band kernels allow for the 8-channel estimate arena of one pass:
+// 2 * (8 B) * S * sumFT < 2^31 (slicqt.hip: inverse_impl) -> B * S <= 7168 for the Bark-262 plan (sumFT = 18640)
+static int default_max_item_slices(const xsq_plan* P) {
+    const int64_t lim = ((1ll << 31) - 1) / (16 * std::max<int64_t>(P->sumFT, P->nbins));
+    return (int)std::min<int64_t>(lim, 65535 / 8);          // and BC * S <= 65535 rows per launch
+}
+
+struct PassPlan {
+    int64_t n = 0, n_pad = 0;        // samples per item that exist / that the slice count is taken from
+    int B = 0, group = 1;            // stacked items (chunk, sample); samples per chunk in this pass
+    int tail = 0;                    // 1: runs on the tail stream
+    int64_t* d_xrows = nullptr;      // [2B] input row offsets
+    int64_t* d_orows = nullptr;      // [8B] output row offsets
+};
+
+struct ForwardPlan {
+    std::vector<PassPlan> passes;
+    int64_t* d_tables = nullptr;     // one allocation behind all d_xrows / d_orows
+    size_t main_bytes = 0, tail_bytes = 0;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+struct xsq_demixer {
+    xsq_plan* plan = nullptr;
+    int max_item_slices = 0;
+    std::vector<int32_t> F, T;
+    std::mutex mu;
+    std::map<std::vector<int64_t>, ForwardPlan> plans;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+namespace {
+
+struct PassLayout {
+    size_t X, masks, Y, fwd, cdae, inv, wien, total;
+    size_t fwd_bytes, cdae_bytes, inv_bytes, wien_bytes;
+};
+
+// workspace of one pass: X arena | masks arena | [Y arena] | forward ws | CDAE ws | inverse ws | [Wiener ws]
+static int pass_layout(xsq_demixer* d, const xsq_model* Mo, int B, int64_t n_pad, int wiener, PassLayout* L) {
+    xsq_plan* P = d->plan;
+    const int S = xsq_plan_num_slices(P, n_pad);
+    XSQ_REQUIRE(S >= 3, "xsq_demix_pass: %lld samples give %d slices; the conv stack needs 3 (pad to sllen/2 + 1)", (long long)n_pad, S);
+    XSQ_REQUIRE(Mo->sumFT == P->sumFT && Mo->nblocks == P->nblocks, "xsq_demix_pass: the model's block table is not the plan's");
+    const size_t coefs = (size_t)S * P->sumFT;
+    size_t o = 0;
+    L->X = o;     o += al256((size_t)2 * B * coefs * 8);
+    L->masks = o; o += al256((size_t)8 * B * coefs * 4);
+    L->Y = o;     if (wiener) o += al256((size_t)8 * B * coefs * 8);
+    L->fwd_bytes = xsq_slicqt_forward_workspace(P, 2 * B, n_pad);
+    L->cdae_bytes = xsq_cdae_workspace(Mo, B, S);
+    L->inv_bytes = xsq_slicqt_inverse_workspace(P, 8 * B, S);
+    L->wien_bytes = wiener ? xsq_wiener_workspace(P->nblocks, d->F.data(), d->T.data(), B, S, 5000) : 0;
+    if (!L->fwd_bytes || !L->cdae_bytes || !L->inv_bytes || (wiener && !L->wien_bytes)) {
+        const std::string why = xsq_last_error();
+        set_error("xsq_demix_pass: B=%d, %lld samples: a stage's workspace query failed (%s)", B, (long long)n_pad, why.c_str());
+        return XSQ_ERR_ARG;
+    }
+    L->fwd = o;  o += al256(L->fwd_bytes);
+    L->cdae = o; o += al256(L->cdae_bytes);
+    L->inv = o;  o += al256(L->inv_bytes);
+    L->wien = o; o += al256(L->wien_bytes);
+    L->total = o + 256;
+    return XSQ_OK;
+}
+
+static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t* x_rows, int B, int64_t n, int64_t n_pad,
+                    int group, int wiener, float* out, const int64_t* out_rows, void* ws, size_t ws_bytes, hipStream_t stream) {
+    xsq_plan* P = d->plan;
+    PassLayout L;
+    int rc = pass_layout(d, Mo, B, n_pad, wiener, &L);
+    if (rc) return rc;
+    if (L.total > ws_bytes) {
+        set_error("xsq_demix_pass: workspace too small (%zu needed, %zu given)", L.total, ws_bytes);
+        return XSQ_ERR_WORKSPACE;
+    }
+    const int S = xsq_plan_num_slices(P, n_pad);
+    char* w = (char*)ws;
+    float* X = (float*)(w + L.X);
+    float* masks = (float*)(w + L.masks);
+    float* Y = (float*)(w + L.Y);
+    const float *mean, *scale;
+    int split;
+    if ((rc = xsq_model_whitening(Mo, &mean, &scale, &split))) return rc;
+    // the analysis kernels write the whitened magnitude into the head of the CDAE workspace (xsq_cdae_forward_xin, xin_ready)
+    float* xin = (float*)(w + L.cdae);
+    if ((rc = xsq_slicqt_forward_rows(P, x, x_rows, 2 * B, n, n_pad, X, xin, mean, scale, split, w + L.fwd, L.fwd_bytes, stream))) return rc;
+    if ((rc = xsq_cdae_forward_xin(Mo, X, B, S, nullptr, masks, w + L.cdae, L.cdae_bytes, stream, 1))) return rc;
+    if (!wiener)
+        return xsq_slicqt_inverse_masked(P, masks, X, 8 * B, 2 * B, S, n, out, out_rows, w + L.inv, L.inv_bytes, stream);
+    if ((rc = xsq_wiener_em_masked(P->nblocks, d->F.data(), d->T.data(), X, masks, Y, B, S, 5000, group, w + L.wien, L.wien_bytes, stream)))
+        return rc;
+    return xsq_slicqt_inverse_rows(P, Y, 8 * B, S, n, out, out_rows, w + L.inv, L.inv_bytes, stream);
+}
+
+// The schedule of one call shape: stacked passes over the full chunks (at most max_stack (chunk, sample) pairs and
+// max_item_slices item-slices per pass), then the remaining chunks one by one (the tail passes).
+static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t N, int64_t cs, int max_stack, int wiener,
+                            ForwardPlan** out) {
+    xsq_plan* P = d->plan;
+    const std::vector<int64_t> key{nb, N, cs, max_stack, wiener, d->max_item_slices, Mo->causal};
+    auto it = d->plans.find(key);
+    if (it != d->plans.end()) { *out = &it->second; return XSQ_OK; }
+    const int64_t min_samples = P->L / 2 + 1;                      // separator.py:162
+    const int cap = d->max_item_slices > 0 ? d->max_item_slices : default_max_item_slices(P);
+    ForwardPlan fp;
+    std::vector<std::vector<int64_t>> xr, orw;
+    auto add_pass = [&](int64_t start, int k, int b0, int nbb, int64_t n, int tail) {
+        PassPlan p;
+        p.n = n; p.n_pad = std::max(n, min_samples); p.B = k * nbb; p.group = nbb; p.tail = tail;
+        std::vector<int64_t> xrow((size_t)2 * p.B), orow((size_t)8 * p.B);
+        for (int j = 0; j < k; ++j)
+            for (int b = 0; b < nbb; ++b)
+                for (int c = 0; c < 2; ++c) {
+                    const int item = j * nbb + b;
+                    xrow[(size_t)item * 2 + c] = ((int64_t)(b0 + b) * 2 + c) * N + start + j * cs;
+                    for (int t = 0; t < 4; ++t)
+                        orow[((size_t)t * p.B + item) * 2 + c] = (((int64_t)t * nb + b0 + b) * 2 + c) * N + start + j * cs;
+                }
+        xr.push_back(xrow); orw.push_back(orow);
+        fp.passes.push_back(p);
+    };
+    const int64_t full = N / cs;
+    const int S_full = xsq_plan_num_slices(P, std::max(cs, min_samples));
+    // samples per pass: the whole batch when one chunk of it fits a launch, else the largest share that does
+    int nbb_max = std::max(1, std::min(nb, cap / std::max(1, S_full)));
+    XSQ_REQUIRE(!(wiener && nbb_max < nb), "xsq_separator_forward: nb_samples=%d at %d slices per chunk exceeds one pass (%d item-slices) "
+                "and the Wiener-EM window maximum spans the batch (norbert/__init__.py:257): use a smaller chunk_size or batch", nb, S_full, cap);
+    int64_t start = 0;
+    std::vector<std::pair<int, int>> parts;                        // (b0, nbb) sample ranges
+    for (int b0 = 0; b0 < nb; b0 += nbb_max) parts.push_back({b0, std::min(nbb_max, nb - b0)});
+    const int per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(max_stack / std::max(1, nbb_max), cap / ((int64_t)nbb_max * S_full)));
+    while (full - start / cs >= 2 && per_pass >= 2) {
+        const int k = (int)std::min<int64_t>(per_pass, full - start / cs);
+        for (auto& pr : parts) add_pass(start, k, pr.first, pr.second, cs, 0);
+        start += (int64_t)k * cs;
+    }
+    const bool stacked = !fp.passes.empty();
+    for (; start < N; start += cs) {
+        const int64_t n = std::min(cs, N - start);
+        // the sample split of a short chunk follows its own slice count
+        const int S_n = xsq_plan_num_slices(P, std::max(n, min_samples));
+        const int nbb_n = std::max(1, std::min(nb, cap / std::max(1, S_n)));
+        XSQ_REQUIRE(!(wiener && nbb_n < nb), "xsq_separator_forward: nb_samples=%d exceeds one pass with Wiener-EM", nb);
+        for (int b0 = 0; b0 < nb; b0 += nbb_n) add_pass(start, 1, b0, std::min(nbb_n, nb - b0), n, stacked ? 1 : 0);
+    }
+    size_t total = 0;
+    for (auto& p : fp.passes) total += (size_t)10 * p.B;
+    std::vector<int64_t> host(total);
+    XSQ_HIP(hipMalloc(&fp.d_tables, std::max<size_t>(total, 1) * sizeof(int64_t)));
+    size_t o = 0;
+    for (size_t i = 0; i < fp.passes.size(); ++i) {
+        PassPlan& p = fp.passes[i];
+        p.d_xrows = fp.d_tables + o; std::copy(xr[i].begin(), xr[i].end(), host.begin() + o); o += xr[i].size();
+        p.d_orows = fp.d_tables + o; std::copy(orw[i].begin(), orw[i].end(), host.begin() + o); o += orw[i].size();
+        PassLayout L;
+        int rc = pass_layout(d, Mo, p.B, p.n_pad, wiener, &L);
+        if (rc) { (void)hipFree(fp.d_tables); return rc; }
+        size_t& dst = p.tail ? fp.tail_bytes : fp.main_bytes;
+        dst = std::max(dst, L.total);
+    }
+    XSQ_HIP(hipMemcpy(fp.d_tables, host.data(), total * sizeof(int64_t), hipMemcpyHostToDevice));
+    auto ins = d->plans.emplace(key, fp);
+    *out = &ins.first->second;
+    return XSQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xsq_demixer_create(xsq_demixer** out, xsq_plan* plan) {
+    XSQ_REQUIRE(out && plan, "xsq_demixer_create: null argument");
+    xsq_demixer* d = new xsq_demixer();
+    d->plan = plan;
+    for (const BlockHost& b : plan->blocks) { d->F.push_back(b.F); d->T.push_back(b.T); }
+    hipError_t e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("xsq_demixer_create: hipEventCreate -> %s", hipGetErrorString(e));
+        delete d;
+        return XSQ_ERR_HIP;
+    }
+    *out = d;
+    return XSQ_OK;
+}
+
+int xsq_demixer_destroy(xsq_demixer* d) {
+    if (!d) return XSQ_OK;
+    for (auto& kv : d->plans) (void)hipFree(kv.second.d_tables);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+    delete d;
+    return XSQ_OK;
+}
+
+int xsq_demixer_set_max_rows(xsq_demixer* d, int max_item_slices) {
+    XSQ_REQUIRE(d, "xsq_demixer_set_max_rows: null argument");
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->max_item_slices = max_item_slices > 0 ? std::min(max_item_slices, default_max_item_slices(d->plan)) : 0;
+    return XSQ_OK;
+}
+
+size_t xsq_demix_pass_workspace(xsq_demixer* d, const xsq_model* Mo, int B, int64_t n_pad, int wiener) {
+    if (!d || !Mo || B <= 0 || n_pad <= 0) return 0;
+    PassLayout L;
+    return pass_layout(d, Mo, B, n_pad, wiener, &L) ? 0 : L.total;
+}
+
+int xsq_demix_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t* x_rows, int B, int64_t n, int64_t n_pad,
+                   int group, int wiener, float* out, const int64_t* out_rows, void* ws, size_t ws_bytes, void* stream) {
+    XSQ_REQUIRE(d && Mo && x && out && out_rows && ws, "xsq_demix_pass: null argument");
+    XSQ_REQUIRE(B > 0 && n > 0 && n_pad >= n, "xsq_demix_pass: B=%d n=%lld n_pad=%lld", B, (long long)n, (long long)n_pad);
+    if (group <= 0) group = B;
+    XSQ_REQUIRE(B % group == 0, "xsq_demix_pass: group=%d does not divide B=%d", group, B);
+    return run_pass(d, Mo, x, x_rows, B, n, n_pad, group, wiener, out, out_rows, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int xsq_separator_workspace(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t N, int64_t cs, int max_stack, int wiener,
+                            size_t* main_bytes, size_t* tail_bytes) {
+    XSQ_REQUIRE(d && Mo && main_bytes && tail_bytes, "xsq_separator_workspace: null argument");
+    XSQ_REQUIRE(nb > 0 && N > 0 && cs > 0 && max_stack > 0, "xsq_separator_workspace: nb=%d N=%lld chunk_size=%lld max_stack=%d",
+                nb, (long long)N, (long long)cs, max_stack);
+    std::lock_guard<std::mutex> lk(d->mu);
+    ForwardPlan* fp;
+    int rc = get_forward_plan(d, Mo, nb, N, cs, max_stack, wiener ? 1 : 0, &fp);
+    if (rc) return rc;
+    *main_bytes = fp->main_bytes;
+    *tail_bytes = fp->tail_bytes;
+    return XSQ_OK;
+}
+
+int xsq_separator_forward(xsq_demixer* d, xsq_model* Mo, const float* audio, int nb, int64_t N, int64_t cs, int max_stack,
+                          int wiener, int overlap_tail, float* out, void* ws, size_t ws_bytes, void* tail_ws,
+                          size_t tail_ws_bytes, void* stream_, void* tail_stream_) {
+    XSQ_REQUIRE(d && Mo && audio && out && ws, "xsq_separator_forward: null argument");
+    XSQ_REQUIRE(nb > 0 && N > 0 && cs > 0 && max_stack > 0, "xsq_separator_forward: nb=%d N=%lld chunk_size=%lld max_stack=%d",
+                nb, (long long)N, (long long)cs, max_stack);
+    hipStream_t main = (hipStream_t)stream_, side = (hipStream_t)tail_stream_;
+    ForwardPlan* fp;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        int rc = get_forward_plan(d, Mo, nb, N, cs, max_stack, wiener ? 1 : 0, &fp);
+        if (rc) return rc;
+    }
+    bool any_tail = false;
+    for (const PassPlan& p : fp->passes) any_tail = any_tail || p.tail;
+    const bool beside = any_tail && overlap_tail && side != main && tail_ws != nullptr;
+    XSQ_REQUIRE(ws_bytes >= fp->main_bytes && (!beside || tail_ws_bytes >= fp->tail_bytes),
+                "xsq_separator_forward: workspace too small (%zu / %zu needed, %zu / %zu given)", fp->main_bytes, fp->tail_bytes,
+                ws_bytes, tail_ws_bytes);
+    XSQ_REQUIRE(beside || ws_bytes >= std::max(fp->main_bytes, fp->tail_bytes), "xsq_separator_forward: workspace too small for the tail pass");
+    int rc;
+    // The short tail chunks are launch-bound passes, independent of the stacked ones: they go out first, on the side
+    // stream with their own workspace, and fill in beside the big launches; the caller's stream joins at the end.
+    if (beside) {
+        XSQ_HIP(hipEventRecord(d->ev_fork, main));
+        XSQ_HIP(hipStreamWaitEvent(side, d->ev_fork, 0));
+        for (const PassPlan& p : fp->passes)
+            if (p.tail && (rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, tail_ws, tail_ws_bytes, side)))
+                return rc;
+        XSQ_HIP(hipEventRecord(d->ev_join, side));
+    }
+    for (const PassPlan& p : fp->passes)
+        if ((!p.tail || !beside) && (rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, ws, ws_bytes, main)))
+            return rc;
+    if (beside) XSQ_HIP(hipStreamWaitEvent(main, d->ev_join, 0));
+    return XSQ_OK;
+}
+
+}  // extern "C"

@@ -301,14 +301,17 @@ __device__ __forceinline__ void fft_steps_2_3(float2* Z, const float2* __restric
 template <int NT, bool PK = false>
 __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
                                                               const FftTables T, float2* __restrict__ U,
-                                                              int S, int64_t n, int h) {
+                                                              int S, int64_t n, int h,
+                                                              const int64_t* __restrict__ xrows = nullptr) {
 #pragma clang fp contract(off)          // fused multiply-adds only where written (fmaf): same bits from every instantiation
     __shared__ float2 Z[FFT_N];
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
     const int tid = threadIdx.x;
     const int row = blockIdx.x;
     const int bc = row / S, s = row - bc * S;
-    const float* xr = x + (int64_t)bc * n;
+    // packed channel bc starts at x + xrows[bc] (a row of the caller's (nb, 2, N) track: the stacked chunks are read in
+    // place, no packing copy) or, without a table, at x + bc * n
+    const float* xr = x + (xrows ? xrows[bc] : (int64_t)bc * n);
     const int64_t i0 = (int64_t)(2 * s - 2) * h;
     const int part = tid >> 8, m = tid & 255;            // wave-uniform part
     const float2* tw2 = reinterpret_cast<const float2*>(tw);

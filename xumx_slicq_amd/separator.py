@@ -81,7 +81,8 @@ class Separator(nn.Module):
                 int(getattr(self, "max_stack", 8)), int(getattr(self, "pass_streams", 1)),
                 m._version(), tuple(bool(b.realtime) for b in m.sliced_umx), self._fused(),
                 bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")),
-                bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")), self._packed_fft())
+                bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")), self._packed_fft(),
+                bool(getattr(self, "native", os.environ.get("XSQ_NATIVE_FORWARD", "1") != "0")), int(getattr(self, "max_item_slices", 0)))
 
     def drop_graphs(self):
         """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
@@ -114,7 +115,8 @@ class Separator(nn.Module):
             # alive with the graph even if a later, larger call replaces them in their owners
             from . import phase
             keep = (list(self.insgt.nsgt.nsgt._ws.values()) + list(self.nsgt.nsgt.nsgt._ws.values())
-                    + list(self.xumx_model._ws.values()) + list(phase._WS.values()))
+                    + list(self.xumx_model._ws.values()) + list(phase._WS.values())
+                    + list(self.__dict__.get("_nws", {}).values()))
             entry = cache[key] = (graph, static_in, static_out, keep)
         graph, static_in, static_out, _keep = entry
         static_in.copy_(audio_big)
@@ -183,11 +185,109 @@ class Separator(nn.Module):
         if tuple(row_offsets.shape) != (4, audio.shape[0], 2) or row_offsets.dtype != torch.int64:
             raise ValueError(f"row_offsets must be int64 (4, {audio.shape[0]}, 2); got {tuple(row_offsets.shape)}")
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
+        wiener = self._native_mode(audio)
+        if wiener is not None and out.is_contiguous() and out.dtype == torch.float32 and audio.shape[0] % max(1, group) == 0:
+            # one C call per pass (xsq_demix_pass): the zero padding of a short item is a slice count, not a copy
+            from . import _lib
+            if audio.dtype != torch.float32 or not audio.is_contiguous():
+                audio = audio.contiguous().float()
+            dev = audio.device
+            offs = row_offsets if row_offsets.is_contiguous() else row_offsets.contiguous()
+            with torch.cuda.device(dev):
+                model = self.xumx_model._model(dev)
+                d = self.nsgt.nsgt.nsgt.demixer(dev)
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                B, n_pad = audio.shape[0], max(n, min_samples)
+                key = ("pass", B, n_pad, wiener, self.xumx_model._version(), dev.index)
+                nbytes = self.__dict__.setdefault("_nsizes", {}).get(key)
+                if nbytes is None:
+                    nbytes = _lib.lib.xsq_demix_pass_workspace(d, model, B, n_pad, wiener)
+                    if nbytes == 0:
+                        raise _lib.XsqError("xsq_demix_pass_workspace: " + _lib.last_error())
+                    self._nsizes[key] = nbytes
+                ws = self._native_ws(dev, stream, "pass", nbytes)
+                _lib.check(_lib.lib.xsq_demix_pass(d, model, audio.data_ptr(), None, B, n, n_pad, int(group), wiener,
+                                                   out.data_ptr(), offs.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                           "xsq_demix_pass")
+            return
         if n < min_samples:
             audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n), device=audio.device,
                                                   dtype=audio.dtype)], dim=-1)
         Xc, ready = self._encode(audio)
         self._decode_into(out, Xc, n, row_offsets, group=group, xin_ready=ready)
+
+    # -- the native whole-call path ---------------------------------------------------------------------------
+    def _native_mode(self, audio: Tensor):
+        """None when this call has to take the Python chunk loop (an A/B switch is off its default, a mixed or
+        non-stereo model), else the post-filter of the native call: 0 mix-phase, 1 Wiener-EM."""
+        if not getattr(self, "native", os.environ.get("XSQ_NATIVE_FORWARD", "1") != "0"):
+            return None
+        if audio.dim() != 3 or audio.shape[1] != 2 or audio.device.type != "cuda" or audio.shape[-1] < 1:
+            return None
+        if not (getattr(self, "batch_chunks", True) and int(getattr(self, "pass_streams", 1)) == 1
+                and getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")
+                and getattr(self, "fuse_phasemix", os.environ.get("XSQ_FUSE_PHASEMIX", "1") != "0")
+                and getattr(self.xumx_model, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")):
+            return None
+        modes = {bool(b.realtime) for b in self.xumx_model.sliced_umx}
+        if len(modes) != 1:
+            return None
+        return 0 if modes.pop() else 1
+
+    def _native_ws(self, dev: torch.device, stream_ptr: int, which: str, nbytes: int) -> Tensor:
+        """Grow-only workspace of the native path per (device, stream, main | tail).  PyTorch owns the memory."""
+        key = (dev.index, stream_ptr, which)
+        pool = self.__dict__.setdefault("_nws", {})
+        ws = pool.get(key)
+        if ws is None or ws.numel() < nbytes:
+            pool[key] = None
+            ws = pool[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        return ws
+
+    def _tail_stream(self, dev: torch.device):
+        pool = self.__dict__.setdefault("_side_streams", {}).setdefault(dev.index, [])
+        if not pool:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[0]
+
+    def _forward_native(self, audio_big: Tensor, wiener: int) -> Tensor:
+        """``forward`` as ONE C call (xsq_separator_forward, csrc/demix.hip): the stacked full chunks on the caller's
+        stream, the tail chunk beside them on a side stream, the input read and the stems written in place through
+        row-offset tables cached per call shape.  Per call the host allocates the result and makes one ctypes call."""
+        from . import _lib
+        import ctypes as C
+        if audio_big.dtype != torch.float32 or not audio_big.is_contiguous():
+            audio_big = audio_big.contiguous().float()
+        nb, N, dev = audio_big.shape[0], audio_big.shape[-1], audio_big.device
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        eng = self.nsgt.nsgt.nsgt
+        self._packed_fft()
+        with torch.cuda.device(dev):
+            model = self.xumx_model._model(dev)
+            d = eng.demixer(dev)
+            main = torch.cuda.current_stream(dev)
+            overlap = bool(getattr(self, "overlap_tail", True))
+            side = self._tail_stream(dev) if overlap else main
+            cs = int(min(self.chunk_size, 1 << 62))
+            max_stack = int(getattr(self, "max_stack", 8))
+            key = (nb, N, cs, max_stack, wiener, self.xumx_model._version(), dev.index, int(getattr(self, "max_item_slices", 0)))
+            sizes = self.__dict__.setdefault("_nsizes", {}).get(key)
+            if sizes is None:
+                _lib.check(_lib.lib.xsq_demixer_set_max_rows(d, int(getattr(self, "max_item_slices", 0))), "xsq_demixer_set_max_rows")
+                mb, tb = C.c_size_t(), C.c_size_t()
+                _lib.check(_lib.lib.xsq_separator_workspace(d, model, nb, N, cs, max_stack, wiener, C.byref(mb), C.byref(tb)),
+                           "xsq_separator_workspace")
+                sizes = self._nsizes[key] = (mb.value, tb.value)
+            two = overlap and sizes[1] > 0
+            ws = self._native_ws(dev, main.cuda_stream, "main", sizes[0] if two else max(sizes))
+            wt = self._native_ws(dev, main.cuda_stream, "tail", sizes[1]) if two else None
+            out = torch.empty(4, nb, 2, N, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib.xsq_separator_forward(
+                d, model, audio_big.data_ptr(), nb, N, cs, max_stack, wiener, 1 if two else 0, out.data_ptr(),
+                ws.data_ptr(), ws.numel(), wt.data_ptr() if two else None, wt.numel() if two else 0,
+                main.cuda_stream, side.cuda_stream if two else main.cuda_stream), "xsq_separator_forward")
+        return out
 
     @torch.no_grad()
     def forward(self, audio_big: Tensor) -> Tensor:
@@ -197,7 +297,12 @@ class Separator(nn.Module):
         The reference walks the chunks one by one; no state crosses the loop, so here all FULL
         chunks of the call are stacked along the batch axis and run as one pass (the Wiener
         window maximum stays per chunk via ``wiener_batch_group``) -- same numbers, a fifth of the
-        launches.  ``batch_chunks = False`` restores the literal loop."""
+        launches.  By default the whole call is issued by native code (``_forward_native``); the Python
+        loop below is the same schedule spelled through the module API and serves the A/B switches
+        (``native = False``, ``batch_chunks = False`` for the literal loop, ``fuse_* = False``, ...)."""
+        wiener = self._native_mode(audio_big)
+        if wiener is not None:
+            return self._forward_native(audio_big, wiener)
         nb, N, cs = audio_big.shape[0], audio_big.shape[-1], self.chunk_size
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
         dev = audio_big.device

@@ -106,6 +106,19 @@ class SliCQEngine:
             self._handles[idx] = h
         return h
 
+    def demixer(self, device: torch.device):
+        """The native whole-call handle of this plan on ``device`` (xsq_demixer: cached row-offset tables of the call
+        shapes + the fork / join events of the tail stream); what ``Separator.forward`` issues a track through."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        d = self.__dict__.setdefault("_demixers", {}).get(idx)
+        if d is None:
+            h = self.handle(device)
+            out = C.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(_lib.lib.xsq_demixer_create(C.byref(out), h), "xsq_demixer_create")
+            d = self._demixers[idx] = out
+        return d
+
     def workspace(self, device: torch.device, nbytes: int) -> Tensor:
         """Grow-only scratch buffer per (device, stream): calls issued on different streams may overlap
         (Separator.forward runs the tail chunk beside the stacked pass). PyTorch owns the memory."""
@@ -121,6 +134,8 @@ class SliCQEngine:
 
     def __del__(self):
         try:
+            for d in self.__dict__.get("_demixers", {}).values():
+                _lib.lib.xsq_demixer_destroy(d)
             for h in self._handles.values():
                 _lib.lib.xsq_plan_destroy(h)
         except Exception:
@@ -133,12 +148,13 @@ class SliCQEngine:
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k in ("_handles", "_ws") else copy.deepcopy(v, memo)
+            new.__dict__[k] = {} if k in ("_handles", "_ws", "_demixers") else copy.deepcopy(v, memo)
         return new
 
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_handles"], st["_ws"] = {}, {}
+        st.pop("_demixers", None)
         return st
 
     # -- transforms --------------------------------------------------------------
