@@ -210,9 +210,11 @@ def pmc_issue(kernel, tag=None):
             "source": os.path.basename(files[-1])}
 
 
-def cpu_baseline(threads):
-    """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this
-    box's host cores on a bounded sample: one 30 s clip through the same configuration."""
+def cpu_baseline(threads, full=False):
+    """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this box's host cores.  Default:
+    a bounded sample, one 30 s clip through the same configuration (~3 s of host time).  `full` (--cpu-baseline-full):
+    the bench's own 240 s track -- the same workload as `value` (~2 min of host time; the oracle's literal chunk loop,
+    4 full chunks + the tail)."""
     import torch
     from oracle import separator as osep
     from oracle import slicqt as oslicqt
@@ -221,14 +223,17 @@ def cpu_baseline(threads):
     torch.set_num_threads(threads)
     plan = oslicqt.make_plan()
     sd = seeded_state_dict([(F, T) for (_, F, T) in plan.blocks])
-    n = 30 * 44100
-    x = synth_audio(n)
+    n = TRACK_SAMPLES if full else 30 * 44100
+    x = synth_audio(n, seed=20260101)
     osep.separate(plan, sd, x[..., :44100], causal=False, wiener=False)   # warm
     t0 = time.perf_counter()
     osep.separate(plan, sd, x, causal=False, wiener=False)
     dt = time.perf_counter() - t0
+    what = ("the bench's own 240 s stereo track (10,584,000 samples, 5 chunks)" if full
+            else "30 s stereo clip (1,323,000 samples)")
     return {"value": round(n / FS / dt, 3), "unit": "x real-time", "cores": threads, "kind": "port",
-            "sample": "30 s stereo clip (1,323,000 samples), offline conv stack + mix-phase, oracle/ torch-CPU fp32 "
+            "sample_matches_workload": bool(full), "seconds": round(dt, 2),
+            "sample": what + ", offline conv stack + mix-phase, oracle/ torch-CPU fp32 "
                       "(the port, timed here; for comparison only: the reference ITSELF ran this configuration's full "
                       "240 s track at 1.87 x real-time on 8 cores of the build container, BASELINE.md section 2)"}
 
@@ -339,6 +344,8 @@ def main():
     ap.add_argument("--stack", type=int, default=4, help="testset50: work items per round / stacked pass")
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the CPU oracle on the whole 240 s track (the workload of `value`; ~2 min of host time) instead of a 30 s clip")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3"],
                     help="arithmetic of the convolution contractions for the headline value (default: exact fp32)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements outside the timed region")
@@ -519,7 +526,7 @@ def bench_track(args, sep, dev, world, rank, dist):
     if variants:
         result["variants"] = variants
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+        result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1), full=args.cpu_baseline_full)
     return result
 
 

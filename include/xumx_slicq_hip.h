@@ -66,21 +66,23 @@ int xsq_plan_num_blocks(const xsq_plan* plan);
 /* slice-FFT backend: 0 (default) = the hand-written LDS-resident transform when L == 18060
  * (the Bark-262 plan of both pretrained models), rocFFT otherwise; 1 = always rocFFT.     */
 int xsq_plan_set_fft_backend(xsq_plan* plan, int backend);
-/* per-band DFTs: 1 (default) = bands with Lg >= 64 run on the radix-4 kernel (one decimation-in-
+/* per-band DFTs: 1 (default) = bands with Lg >= 24 (163 of the 263 Bark-262 bands, 99 % of the band-DFT flops; the split
+ * point XSQ_D4_MIN_LG_DEFAULT of csrc/slicqt.hip) run on the radix-4 kernel (one decimation-in-
  * frequency stage fused into the operand staging, 4x fewer MFMA flops); 0 = all bands on the
  * dense grouped GEMM.                                                                      */
 int xsq_plan_set_band_radix4(xsq_plan* plan, int on);
-/* inverse transform, bands with Lg < 64 (167 of the 263 Bark-262 bands): 0 (default) = on the dense grouped GEMM;
+/* inverse transform, bands below the radix-4 split (Lg < 24: 100 of the 263 Bark-262 bands): 0 (default) = on the dense grouped GEMM;
  * 1 = synthesised inside the inverse slice-FFT kernel straight from the coefficients (radix-4 stage + 4..15-point
  * codelets, no Z round trip, no dense DFT-matrix GEMM) -- an experiment that measured 0.03-0.05 ms SLOWER per 240 s
  * track (the kernel is bound by its chain of memory / LDS round trips) and is kept as an A/B switch.  Ignored
  * when the plan is not eligible (rocFFT backend, other band lengths).                                       */
 int xsq_plan_set_short_inline(xsq_plan* plan, int on);
 /* hand-written slice FFT only: 1 = its 43 / 14 / 15-point butterflies on packed-fp32 vector instructions (v_pk_fma_f32
- * on the (re, im) register pair: half the vector instructions, bitwise the same results).  Default 0, and meant to be
- * switched on ONLY while no split-bf16 MFMA kernel can run beside the transform (xsq_model_set_precision mode 0): a
- * packed-fp32 transform next to v_mfma_f32_16x16x32_bf16 waves of another stream returned wrong values on MI355X
- * (tools/probe/pk_mfma_hazard.hip).  The Python Separator sets it per call from the model's mode. */
+ * on the (re, im) register pair: half the vector instructions, bitwise the same results).  DIAGNOSTIC builds only
+ * (csrc/Makefile PACKED_FFT=1): the product library does not contain those kernels and returns XSQ_ERR_ARG for on != 0 --
+ * a packed-fp32 transform next to v_mfma_f32_16x16x32_bf16 waves of another stream returned wrong values on MI355X
+ * (tools/probe/pk_mfma_hazard.hip), which no guard at this level can exclude, and it measured no
+ * faster.                                                                                                       */
 int xsq_plan_set_packed_fft(xsq_plan* plan, int on);
 /* table: nblocks x 4 int64 (first_band, F_b, T_b, cum_b) */
 int xsq_plan_block_table(const xsq_plan* plan, int64_t* table);

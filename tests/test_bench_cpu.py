@@ -32,9 +32,11 @@ def test_algorithmic_work_of_the_bench_track():
     # the figures DESIGN.md section 4 quotes (GFLOP per 240 s track)
     assert abs(w["cdae_l2_slab"][1] / 1e9 - 112.3) < 0.5
     assert abs(w["cdae_l1_gemm"][1] / 1e9 - 46.4) < 0.5
-    # radix-4 split point: the bands at or above XSQ_D4_MIN_LG_DEFAULT carry 97 % of the band-DFT flops
+    # radix-4 split point: the bands at or above XSQ_D4_MIN_LG_DEFAULT = 24 carry 99 % of the band-DFT flops
     Lg = np.asarray(plan.Lg, dtype=np.int64)
-    assert abs((Lg[Lg >= 48] ** 2).sum() / (Lg ** 2).sum() - 0.970) < 0.005
+    assert abs((Lg[Lg >= 24] ** 2).sum() / (Lg ** 2).sum() - 0.990) < 0.002 and int((Lg < 24).sum()) == 100
+    src = open(os.path.join(os.path.dirname(bench.__file__), "xumx_slicq_amd", "csrc", "slicqt.hip")).read()
+    assert "#define XSQ_D4_MIN_LG_DEFAULT 24" in src          # the number the header, bench.py and this test quote
 
 
 def test_committed_profiles_fill_the_traffic_and_counter_fields():

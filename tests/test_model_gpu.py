@@ -631,32 +631,24 @@ def test_whitening_fused_into_the_analysis_epilogues_is_bitwise_equal(seps, name
         sep.xumx_model.set_precision("fp32")
 
 
-def test_packed_slice_fft_follows_the_contraction_mode(seps):
-    """The packed-fp32 slice FFT kernels run only while every model of the process contracts in fp32 (beside split-bf16
-    MFMA waves of another stream a packed transform returned wrong values): the separator switches
-    them per call, a bf16 mode anywhere in the process switches them off, and the fp32 stems do not depend on the switch."""
+def test_packed_slice_fft_is_refused_by_the_product_library(seps):
+    """``packed_fft = True`` asks for the packed-fp32 slice FFT kernels; the product library does not contain them (next to
+    split-bf16 MFMA waves of another stream they returned wrong values) and says so."""
+    from xumx_slicq_amd import _lib
     sep = seps["offline_phasemix"]
-    x = synth_audio(200_000, seed=5).cuda()
-    eng = sep.nsgt.nsgt.nsgt
-    b = sep(x).clone()                             # default: scalar kernels
-    assert not eng._packed_fft
-    sep.packed_fft = True                          # opt in
+    x = synth_audio(60_000, seed=5).cuda()
+    b = sep(x).clone()
+    sep.packed_fft = True
     try:
-        a = sep(x).clone()
-        assert sep._packed_fft() and eng._packed_fft and torch.equal(a, b)
-        other = seps["realtime"].xumx_model
-        other.set_precision("bf16x3")              # ANOTHER model of the process goes split-bf16
         try:
-            sep(x)
-            assert not eng._packed_fft
-        finally:
-            other.set_precision("fp32")
-        c = sep(x)
-        assert eng._packed_fft and torch.equal(a, c)
+            a = sep(x)
+        except _lib.XsqError as e:
+            assert "built without the packed-fp32" in str(e)
+        else:                                          # a diagnostic build (XSQ_LIB): same bits
+            assert torch.equal(a, b)
     finally:
         del sep.packed_fft
-        sep(x)
-        assert not eng._packed_fft
+    assert torch.equal(sep(x), b) and not sep.nsgt.nsgt.nsgt._packed_fft
 
 
 @pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener", "realtime"])
@@ -704,3 +696,36 @@ def test_batch_larger_than_one_pass_is_split_over_the_samples(seps):
         sep.chunk_size, sep.max_item_slices = 2621440, 0
         seps["offline_wiener"].chunk_size, seps["offline_wiener"].max_item_slices = 2621440, 0
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["realtime", "offline_wiener"])
+def test_real_audio_through_the_front_end_matches_the_reference(tmp_path, seps, name):
+    """The reference's one real recording (gspi.wav: mono 16-bit PCM) as a file: RIFF decode (audio.load_audio, the
+    reference's torchaudio.load), preprocess_audio (mono -> duplicated stereo, data.py:123-146), inference.separate
+    (inference.py:14-33) -- against the stems of the reference's own front end + Separator on the same samples
+    (tests/golden/stems_gspi.npz, oracle/make_golden_gspi.py), one chunk and three chunks."""
+    import wave
+    from xumx_slicq_amd import audio as A
+    from xumx_slicq_amd.inference import separate
+    g = load_golden("stems_gspi.npz")
+    path = str(tmp_path / "gspi.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(int(g["rate"]))
+        w.writeframes(g["pcm"].astype("<i2").tobytes())
+    sig, rate = A.load_audio(path)
+    assert rate == 44100 and sig.shape == (1, int(g["n"])) and sig.dtype == torch.float32
+    sep = seps[name]
+    try:
+        for cs in (2621440, 100000):
+            sep.chunk_size = cs
+            est, dt = separate(sig, sep, rate=rate, device="cuda")
+            stems = torch.stack([est[t] for t in sep.sources]).cpu()
+            assert stems.shape == (4, 1, 2, int(g["n"])) and dt > 0
+            ref = torch.from_numpy(g[f"{name}_cs{cs}"])
+            d = stems[..., ::int(g["stride"])] - ref
+            rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+            assert rms < RMS_TOL and mx < MAX_TOL, (cs, rms, mx)
+            sums = np.stack([[float(s.double().sum()), float((s.double() ** 2).sum()), float(s.abs().max())] for s in stems])
+            assert np.allclose(sums[:, 1], g[f"{name}_cs{cs}_sums"][:, 1], rtol=1e-4)        # energy of every full stem
+    finally:
+        sep.chunk_size = 2621440

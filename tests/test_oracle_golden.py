@@ -109,3 +109,24 @@ def test_stems_match_reference(oracle_plan, seeded_sd, n, name, causal, wiener):
     rms = float(d.pow(2).mean().sqrt())
     assert rms < 1e-5 and float(d.abs().max()) < 1e-4, (rms, float(d.abs().max()))
     assert float(ref.pow(2).mean().sqrt()) > 1e-2
+
+
+@pytest.mark.parametrize("name,causal,wiener", [("realtime", True, False), ("offline_wiener", False, True)])
+def test_real_audio_stems_match_reference(oracle_plan, seeded_sd, name, causal, wiener):
+    """The one real signal the reference ships (.github/gspi.wav: mono, 16-bit, 262,144 samples) through the
+    reference's own front end and Separator (oracle/make_golden_gspi.py): the oracle on the same decoded samples,
+    one chunk and three chunks of 100,000."""
+    from xumx_slicq_amd.audio import preprocess_audio
+    g = load_golden("stems_gspi.npz")
+    sig = torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0)[None, :]
+    audio = preprocess_audio(sig, 44100, 44100.0)
+    assert audio.shape == (1, 2, int(g["n"])) and torch.equal(audio[0, 0], audio[0, 1])
+    a = audio.double().flatten()
+    assert np.allclose([float(a.sum()), float((a * a).sum()), float(a.abs().max())], g["audio_sums"], rtol=1e-12)
+    for cs in (2621440, 100000):
+        est = osep.separate(oracle_plan, seeded_sd, audio, causal=causal, wiener=wiener, chunk_size=cs)
+        ref = torch.from_numpy(g[f"{name}_cs{cs}"])
+        d = est[..., ::int(g["stride"])] - ref
+        rms = float(d.pow(2).mean().sqrt())
+        assert rms < 1e-5 and float(d.abs().max()) < 1e-4, (cs, rms, float(d.abs().max()))
+        assert float(ref.pow(2).mean().sqrt()) > 1e-3

@@ -61,3 +61,18 @@ def test_hand_packed_transform_is_exact_next_to_the_fp32_aggressors(tmp_path):
     for name, bad, _ in packed:
         if name.replace("aggressor ", "").strip() in fp32_side:
             assert bad == 0, out
+
+
+def test_buffer_range_check_covers_the_scalar_offset(tmp_path):
+    """common.h's buffer loads / stores (layer-1 / layer-4 operands, the wide-store epilogues, band_dft4.h) switch rows and
+    columns off by an out-of-range offset and put tile displacements into the SCALAR offset: that is only right if the
+    hardware checks voffset + soffset against num_records as one sum, returns 0 for loads past it and drops stores there.
+    tools/probe/buf_range.hip asserts exactly that on this device (incl. soffset alone past the range)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available on this box")
+    exe = str(tmp_path / "buf_range")
+    subprocess.run([HIPCC, "-O2", "-w", "--offload-arch=gfx950", os.path.join(ROOT, "tools", "probe", "buf_range.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, timeout=120, text=True)
+    print("\n" + r.stdout)
+    assert r.returncode == 0 and "ALL AS RELIED ON" in r.stdout and "UNEXPECTED" not in r.stdout, r.stdout

@@ -116,7 +116,7 @@ def test_rocfft_and_lds_fft_backends_agree(fb, oracle_plan):
 
 
 def test_radix4_band_kernel_matches_dense_gemm(fb, oracle_plan):
-    """Bands with Lg >= 48 run on the radix-4 DFT kernel by default; the dense grouped GEMM is the
+    """Bands with Lg >= 24 (XSQ_D4_MIN_LG_DEFAULT) run on the radix-4 DFT kernel by default; the dense grouped GEMM is the
     reference implementation of the same sums."""
     from oracle import slicqt as O
     base, enc, dec = fb
@@ -181,13 +181,18 @@ def test_short_bands_in_kernel_equal_the_dense_gemm_path(fb, n, lead):
     assert bool(torch.isnan(out[0])) and bool(torch.isnan(out[1 + n - 1: 1 + n + 3]).all())
 
 
-def test_packed_butterflies_are_bitwise_the_scalar_ones(fb):
-    """k_slice_rfft<512, true> / k_slice_irfft<512, true> (43 / 14 / 15-point butterflies on hand-placed v_pk_fma_f32 /
-    v_pk_add_f32, slice_fft.h) against the scalar kernels: every lane of a packed instruction is the IEEE operation of its
-    scalar twin, in the same order -- coefficients and reconstructed audio must agree bit for bit, at several sizes
-    (edge slices, interior slices, odd lengths)."""
+def test_packed_butterflies_are_a_diagnostic_build_only(fb):
+    """The packed-fp32 slice FFT kernels (k_slice_rfft<512, true> / k_slice_irfft<512, true>, slice_fft.h) are not part of
+    the product library: xsq_plan_set_packed_fft(1) is refused with a message.  A diagnostic build (make PACKED_FFT=1,
+    selected through XSQ_LIB) accepts it, and there the packed kernels must be bitwise the scalar ones."""
+    from xumx_slicq_amd import _lib
     base, enc, dec = fb
     eng = base.nsgt
+    try:
+        eng.set_packed_fft(True)
+    except _lib.XsqError as e:
+        assert "built without the packed-fp32" in str(e) and not eng._packed_fft
+        return
     try:
         for n in (9031, 70001, 300_000):
             x = synth_audio(n, seed=7 + n).cuda()

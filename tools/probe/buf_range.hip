@@ -12,7 +12,8 @@ __global__ void k(float* p, float* out, int records, int voff, int soff) {
 }
 int main() {
     float *p, *o; hipMalloc(&p, 4096); hipMalloc(&o, 16);
-    float h[1024]; 
+    float h[1024];
+    int bad = 0;
     struct { int rec, vo, so; const char* what; } cases[] = {
         {64, 0, 0, "in range"}, {64, 128, 0, "voffset past the range"}, {64, 0, 128, "scalar offset past the range"},
         {64, 32, 48, "voffset + scalar offset past the range, each inside"}, {64, 60, 0, "last dword"}, {64, 64, 0, "first dword past"}};
@@ -24,6 +25,12 @@ int main() {
         const int idx = (c.vo + c.so) / 4;
         printf("num_records %d, voffset %d, soffset %d (%s): load returned %g (memory holds %d), store %s\n", c.rec, c.vo, c.so, c.what,
                got, idx, h[idx] == 777.f ? "WRITTEN" : "dropped");
+        // what common.h's buf_ld* / buf_st* rely on (cdae.hip epilogues, band_dft4.h): voffset + soffset is checked
+        // against num_records as ONE sum; inside -> the access happens, past it -> the load returns 0 and the store is dropped
+        const bool inside = c.vo + c.so + 4 <= c.rec;
+        const bool ok = inside ? (got == (float)idx && h[idx] == 777.f) : (got == 0.f && h[idx] == (float)idx);
+        if (!ok) { printf("UNEXPECTED\n"); ++bad; }
     }
-    return 0;
+    printf("%s\n", bad ? "FAILED" : "ALL AS RELIED ON");
+    return bad ? 1 : 0;
 }

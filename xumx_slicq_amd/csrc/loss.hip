@@ -108,13 +108,17 @@ __global__ void k_loss_combine(const double* __restrict__ partial, const int* __
 
 using namespace xsq;
 
-// work tables of one (block table, B, S): built once, resident (the step must not wait for the host in mid-flight)
+// work tables of one (device, block table, B, S): built once on first use -- a synchronous upload, so a shape has to be warmed up
+// before it is captured in a graph -- and resident for the life of the process (a few KB per shape; the step must not wait
+// for the host in mid-flight)
 struct LossTables { LossWork* d_work = nullptr; double* d_inv = nullptr; int* d_first = nullptr; int nwork = 0; };
 static std::mutex g_loss_mu;
 static std::map<std::vector<int>, LossTables> g_loss_tables;
 
 static int loss_tables(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, LossTables* out) {
-    std::vector<int> key{nblocks, Bn, S};
+    int dev = 0;
+    XSQ_HIP(hipGetDevice(&dev));                 // the tables live in one device's memory: keyed by it
+    std::vector<int> key{dev, nblocks, Bn, S};
     for (int b = 0; b < nblocks; ++b) { key.push_back(F[b]); key.push_back(T[b]); }
     std::lock_guard<std::mutex> lk(g_loss_mu);
     auto it = g_loss_tables.find(key);

@@ -802,6 +802,13 @@ extern "C" int xsq_debug_fft_stamps(unsigned long long* host, int rows) {
 
 int xsq_plan_set_packed_fft(xsq_plan* P, int on) {
     XSQ_REQUIRE(P, "xsq_plan_set_packed_fft: null plan");
+#if !XSQ_PACKED_FFT_KERNELS
+    // The product library does not contain the packed-fp32 transform: next to v_mfma_f32_16x16x32_bf16 waves of another
+    // stream it returned wrong values (tools/probe/pk_mfma_hazard.hip, cause below the ISA), no guard at this level can
+    // see what other streams or a later precision switch put beside it, and it measured no faster.
+    XSQ_REQUIRE(!on, "xsq_plan_set_packed_fft: this library is built without the packed-fp32 slice FFT kernels "
+                "(diagnostic build: make PACKED_FFT=1)");
+#endif
     P->packed_fft = on ? 1 : 0;
     return XSQ_OK;
 }
@@ -885,8 +892,11 @@ int xsq_slicqt_forward_rows(xsq_plan* P, const float* x, const int64_t* x_rows, 
     }
     if (lds_fft(P)) {
         XSQ_PROF("slice_rfft", stream);
+#if XSQ_PACKED_FFT_KERNELS
         if (fft_threads(0) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_rfft<512, true>), dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
-        else if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
+        else
+#endif
+        if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
         else hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
     } else {
         { XSQ_PROF("slice_window", stream);
@@ -1005,10 +1015,13 @@ static int inverse_impl(xsq_plan* P, const float* coef, const float* mask, int B
             const bool sh = SS.n1 > 0;
             bool fast4 = !sh && fft_threads(1) == 512 && G.tgt16 != nullptr && !getenv("XSQ_FFT_GATHER2");
             for (int ph = 0; ph < 4; ++ph) fast4 = fast4 && (G.begin[ph + 1] - (G.lo[ph] & ~1) <= 2 * 512 * ((4864 / 2 + 1 + 511) / 512));
+#if XSQ_PACKED_FFT_KERNELS
             if (fast4 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
-            else if (fast4) hipLaunchKernelGGL((k_slice_irfft<512, false, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else if (!fast4 && !sh && fft_threads(1) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
+            else
+#endif
+            if (fast4) hipLaunchKernelGGL((k_slice_irfft<512, false, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else if (fft_threads(1) == 512 && sh) hipLaunchKernelGGL((k_slice_irfft<512, false, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
-            else if (fft_threads(1) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_irfft<512, true>), dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else if (fft_threads(1) == 512) hipLaunchKernelGGL(k_slice_irfft<512>, dim3(BC * nsl), dim3(512), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else if (sh) hipLaunchKernelGGL((k_slice_irfft<256, false, true>), dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);
             else hipLaunchKernelGGL(k_slice_irfft<256>, dim3(BC * nsl), dim3(256), 0, stream, (const float2*)Z, G, fft_tables(P), O, SS, SI);

@@ -764,6 +764,12 @@ static int train_build(xsq_train* Tr, int nblocks, const int32_t* F, const int32
 int xsq_train_create(xsq_train** out, int nblocks, const int32_t* F, const int32_t* T, int causal, const float* params,
                      int64_t nparams) {
     XSQ_REQUIRE(out && F && T && params && nblocks > 0, "xsq_train_create: null argument");
+    // the step runs the Wiener-EM from the masks (xsq_wiener_em_masked: two frames per thread), which needs an even frame
+    // count S * T_b in every block for any S: refuse other plans here, with the reason, instead of failing a step later
+    // (every plan nsgfwin builds has T_b = 4 k, nsgt/nsgfwin_sl.py:70-72)
+    for (int b = 0; b < nblocks; ++b)
+        XSQ_REQUIRE(T[b] % 2 == 0, "xsq_train_create: block %d has an odd T = %d; the training step needs even band lengths "
+                    "(Wiener-EM from the masks processes two frames per thread)", b, T[b]);
     xsq_train* Tr = new xsq_train();
     int rc = train_build(Tr, nblocks, F, T, causal, params, nparams);
     if (!rc && hipStreamCreateWithFlags(&Tr->side, hipStreamNonBlocking) != hipSuccess) rc = XSQ_ERR_HIP;

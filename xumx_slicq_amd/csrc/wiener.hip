@@ -532,6 +532,9 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restri
 // ------------------------------------------------------------------------------------------------
 static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, int group, WTable* out) {
     std::vector<int> key;
+    int dev = 0;
+    XSQ_HIP(hipGetDevice(&dev));                 // the tables live in one device's memory: keyed by it
+    key.push_back(dev);
     key.push_back(nblocks); key.push_back(Bn); key.push_back(S); key.push_back(win_len); key.push_back(group);
     for (int b = 0; b < nblocks; ++b) { key.push_back(F[b]); key.push_back(T[b]); }
     std::lock_guard<std::mutex> lk(g_wmu);

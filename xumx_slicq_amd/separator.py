@@ -124,15 +124,19 @@ class Separator(nn.Module):
         return static_out
 
     def _packed_fft(self) -> bool:
-        """Packed-fp32 butterflies in the slice FFTs (``packed_fft = True`` / XSQ_PACKED_FFT=1; bitwise the scalar ones at
-        half the butterflies' vector instructions).  OFF by default: measured, they change nothing -- the transforms are
-        bound by their HBM phases (band-spectrum gather 0.31 ms, output / overlap-add 0.15 ms of the inverse's 0.66 ms; the
-        43 / 14 / 15-point butterflies together 0.11 ms).  When asked for, they run only while no model
-        or trainer of this process contracts on split-bf16 MFMAs: next to v_mfma_f32_16x16x32_bf16 waves of another stream
-        the packed transform returns wrong values (tools/probe/pk_mfma_hazard.hip)."""
+        """Packed-fp32 butterflies in the slice FFTs: a DIAGNOSTIC build option (csrc/Makefile PACKED_FFT=1), not part of
+        the product library -- measured, they change nothing (the transforms are bound by their HBM phases, DESIGN.md
+        section 4) and next to v_mfma_f32_16x16x32_bf16 waves of another stream the packed transform returned wrong values
+        (tools/probe/pk_mfma_hazard.hip).  ``packed_fft = True`` / XSQ_PACKED_FFT=1 asks the library for them; the product
+        build refuses with ``XsqError``.  A diagnostic build honours it only while no model or trainer of this process
+        contracts on split-bf16 MFMAs."""
+        want = bool(getattr(self, "packed_fft", os.environ.get("XSQ_PACKED_FFT", "0") != "0"))
+        eng = self.nsgt.nsgt.nsgt
+        if not want and not eng._packed_fft:
+            return False
         from .model import split_bf16_active
-        on = bool(getattr(self, "packed_fft", os.environ.get("XSQ_PACKED_FFT", "0") != "0")) and not split_bf16_active()
-        self.nsgt.nsgt.nsgt.set_packed_fft(on)
+        on = want and not split_bf16_active()
+        eng.set_packed_fft(on)
         self.insgt.nsgt.nsgt.set_packed_fft(on)
         return on
 

@@ -64,15 +64,15 @@ class SliCQEngine:
 
     def set_packed_fft(self, on: bool):
         """True: the hand-written slice FFT runs its butterflies on packed-fp32 vector instructions (half the vector
-        instructions, bitwise the same results).  Off by default; ``Separator`` switches it on per call while every model
-        of the process runs its contractions in fp32 -- a packed-fp32 transform next to split-bf16 MFMA waves of another
-        stream returned wrong values on MI355X."""
+        instructions, bitwise the same results).  Diagnostic builds only (csrc/Makefile PACKED_FFT=1): the product library
+        refuses (``XsqError``) -- a packed-fp32 transform next to split-bf16 MFMA waves of another stream returned wrong
+        values on MI355X and it measured no faster."""
         on = bool(on)
         if on == getattr(self, "_packed_fft", False):
             return
-        self._packed_fft = on
         for h in self._handles.values():
             _lib.check(_lib.lib.xsq_plan_set_packed_fft(h, int(on)), "xsq_plan_set_packed_fft")
+        self._packed_fft = on
 
     def set_short_inline(self, on: bool):
         """False (default): bands with Lg < 24 on the dense GEMM with a round trip through the workspace; True: the inverse
