@@ -354,6 +354,10 @@ def main():
     ap.add_argument("--gather-at-1", action="store_true",
                     help="testset50 on ONE rank with the exchange machinery on (process group of one rank on nccl, exchange "
                          "blocks, one-rank all-gather, placement launches): what packing + placement cost without any link")
+    ap.add_argument("--exchange", default="sendrecv", choices=["sendrecv", "allgather"],
+                    help="testset50: how the stems reach every rank -- sendrecv (default): every rank keeps the same flat per-track "
+                         "layout, kernels write their rows in place, one grouped RCCL send/recv per pass moves rows owner -> peers "
+                         "(xsq_exchange_rows); allgather: in-place all_gather_into_tensor per pass + one placement launch per exchange")
     ap.add_argument("--no-gather", action="store_true",
                     help="testset50: headline without the all-gather (default: with it; the other one is a variant)")
     args = ap.parse_args()
@@ -703,7 +707,7 @@ def bench_testset(args, sep, dev, world, rank, dist):
     gather = not args.no_gather
     if world == 1 and args.gather_at_1:
         gather = "always"
-    dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack)
+    dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange=args.exchange)
     gather = dmx.gather
     for q in dmx.plan.rounds:
         for p in q[rank]:
@@ -724,7 +728,7 @@ def bench_testset(args, sep, dev, world, rank, dist):
     if not args.no_variants:
         # (a) the same step with the other exchange setting
         if world > 1:
-            other = ShardedDemixer(sep, lengths, get_chunk, dev, gather=not gather, stack=args.stack)
+            other = ShardedDemixer(sep, lengths, get_chunk, dev, gather=not gather, stack=args.stack, exchange=args.exchange)
             for _ in range(max(1, args.warmup)):
                 other.run()
             dto, _ = timed_steps(other.run, args.steps, world, dist, dev)
@@ -734,6 +738,17 @@ def bench_testset(args, sep, dev, world, rank, dist):
                 "value": round(args.steps * total_s / dto, 2), "unit": "x real-time", "ms_per_step": round(dto / args.steps * 1e3, 3)}
             other_ms = dto / args.steps * 1e3
             del other
+        # (a2) the same step through the OTHER exchange (A/B of the two forms of the waveform concat)
+        if (world > 1 or dmx.gather) and gather:
+            alt_name = "allgather" if args.exchange == "sendrecv" else "sendrecv"
+            alt = ShardedDemixer(sep, lengths, get_chunk, dev, gather=("always" if world == 1 else True), stack=args.stack, exchange=alt_name)
+            for _ in range(max(1, args.warmup)):
+                alt.run()
+            dta, _ = timed_steps(alt.run, args.steps, world, dist, dev)
+            variants["exchange_" + alt_name] = {
+                "what": "the same step with exchange = %s (%s)" % (alt_name, EXCHANGE_WHAT[alt_name]),
+                "value": round(args.steps * total_s / dta, 2), "unit": "x real-time", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+            del alt
         # (b) the whole set on rank 0 alone: the single-GPU rate on the SAME workload
         if world > 1:
             dist.barrier()
@@ -788,8 +803,7 @@ def bench_testset(args, sep, dev, world, rank, dist):
                                                               "norbert Wiener-EM niter=1" if args.wiener else "Wiener off (mix-phase)"),
                    "parallelism": "chunk items dealt longest-first to %d rank(s) (imbalance %.4f), %d items per stacked round, %s"
                                   % (world, dmx.plan.imbalance(), args.stack,
-                                     ("in-place RCCL all_gather_into_tensor of the stems per pass kind and round (%.1f GB per step to every rank), "
-                                      "overlapped with the next pass's kernels, then one placement launch per exchange into per-track tensors" % stems_gb)
+                                     ("%.1f GB of stems per step to every rank; %s" % (stems_gb, EXCHANGE_WHAT[dmx.exchange]))
                                      if dmx.gather else "no data-path collective")},
         "roofline": roofline,
         "roofline_hbm": hbm,
@@ -802,6 +816,10 @@ def bench_testset(args, sep, dev, world, rank, dist):
     return result
 
 
+EXCHANGE_WHAT = {"sendrecv": "sendrecv-inplace: same flat per-track layout on every rank, kernels write their rows in place, one grouped "
+                             "ncclSend / ncclRecv per pass kind and round moves rows owner -> peers at identical offsets (xsq_exchange_rows)",
+                 "allgather": "allgather+place: in-place all_gather_into_tensor per pass kind and round, async beside the next pass; "
+                              "one xsq_place_rows launch per exchange"}
 XGMI_LINK_GBPS = 153.0            # MI355X_MICROARCH.md: 7 point-to-point xGMI links per GPU, ~153 GB/s each way
 
 
@@ -819,6 +837,10 @@ def collective_block(dmx, dist, world, rank, dev, step_ms, other_ms, gather):
         return None
     acct = dmx.plan.exchange_bytes() if dmx.gather else {"collectives_per_step": 0, "bytes_in_per_rank_per_step": 0,
                                                           "stem_bytes_in_per_rank_per_step": 0, "largest_collective_bytes_per_rank": 0}
+    if dmx.gather and getattr(dmx, "exchange", "allgather") == "sendrecv":
+        # rows travel as they are: no padding of ragged blocks, the wire bytes ARE the stems of the other ranks
+        acct = dict(acct, bytes_in_per_rank_per_step=acct["stem_bytes_in_per_rank_per_step"],
+                    largest_collective_bytes_per_rank=max((int(t[:, 3].sum()) * 4 for t in dmx._xtable.values()), default=0))
     backend = dist.get_backend()
     try:
         ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
@@ -828,7 +850,8 @@ def collective_block(dmx, dist, world, rank, dev, step_ms, other_ms, gather):
     links = max(1, world - 1)
     return {"backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged functional path, not a measurement of xGMI)"),
             "world": world, "devices": devices, "nccl_version": ver,
-            "op": "in-place all_gather_into_tensor per pass kind and round, async beside the next pass; one xsq_place_rows launch per exchange",
+            "exchange": "sendrecv-inplace" if getattr(dmx, "exchange", "allgather") == "sendrecv" else "allgather+place",
+            "op": EXCHANGE_WHAT[getattr(dmx, "exchange", "allgather")],
             **acct,
             "step_ms_with_gather": round(with_ms, 3) if with_ms is not None else None,
             "step_ms_without_gather": round(without_ms, 3) if without_ms is not None else None,

@@ -221,6 +221,28 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
  * max_len = the largest row length (sizes the grid).  Rows must not overlap in dst.                     */
 int xsq_place_rows(const float* src, float* dst, const int64_t* table, int nrows, int64_t max_len, void* stream);
 
+/* ---- in-place exchange of stems between the ranks of the sharded path (RCCL over xGMI) -------------------------------
+ * The form of "the final waveform concat" (separator.py:229-231 across ranks) that needs no packing buffer and no
+ * placement pass: every rank holds the SAME flat per-track layout, its kernels write the rows it owns in place
+ * (xsq_demix_pass through out_rows), and ONE grouped ncclSend / ncclRecv per pass moves every row owner -> peers at
+ * identical offsets -- point to point, one xGMI link per peer.
+ *   xsq_comm_load       resolve RCCL from the library the process already uses (path of torch's librccl.so; NULL: by name)
+ *   xsq_comm_unique_id  rank 0: 128 bytes to hand to every rank (torch.distributed broadcast)
+ *   xsq_comm_create     ncclCommInitRank on the CURRENT device -- collective over the ranks
+ *   xsq_exchange_rows   rows: HOST int64[nrows][4] = (owner rank, src float offset, dst float offset, length), the same
+ *                       table on every rank; the owner sends src + src_off to every peer, every other rank receives into
+ *                       dst + dst_off (src == dst and equal offsets: in place).  One ncclGroupStart ... ncclGroupEnd on
+ *                       `stream`, asynchronous.  self_loop != 0 (tests, group of one): the owner also sends to ITSELF and
+ *                       receives into dst -- src and dst must then not overlap.                                       */
+typedef struct xsq_comm xsq_comm;
+int xsq_comm_load(const char* librccl_path);
+int xsq_comm_version(void);                                                /* ncclGetVersion code, -1 on error */
+int xsq_comm_unique_id(void* id128);
+int xsq_comm_create(xsq_comm** out, const void* id128, int world, int rank);
+int xsq_comm_destroy(xsq_comm* comm);
+int xsq_exchange_rows(xsq_comm* comm, const float* src, float* dst, const int64_t* rows, int nrows, int self_loop,
+                      void* stream);
+
 /* The same EM iteration fed by the MASKS (real arena, 8*B channels: what xsq_cdae_forward writes with Y = NULL): the
  * initial estimate y0 = mask * x (model.py:262-264 -> phase.py:96-113; == mask * X) is formed
  * while both passes load, so the CDAE's last layer stores 4 instead of 8 bytes per coefficient and the statistics pass

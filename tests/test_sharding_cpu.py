@@ -138,11 +138,17 @@ def _worker(rank, world, port, q):
         # stacked rounds + one all-gather per round + placement (what bench.py --gpus N runs)
         get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
         lens = [x.shape[-1] for x in tracks]
-        dmx = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2)
         ok_dmx = True
-        for _ in range(2):                                       # buffers are reused across steps
-            got = dmx.run()
-            ok_dmx = ok_dmx and all(torch.equal(got[t], ref[t]) for t in ref)
+        for exchange in ("allgather", "sendrecv"):               # all-gather + placement | rows in place, owner -> peers
+            dmx = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange=exchange)
+            for _ in range(2):                                   # buffers are reused across steps
+                got = dmx.run()
+                ok_dmx = ok_dmx and all(torch.equal(got[t], ref[t]) for t in ref)
+            # the in-place exchange's table: every row of every item once, owned by the rank the plan gave the item to
+            if exchange == "sendrecv":
+                rows = sum((dmx._xtable[key].tolist() for key in dmx.plan.exchanges()), [])
+                ok_dmx = ok_dmx and len(rows) == 8 * sum(len(q_) for q_ in dmx.plan.queues)
+                ok_dmx = ok_dmx and sum(r[3] for r in rows) == 8 * sum(lens) and all(r[1] == r[2] for r in rows)
         own = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, gather=False).run()
         mine2 = [p.item for rnd in dmx.plan.rounds for p in rnd[rank]]
         ok_dmx = ok_dmx and sorted(mine2, key=lambda i: (i.track, i.chunk)) == sorted(mine, key=lambda i: (i.track, i.chunk))

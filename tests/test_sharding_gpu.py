@@ -89,7 +89,7 @@ def test_place_rows_moves_ragged_rows_bitwise():
         _lib.check(_lib.lib.xsq_place_rows(None, dst.data_ptr(), table.data_ptr(), 1, 4, _lib.stream_ptr()), "xsq_place_rows")
 
 
-def _worker(rank, world, port, q, backend="gloo", gather=True):
+def _worker(rank, world, port, q, backend="gloo", gather=True, exchange="sendrecv"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     # gloo: both ranks share device 0 (the functional path of a 1-GPU box); nccl (= RCCL): one rank per device
@@ -110,8 +110,8 @@ def _worker(rank, world, port, q, backend="gloo", gather=True):
             tracks = _tracks(dev)
             ref = _reference(sep, tracks)
             get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
-            dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=2, gather=gather)
-            assert dmx.world == world and dmx.gather
+            dmx = ShardedDemixer(sep, LENGTHS, get, dev, stack=2, gather=gather, exchange=exchange)
+            assert dmx.world == world and dmx.gather and dmx.exchange == exchange
             for step in range(2):
                 out = dmx.run()
                 torch.cuda.synchronize()
@@ -133,14 +133,14 @@ def _worker(rank, world, port, q, backend="gloo", gather=True):
         dist.destroy_process_group()
 
 
-def _run_ranks(world, backend, gather=True):
+def _run_ranks(world, backend, gather=True, exchange="sendrecv"):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, gather)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, gather, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in procs)
@@ -149,24 +149,64 @@ def _run_ranks(world, backend, gather=True):
     assert res == [(r, "ok") for r in range(world)], res
 
 
-def test_two_ranks_all_gather_and_place_bitwise():
-    _run_ranks(2, "gloo")
+EXCHANGES = ["sendrecv", "allgather"]        # in-place grouped send / recv (default) | all-gather + placement (fallback)
 
 
-def test_rccl_group_of_one_runs_the_collective_path():
+@pytest.mark.parametrize("exchange", EXCHANGES)
+def test_two_ranks_exchange_bitwise(exchange):
+    _run_ranks(2, "gloo", exchange=exchange)
+
+
+@pytest.mark.parametrize("exchange", EXCHANGES)
+def test_rccl_group_of_one_runs_the_collective_path(exchange):
     """What a 1-GPU box CAN execute of the RCCL branch: a process group of one rank on backend nccl with ``device_id``
-    set, ``ShardedDemixer(gather="always")`` -- communicator creation, the in-place ``all_gather_into_tensor`` issued
-    asynchronously behind the kernels, the place stream's wait on its work handle, ``xsq_place_rows`` -- bitwise equal to
-    the single-process chunk loop, mix-phase and Wiener-EM.  (Several ranks: the test below, wherever >= 2 devices exist.)"""
-    _run_ranks(1, "nccl", gather="always")
+    set, ``ShardedDemixer(gather="always")``.  allgather: communicator creation, the in-place ``all_gather_into_tensor``
+    issued asynchronously behind the kernels, the place stream's wait on its work handle, ``xsq_place_rows``.  sendrecv:
+    the library's own communicator (xsq_comm_create on torch's librccl), kernels writing their rows in place, one
+    grouped exchange per pass on the exchange stream.  Bitwise equal to the single-process chunk loop, mix-phase and
+    Wiener-EM.  (Several ranks: the test below, wherever >= 2 devices exist.)"""
+    _run_ranks(1, "nccl", gather="always", exchange=exchange)
 
 
-def test_rccl_ranks_all_gather_and_place_bitwise():
+def test_rccl_self_loop_moves_rows_bitwise():
+    """xsq_exchange_rows through RCCL on ONE device: a communicator of one rank, every row sent to the rank itself and
+    received into a second buffer (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the caller's stream) -- ragged
+    rows of odd offsets and lengths arrive bit for bit, untouched spans stay untouched, bad tables are refused."""
+    import numpy as np
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.sharding import RowExchange
+    dev = torch.device("cuda", 0)
+    rx = RowExchange(dev, world=1, rank=0)
+    assert rx.comm is not None and rx.version() > 20000
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(3_000_000, generator=g).to(dev)
+    dst = torch.full((3_000_000,), -7.0, device=dev)
+    rows = np.asarray([(0, 0, 5, 1), (0, 17, 1001, 333_333), (0, 1_000_001, 400_003, 2_000_000 - 13), (0, 9, 9, 0)], dtype=np.int64)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        rx.exchange(src, rows, dst=dst, self_loop=True)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    want = torch.full((3_000_000,), -7.0, device=dev)
+    for _, so, do, n in rows.tolist():
+        want[do:do + n] = src[so:so + n]
+    assert torch.equal(dst, want)
+    bad = np.asarray([(3, 0, 0, 4)], dtype=np.int64)
+    with pytest.raises(_lib.XsqError, match="owner"):
+        rx.exchange(src, bad, dst=dst, self_loop=True)
+    rx.close()
+
+
+@pytest.mark.parametrize("exchange", EXCHANGES)
+def test_rccl_ranks_exchange_bitwise(exchange):
     """The exchange as it ships: one rank per device, backend nccl (= RCCL over xGMI), ``device_id`` set, the real
-    Separator through ``ShardedDemixer(gather=True)`` -- in-place all-gather per pass kind and round, one placement
-    launch per exchange -- bitwise equal to the single-process chunk loop, mix-phase and Wiener-EM.  Switches itself
-    on wherever two or more devices are visible (the 1-GPU test box skips it: RCCL refuses two ranks on one device)."""
+    Separator through ``ShardedDemixer(gather=True)`` -- sendrecv: kernels write their rows of the shared flat layout in
+    place, one grouped ncclSend / ncclRecv per pass kind and round moves them owner -> peers; allgather: in-place
+    all-gather per pass kind and round + one placement launch per exchange -- bitwise equal to the single-process chunk
+    loop, mix-phase and Wiener-EM.  Switches itself on wherever two or more devices are visible (the 1-GPU test box skips
+    it: RCCL refuses two ranks on one device)."""
     n = torch.cuda.device_count()                # does not initialise the GPU in this (parent) process
     if n < 2:
         pytest.skip(f"needs >= 2 devices for RCCL (found {n}); the same path runs over gloo in the test above")
-    _run_ranks(min(n, 8), "nccl")
+    _run_ranks(min(n, 8), "nccl", exchange=exchange)

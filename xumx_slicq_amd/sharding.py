@@ -181,6 +181,78 @@ def all_gather_stems(recv: Tensor, send: Tensor, group=None, async_op: bool = Tr
     return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
 
 
+class RowExchange:
+    """In-place exchange of stem rows between the ranks: every rank holds the same flat layout, the owner of a row sends it
+    to every peer at the same offset (``xsq_exchange_rows``: one grouped ncclSend / ncclRecv per call on the current
+    stream -- RCCL over xGMI, one point-to-point link per peer, no packing buffer, no placement pass).  The communicator is
+    the library's own (``xsq_comm_create``: ncclCommInitRank with an id handed round through ``torch.distributed``), on
+    the RCCL build torch already loaded.  With the ``gloo`` backend -- CPU tests, two ranks sharing the one GPU of a test
+    box -- the same rows travel as host-staged broadcasts (functional path only)."""
+
+    def __init__(self, device: torch.device, group=None, world: Optional[int] = None, rank: Optional[int] = None):
+        self.dev, self.group = torch.device(device), group
+        live = dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
+        self.backend = dist.get_backend(group) if live else "none"
+        self.comm = None
+        if self.dev.type == "cuda" and self.backend != "gloo":
+            import ctypes as C
+            import os
+            from . import _lib
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            _lib.check(_lib.lib.xsq_comm_load(path.encode() if os.path.exists(path) else None), "xsq_comm_load")
+            uid = C.create_string_buffer(128)
+            if self.rank == 0:
+                _lib.check(_lib.lib.xsq_comm_unique_id(uid), "xsq_comm_unique_id")
+            if self.world > 1:
+                box = [uid.raw]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = C.create_string_buffer(box[0], 128)
+            out = C.c_void_p()
+            with torch.cuda.device(self.dev):
+                _lib.check(_lib.lib.xsq_comm_create(C.byref(out), uid, self.world, self.rank), "xsq_comm_create")
+            self.comm = out
+
+    def version(self):
+        from . import _lib
+        return _lib.lib.xsq_comm_version() if self.comm is not None else None
+
+    def exchange(self, flat: Tensor, table, dst: Optional[Tensor] = None, self_loop: bool = False):
+        """table: numpy int64 (nrows, 4) = (owner, src offset, dst offset, length), identical on every rank.  Asynchronous
+        on the current stream (RCCL); ``dst`` defaults to ``flat`` (in place)."""
+        dst = flat if dst is None else dst
+        if self.comm is not None:
+            from . import _lib
+            _lib.check(_lib.lib.xsq_exchange_rows(self.comm, flat.data_ptr(), dst.data_ptr(), table.ctypes.data, int(table.shape[0]),
+                                                  1 if self_loop else 0, _lib.stream_ptr()), "xsq_exchange_rows")
+            return
+        if self.world == 1 and not self_loop:
+            return
+        for owner, so, do, n in table.tolist():               # gloo / no process group: host-staged, functional only
+            if n == 0:
+                continue
+            if self.world == 1:
+                dst[do:do + n].copy_(flat[so:so + n])
+                continue
+            buf = flat[so:so + n].cpu() if owner == self.rank else torch.empty(n, dtype=flat.dtype)
+            dist.broadcast(buf, src=dist.get_global_rank(self.group, owner) if self.group is not None else owner, group=self.group)
+            if owner != self.rank:
+                dst[do:do + n].copy_(buf)
+
+    def close(self):
+        if self.comm is not None:
+            from . import _lib
+            _lib.lib.xsq_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass(frozen=True)
 class PlacedItem:
     item: WorkItem
@@ -273,8 +345,11 @@ class ShardedDemixer:
 
     def __init__(self, separator, track_lengths: Sequence[int], get_chunk: Callable[[WorkItem], Tensor],
                  device: torch.device, group: Optional[dist.ProcessGroup] = None, gather: bool = True,
-                 nb_samples: int = 1, stack: int = 4, solo: bool = False):
+                 nb_samples: int = 1, stack: int = 4, solo: bool = False, exchange: str = "sendrecv"):
+        if exchange not in ("sendrecv", "allgather"):
+            raise ValueError(f"exchange must be 'sendrecv' or 'allgather'; got {exchange!r}")
         self.sep, self.get_chunk, self.dev, self.group, self.gather = separator, get_chunk, torch.device(device), group, gather
+        self.exchange = exchange
         live = dist.is_initialized() and not solo
         self.world = dist.get_world_size(group) if live else 1
         self.rank = dist.get_rank(group) if live else 0
@@ -293,7 +368,14 @@ class ShardedDemixer:
         self.recv: Dict[tuple, Tensor] = {}       # (round, part) -> (world * width) floats, rank-major
         self.send: Dict[tuple, Tensor] = {}       # this rank's slice of it: what the kernels write (in-place all-gather)
         self._place: Dict[tuple, tuple] = {}      # (round, part) -> (row table on the device, rows, longest row)
-        if self.gather:
+        self._xtable: Dict[tuple, object] = {}    # (round, part) -> host table (owner, src offset, dst offset, length) of the in-place exchange
+        self._rowx = None
+        if self.gather and self.exchange == "sendrecv":
+            # every rank keeps the same flat layout; kernels write their rows in place, rows travel owner -> peers
+            self._rowx = RowExchange(self.dev, group if live else None, self.world, self.rank)
+            for key in self.plan.exchanges():
+                self._xtable[key] = self._exchange_table(*key)
+        elif self.gather:
             for key in self.plan.exchanges():
                 w = self.plan.width[key[0]][key[1]]
                 self.recv[key] = torch.zeros(self.world * w, dtype=dt, device=self.dev)
@@ -316,7 +398,7 @@ class ShardedDemixer:
                     for b in range(nb):
                         for c in range(2):
                             r = (tg * nb + b) * 2 + c
-                            if self.gather:       # packed (4, nb, 2, length) block of the exchange buffer
+                            if self.gather and self.exchange == "allgather":       # packed (4, nb, 2, length) block of the exchange buffer
                                 rows[tg, i * nb + b, c] = p.offset + r * it.length
                             else:                 # final position inside the track's (4, nb, 2, N_t)
                                 rows[tg, i * nb + b, c] = self.track_off[it.track] + r * self.plan.lengths[it.track] + it.start
@@ -339,8 +421,23 @@ class ShardedDemixer:
         table = torch.tensor(rows, dtype=torch.int64).reshape(-1, 3)
         return table.to(self.dev), len(rows), max((r[2] for r in rows), default=0)
 
+    def _exchange_table(self, k: int, part: int):
+        """Host table of one in-place exchange (xsq_exchange_rows): every (rank, item, target, sample, channel) row of the
+        pass kind ``part`` of round k -> (owner, offset, offset, length) in the flat per-track allocation."""
+        import numpy as np
+        nb, rows = self.plan.nb, []
+        for r in range(self.world):
+            for p in self.plan.rounds[k][r]:
+                if p.part != part:
+                    continue
+                it = p.item
+                for row in range(8 * nb):
+                    off = self.track_off[it.track] + row * self.plan.lengths[it.track] + it.start
+                    rows.append((r, off, off, it.length))
+        return np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1, 4))
+
     def _run_pass(self, k: int, pi: int, placed: Sequence[PlacedItem]):
-        target = self.send[(k, placed[0].part)] if self.gather else self.flat
+        target = self.send[(k, placed[0].part)] if (self.gather and self.exchange == "allgather") else self.flat
         audio = [self.get_chunk(p.item) for p in placed]
         audio = audio[0] if len(audio) == 1 else torch.cat(audio, dim=0)
         self.sep.demix_into(audio, target, self._row_offsets(k, pi, placed), group=self.plan.nb)
@@ -400,6 +497,28 @@ class ShardedDemixer:
                 self._compute_round(k, skip_tails=moved)
             if moved:
                 main.wait_stream(self._tail_stream)
+            return self.out
+        if self.exchange == "sendrecv":
+            xs = self._place_stream
+            joined = False
+            for key in self.plan.exchanges():
+                k, part = key
+                if part == 1 and moved:
+                    if not joined:
+                        main.wait_stream(self._tail_stream)
+                        joined = True
+                else:
+                    self._compute_round(k, part=part)
+                # the rows of this pass kind leave behind its kernels on the exchange stream, beside the next pass's kernels
+                # (which write other rows of the flat layout); incoming rows land where no kernel of this rank writes
+                if xs is not None:
+                    xs.wait_stream(main)
+                    with torch.cuda.stream(xs):
+                        self._rowx.exchange(self.flat, self._xtable[key])
+                else:
+                    self._rowx.exchange(self.flat, self._xtable[key])
+            if xs is not None:
+                main.wait_stream(xs)
             return self.out
         pending, joined = [], False
         for key in self.plan.exchanges():
