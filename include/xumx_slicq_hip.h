@@ -252,6 +252,18 @@ int xsq_wiener_em_masked(int nblocks, const int32_t* F, const int32_t* T, const 
                          float* Y, int B, int S, int win_len, int batch_group, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* A batch too large for one pass (xsq_separator_forward splits it over the samples): the window maximum of norbert :257
+ * spans the WHOLE batch, so every pass first folds the maxima of its samples into a shared table, and the EM of each pass
+ * then takes max(own, table).  ext_max: DEVICE float[xsq_wiener_num_windows(...)], one entry per (block, group, window)
+ * in block-major order, zeroed by the caller before the first xsq_wiener_window_max; holds max |x|^2.  Passes of one set
+ * must agree on B / batch_group = number of groups.  ext_max == NULL: xsq_wiener_em_masked.                            */
+int64_t xsq_wiener_num_windows(int nblocks, const int32_t* F, const int32_t* T, int B, int S, int win_len, int batch_group);
+int xsq_wiener_window_max(int nblocks, const int32_t* F, const int32_t* T, const float* X, int B, int S, int win_len,
+                          int batch_group, float* ext_max, void* stream);
+int xsq_wiener_em_masked_ext(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* masks,
+                             float* Y, int B, int S, int win_len, int batch_group, const float* ext_max,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- loss forward (validation half of training.loop, training.py:34-112 with train=False) -------
  * Replaces ComplexMSELossCriterion (loss.py:37-76) and MaskSumLossCriterion (loss.py:79-96).
  *   pred, target  complex arenas, 8*B channels (4 targets, B, 2, ...)
@@ -327,8 +339,9 @@ int xsq_train_set_precision(xsq_train* t, int mode);
  *   int64[8B] element offsets of packed channel (target, item, c) in `out`; n = samples per item, n_pad as above.
  * xsq_separator_forward: audio (nb, 2, N) -> out (4, nb, 2, N), both DEVICE fp32 contiguous.  Full chunks are stacked
  *   along the batch axis, at most max_stack (chunk, sample) pairs per pass and never more rows than one launch
- *   addresses (a batch too large for one pass is split over the samples; with Wiener-EM a split batch would change
- *   the window maximum's scope and is refused); the remaining chunks run one by one, on `tail_stream` beside the
+ *   addresses (a batch too large for one pass is split over the samples; with Wiener-EM the passes of such a set first
+ *   fold their window maxima into a shared table, xsq_wiener_window_max, so the maximum keeps its batch-wide scope,
+ *   norbert/__init__.py:257); the remaining chunks run one by one, on `tail_stream` beside the
  *   stacked passes when overlap_tail != 0 and tail_stream != stream (forked / joined with events: capturable in a
  *   HIP graph).  workspace / tail_workspace: xsq_separator_workspace bytes each (the tail one may be NULL when nothing
  *   runs on the tail stream).  Same bits as the chunk-by-chunk loop.                                              */

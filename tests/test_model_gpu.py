@@ -675,27 +675,27 @@ def test_native_forward_is_bitwise_the_python_schedule(seps, name):
     assert torch.equal(a, b) and torch.equal(c, d)
 
 
-def test_batch_larger_than_one_pass_is_split_over_the_samples(seps):
+@pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener"])
+def test_batch_larger_than_one_pass_is_split_over_the_samples(seps, name):
     """separator.py:133-232 takes any nb_samples; a pass addresses at most 7168 item-slices (32-bit arena offsets), so a
     larger batch runs as several passes over sample ranges.  Scaled down through ``max_item_slices``: nb = 5 at S = 8
-    with a cap of 20 item-slices -> passes of 2 + 2 + 1 samples; mix-phase results are bitwise those of the whole batch,
-    Wiener-EM (window maximum over the batch, norbert/__init__.py:257) refuses the split loudly."""
-    from xumx_slicq_amd import _lib
-    sep = seps["offline_phasemix"]
+    with a cap of 20 item-slices -> passes of 2 + 2 + 1 samples, stacked chunks and the tail alike.  Bitwise the
+    unsplit call -- also under Wiener-EM, whose window maximum spans the batch (norbert/__init__.py:257): the passes of
+    a set first fold their maxima into a shared table (xsq_wiener_window_max).  Sample 3 is the loud one, so that the
+    maximum of every window comes from a sample in ANOTHER pass than samples 0, 1 and 4."""
+    sep = seps[name]
     x = synth_audio(60000 * 2 + 30000, seed=93, nb_samples=5).cuda()
+    x[3] *= 40.0
     try:
         sep.chunk_size = 60000
         a = sep(x)
         sep.max_item_slices = 20
         b = sep(x)
-        sepw = seps["offline_wiener"]
-        sepw.chunk_size, sepw.max_item_slices = 60000, 20
-        with pytest.raises(_lib.XsqError, match="Wiener"):
-            sepw(x)
+        sep.native = False                         # the module-API schedule (one pass over the whole batch)
+        c = sep(x)
     finally:
-        sep.chunk_size, sep.max_item_slices = 2621440, 0
-        seps["offline_wiener"].chunk_size, seps["offline_wiener"].max_item_slices = 2621440, 0
-    assert torch.equal(a, b)
+        sep.native, sep.chunk_size, sep.max_item_slices = True, 2621440, 0
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("name", ["realtime", "offline_wiener"])

@@ -84,6 +84,9 @@ _SIGS = {
     "xsq_train_step_count": (C.c_int64, [_vp, C.c_int64]),
     "xsq_train_set_precision": (C.c_int, [_vp, C.c_int]),
     "xsq_place_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp]),
+    "xsq_wiener_num_windows": (C.c_int64, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "xsq_wiener_window_max": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "xsq_wiener_em_masked_ext": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "xsq_demixer_create": (C.c_int, [C.POINTER(_vp), _vp]),
     "xsq_demixer_destroy": (C.c_int, [_vp]),
     "xsq_demixer_set_max_rows": (C.c_int, [_vp, C.c_int]),

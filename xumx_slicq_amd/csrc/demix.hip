@@ -29,6 +29,11 @@ struct PassPlan {
     int64_t n = 0, n_pad = 0;        // samples per item that exist / that the slice count is taken from
     int B = 0, group = 1;            // stacked items (chunk, sample); samples per chunk in this pass
     int tail = 0;                    // 1: runs on the tail stream
+    // a batch split over several passes under Wiener-EM: the passes of one chunk range (a "set") share a table of window
+    // maxima taken over ALL their samples (norbert/__init__.py:257 spans the batch) -- float offset into the table buffer at
+    // the head of the workspace, -1 = none; set_first / set_count: the passes of the set (consecutive)
+    int64_t ext_off = -1;
+    int set_first = 0, set_count = 1;
     int64_t* d_xrows = nullptr;      // [2B] input row offsets
     int64_t* d_orows = nullptr;      // [8B] output row offsets
 };
@@ -37,6 +42,7 @@ struct ForwardPlan {
     std::vector<PassPlan> passes;
     int64_t* d_tables = nullptr;     // one allocation behind all d_xrows / d_orows
     size_t main_bytes = 0, tail_bytes = 0;
+    size_t ext_floats = 0;           // window-maximum tables of the split sets (zeroed at the start of every call)
 };
 
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -88,7 +94,8 @@ static int pass_layout(xsq_demixer* d, const xsq_model* Mo, int B, int64_t n_pad
 }
 
 static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t* x_rows, int B, int64_t n, int64_t n_pad,
-                    int group, int wiener, float* out, const int64_t* out_rows, void* ws, size_t ws_bytes, hipStream_t stream) {
+                    int group, int wiener, float* out, const int64_t* out_rows, void* ws, size_t ws_bytes, hipStream_t stream,
+                    const float* ext_max = nullptr) {
     xsq_plan* P = d->plan;
     PassLayout L;
     int rc = pass_layout(d, Mo, B, n_pad, wiener, &L);
@@ -111,9 +118,26 @@ static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t
     if ((rc = xsq_cdae_forward_xin(Mo, X, B, S, nullptr, masks, w + L.cdae, L.cdae_bytes, stream, 1))) return rc;
     if (!wiener)
         return xsq_slicqt_inverse_masked(P, masks, X, 8 * B, 2 * B, S, n, out, out_rows, w + L.inv, L.inv_bytes, stream);
-    if ((rc = xsq_wiener_em_masked(P->nblocks, d->F.data(), d->T.data(), X, masks, Y, B, S, 5000, group, w + L.wien, L.wien_bytes, stream)))
+    if ((rc = xsq_wiener_em_masked_ext(P->nblocks, d->F.data(), d->T.data(), X, masks, Y, B, S, 5000, group, ext_max, w + L.wien,
+                                       L.wien_bytes, stream)))
         return rc;
     return xsq_slicqt_inverse_rows(P, Y, 8 * B, S, n, out, out_rows, w + L.inv, L.inv_bytes, stream);
+}
+
+// One pass of a split batch, first half: its mix transform and the window maxima of its samples folded into the set's table.
+static int run_prepass(xsq_demixer* d, xsq_model* Mo, const float* x, const PassPlan& p, void* ws, size_t ws_bytes, float* ext,
+                       hipStream_t stream) {
+    xsq_plan* P = d->plan;
+    PassLayout L;
+    int rc = pass_layout(d, Mo, p.B, p.n_pad, 1, &L);
+    if (rc) return rc;
+    XSQ_REQUIRE(L.total <= ws_bytes, "xsq_separator_forward: workspace too small");
+    const int S = xsq_plan_num_slices(P, p.n_pad);
+    char* w = (char*)ws;
+    float* X = (float*)(w + L.X);
+    if ((rc = xsq_slicqt_forward_rows(P, x, p.d_xrows, 2 * p.B, p.n, p.n_pad, X, nullptr, nullptr, nullptr, 0, w + L.fwd, L.fwd_bytes, stream)))
+        return rc;
+    return xsq_wiener_window_max(P->nblocks, d->F.data(), d->T.data(), X, p.B, S, 5000, p.group, ext + p.ext_off, stream);
 }
 
 // The schedule of one call shape: stacked passes over the full chunks (at most max_stack (chunk, sample) pairs and
@@ -147,15 +171,27 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     const int S_full = xsq_plan_num_slices(P, std::max(cs, min_samples));
     // samples per pass: the whole batch when one chunk of it fits a launch, else the largest share that does
     int nbb_max = std::max(1, std::min(nb, cap / std::max(1, S_full)));
-    XSQ_REQUIRE(!(wiener && nbb_max < nb), "xsq_separator_forward: nb_samples=%d at %d slices per chunk exceeds one pass (%d item-slices) "
-                "and the Wiener-EM window maximum spans the batch (norbert/__init__.py:257): use a smaller chunk_size or batch", nb, S_full, cap);
+    // a set of passes over sample ranges of the same chunks; under Wiener-EM it gets a shared table of window maxima
+    auto close_set = [&](size_t first, int64_t n_pad, int k) {
+        const int count = (int)(fp.passes.size() - first);
+        int64_t off = -1;
+        if (wiener && count > 1) {
+            off = (int64_t)fp.ext_floats;
+            fp.ext_floats += (size_t)xsq_wiener_num_windows(P->nblocks, d->F.data(), d->T.data(), k, xsq_plan_num_slices(P, n_pad), 5000, 1);
+        }
+        for (size_t i = first; i < fp.passes.size(); ++i) {
+            fp.passes[i].ext_off = off; fp.passes[i].set_first = (int)first; fp.passes[i].set_count = count;
+        }
+    };
     int64_t start = 0;
     std::vector<std::pair<int, int>> parts;                        // (b0, nbb) sample ranges
     for (int b0 = 0; b0 < nb; b0 += nbb_max) parts.push_back({b0, std::min(nbb_max, nb - b0)});
     const int per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(max_stack / std::max(1, nbb_max), cap / ((int64_t)nbb_max * S_full)));
     while (full - start / cs >= 2 && per_pass >= 2) {
         const int k = (int)std::min<int64_t>(per_pass, full - start / cs);
+        const size_t first = fp.passes.size();
         for (auto& pr : parts) add_pass(start, k, pr.first, pr.second, cs, 0);
+        close_set(first, std::max(cs, min_samples), k);
         start += (int64_t)k * cs;
     }
     const bool stacked = !fp.passes.empty();
@@ -164,9 +200,12 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
         // the sample split of a short chunk follows its own slice count
         const int S_n = xsq_plan_num_slices(P, std::max(n, min_samples));
         const int nbb_n = std::max(1, std::min(nb, cap / std::max(1, S_n)));
-        XSQ_REQUIRE(!(wiener && nbb_n < nb), "xsq_separator_forward: nb_samples=%d exceeds one pass with Wiener-EM", nb);
+        const size_t first = fp.passes.size();
         for (int b0 = 0; b0 < nb; b0 += nbb_n) add_pass(start, 1, b0, std::min(nbb_n, nb - b0), n, stacked ? 1 : 0);
+        close_set(first, std::max(n, min_samples), 1);
     }
+    if (fp.ext_floats)                       // split sets under Wiener-EM run in order on the caller's stream
+        for (auto& p : fp.passes) p.tail = 0;
     size_t total = 0;
     for (auto& p : fp.passes) total += (size_t)10 * p.B;
     std::vector<int64_t> host(total);
@@ -182,6 +221,7 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
         size_t& dst = p.tail ? fp.tail_bytes : fp.main_bytes;
         dst = std::max(dst, L.total);
     }
+    fp.main_bytes += al256(fp.ext_floats * 4);
     XSQ_HIP(hipMemcpy(fp.d_tables, host.data(), total * sizeof(int64_t), hipMemcpyHostToDevice));
     auto ins = d->plans.emplace(key, fp);
     *out = &ins.first->second;
@@ -284,9 +324,21 @@ int xsq_separator_forward(xsq_demixer* d, xsq_model* Mo, const float* audio, int
                 return rc;
         XSQ_HIP(hipEventRecord(d->ev_join, side));
     }
-    for (const PassPlan& p : fp->passes)
-        if ((!p.tail || !beside) && (rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, ws, ws_bytes, main)))
+    float* ext = (float*)ws;                                  // window-maximum tables of split sets (head of the workspace)
+    const size_t ext_bytes = al256(fp->ext_floats * 4);
+    char* pws = (char*)ws + ext_bytes;
+    const size_t pws_bytes = ws_bytes - ext_bytes;
+    if (fp->ext_floats) XSQ_HIP(hipMemsetAsync(ext, 0, fp->ext_floats * 4, main));
+    for (size_t i = 0; i < fp->passes.size(); ++i) {
+        const PassPlan& p = fp->passes[i];
+        if (p.tail && beside) continue;
+        if (p.ext_off >= 0 && (int)i == p.set_first)       // first pass of a split set: every pass's maxima first
+            for (int j = 0; j < p.set_count; ++j)
+                if ((rc = run_prepass(d, Mo, audio, fp->passes[i + j], pws, pws_bytes, ext, main))) return rc;
+        if ((rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, pws, pws_bytes, main,
+                           p.ext_off >= 0 ? ext + p.ext_off : nullptr)))
             return rc;
+    }
     if (beside) XSQ_HIP(hipStreamWaitEvent(main, d->ev_join, 0));
     return XSQ_OK;
 }

@@ -44,6 +44,7 @@ struct WTable {
     int* d_work = nullptr;     // (row, window) pairs for the stats / finalize launches
     int nrows = 0, nwork = 0, nblockwin = 0;
     int* d_blockwin = nullptr; // (first_row, window) per (block, window)
+    int* d_bw_of_work = nullptr;   // per (row, window) work item: index of its (block, group, window) in d_blockwin order
     int64_t stat_floats = 0;
     int64_t max_frames = 0;
 };
@@ -132,9 +133,11 @@ __global__ __launch_bounds__(256) void k_wiener_stats(const float2* __restrict__
 }
 
 // ---- pass 2: window max over all rows of the block, then R per row.  One workgroup per (block, window).
+// ext_max (optional): max |x|^2 per (block, group, window) in blockwin order, taken over MORE batch items than this call holds
+// (a batch split into several passes, demix.hip): the window maximum of norbert :257 spans the whole batch.
 __global__ __launch_bounds__(256) void k_wiener_finalize(const WRow* __restrict__ rows,
                                                           const int* __restrict__ blockwin,
-                                                          float* __restrict__ stats) {
+                                                          float* __restrict__ stats, const float* __restrict__ ext_max = nullptr) {
     const int first = blockwin[2 * blockIdx.x], w = blockwin[2 * blockIdx.x + 1];
     const int nrows = rows[first].nrows;
     __shared__ float smax[256];
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256) void k_wiener_finalize(const WRow* __restrict_
         if (threadIdx.x < s) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
         __syncthreads();
     }
-    const float ma = fmaxf(1.f, 0.1f * sqrtf(smax[0]));     // norbert :257
+    const float mx2 = ext_max ? fmaxf(smax[0], ext_max[blockIdx.x]) : smax[0];
+    const float ma = fmaxf(1.f, 0.1f * sqrtf(mx2));         // norbert :257
     const float inv_ma2 = 1.f / (ma * ma);
     const float eps = FLT_EPSILON;
     for (int i = threadIdx.x; i < nrows; i += 256) {
@@ -529,6 +533,28 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restri
     }
 }
 
+// ---- max |x|^2 per (block, group, window) of ONE pass of a split batch, folded into ext_max (non-negative floats order
+// like their bit patterns: atomicMax on the words).  One workgroup per (row, window), as the statistics pass.
+__global__ __launch_bounds__(256) void k_wiener_window_max(const float2* __restrict__ X, const WRow* __restrict__ rows,
+                                                            const int* __restrict__ work, const int* __restrict__ bw_of_work,
+                                                            float* __restrict__ ext_max, int Bn, int S, int win_len) {
+    const int row = work[2 * blockIdx.x], w = work[2 * blockIdx.x + 1];
+    const WRow r = rows[row];
+    const int64_t N = (int64_t)S * r.T;
+    const int64_t n0 = (int64_t)w * win_len;
+    const int64_t n1 = n0 + win_len < N ? n0 + win_len : N;
+    const float2* x0 = X + cidx(r, 2 * Bn, S, r.b * 2, 0);
+    const float2* x1 = X + cidx(r, 2 * Bn, S, r.b * 2 + 1, 0);
+    float m = 0.f;
+    for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+        const float2 a = x0[n], b = x1[n];
+        m = fmaxf(m, fmaxf(a.x * a.x + a.y * a.y, b.x * b.x + b.y * b.y));      // the expression of the statistics pass: same bits
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(ext_max) + bw_of_work[blockIdx.x], __builtin_bit_cast(unsigned, m));
+}
+
 // ------------------------------------------------------------------------------------------------
 static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, int group, WTable* out) {
     std::vector<int> key;
@@ -541,15 +567,17 @@ static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, i
     auto it = g_wtables.find(key);
     if (it != g_wtables.end()) { *out = it->second; return XSQ_OK; }
     std::vector<WRow> rows;
-    std::vector<int> work, blockwin;
+    std::vector<int> work, blockwin, bw_of_work;
     int64_t cum = 0, stat = 0, maxN = 0;
     for (int k = 0; k < nblocks; ++k) {
         const int64_t N = (int64_t)S * T[k];
         const int nwin = (int)((N + win_len - 1) / win_len);
         const int first = (int)rows.size();
+        const int bw0 = (int)blockwin.size() / 2;          // this block's (group, window) entries start here
         maxN = N > maxN ? N : maxN;
         for (int b = 0; b < Bn; ++b)
             for (int f = 0; f < F[k]; ++f) {
+                for (int w = 0; w < nwin; ++w) bw_of_work.push_back(bw0 + (b / group) * nwin + w);
                 WRow r;
                 r.F = F[k]; r.T = T[k]; r.b = b; r.f = f; r.nwin = nwin;
                 // rows sharing one window maximum: the `group` consecutive batch items of this row's group
@@ -572,6 +600,8 @@ static int get_wtable(int nblocks, const int32_t* F, const int32_t* T, int Bn, i
     XSQ_HIP(hipMemcpy(t.d_work, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice));
     XSQ_HIP(hipMalloc(&t.d_blockwin, blockwin.size() * sizeof(int)));
     XSQ_HIP(hipMemcpy(t.d_blockwin, blockwin.data(), blockwin.size() * sizeof(int), hipMemcpyHostToDevice));
+    XSQ_HIP(hipMalloc(&t.d_bw_of_work, bw_of_work.size() * sizeof(int)));
+    XSQ_HIP(hipMemcpy(t.d_bw_of_work, bw_of_work.data(), bw_of_work.size() * sizeof(int), hipMemcpyHostToDevice));
     g_wtables[key] = t;
     *out = t;
     return XSQ_OK;
@@ -665,6 +695,37 @@ int xsq_wiener_em(int nblocks, const int32_t* F, const int32_t* T, const float* 
 
 int xsq_wiener_em_masked(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* masks, float* Y,
                          int Bn, int S, int win_len, int batch_group, void* ws, size_t ws_bytes, void* stream_) {
+    return xsq_wiener_em_masked_ext(nblocks, F, T, X, masks, Y, Bn, S, win_len, batch_group, nullptr, ws, ws_bytes, stream_);
+}
+
+int64_t xsq_wiener_num_windows(int nblocks, const int32_t* F, const int32_t* T, int Bn, int S, int win_len, int batch_group) {
+    if (nblocks <= 0 || !F || !T || Bn <= 0 || S <= 0 || win_len <= 0) return 0;
+    if (batch_group <= 0) batch_group = Bn;
+    if (Bn % batch_group) return 0;
+    int64_t n = 0;
+    for (int k = 0; k < nblocks; ++k) n += (int64_t)(Bn / batch_group) * (((int64_t)S * T[k] + win_len - 1) / win_len);
+    return n;
+}
+
+int xsq_wiener_window_max(int nblocks, const int32_t* F, const int32_t* T, const float* X, int Bn, int S, int win_len,
+                          int batch_group, float* ext_max, void* stream_) {
+    int rc = check_table("xsq_wiener_window_max", nblocks, F, T, Bn, S);
+    if (rc) return rc;
+    XSQ_REQUIRE(X && ext_max && win_len > 0, "xsq_wiener_window_max: bad argument");
+    if (batch_group <= 0) batch_group = Bn;
+    XSQ_REQUIRE(Bn % batch_group == 0, "xsq_wiener_window_max: batch_group=%d does not divide B=%d", batch_group, Bn);
+    WTable t;
+    if ((rc = get_wtable(nblocks, F, T, Bn, S, win_len, batch_group, &t))) return rc;
+    XSQ_PROF("wiener_window_max", (hipStream_t)stream_);
+    hipLaunchKernelGGL(k_wiener_window_max, dim3(t.nwork), dim3(256), 0, (hipStream_t)stream_, (const float2*)X, t.d_rows, t.d_work,
+                       t.d_bw_of_work, ext_max, Bn, S, win_len);
+    XSQ_HIP(hipGetLastError());
+    return XSQ_OK;
+}
+
+int xsq_wiener_em_masked_ext(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* masks, float* Y,
+                             int Bn, int S, int win_len, int batch_group, const float* ext_max, void* ws, size_t ws_bytes,
+                             void* stream_) {
     int rc = check_table("xsq_wiener_em_masked", nblocks, F, T, Bn, S);
     if (rc) return rc;
     XSQ_REQUIRE(X && masks && Y && ws, "xsq_wiener_em_masked: null argument");
@@ -682,7 +743,7 @@ int xsq_wiener_em_masked(int nblocks, const int32_t* F, const int32_t* T, const 
     hipLaunchKernelGGL(k_wiener_stats_masked, dim3(t.nwork), dim3(256), 0, stream, (const float2*)X, masks,
                        t.d_rows, t.d_work, stats, Bn, S, win_len); }
     { XSQ_PROF("wiener_finalize", stream);
-    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats); }
+    hipLaunchKernelGGL(k_wiener_finalize, dim3(t.nblockwin), dim3(256), 0, stream, t.d_rows, t.d_blockwin, stats, ext_max); }
     { XSQ_PROF("wiener_apply", stream);
     hipLaunchKernelGGL(k_wiener_apply_masked, dim3((unsigned)((t.max_frames / 2 + 255) / 256), t.nrows), dim3(256), 0, stream,
                        (const float2*)X, masks, (float2*)Y, t.d_rows, stats, Bn, S, win_len); }
