@@ -170,6 +170,11 @@ int xsq_model_destroy(xsq_model* model);
  *      product, one fp32 rounding -- measured as close to the torch-cpu reference as mode 0
  *      (1.1e-7 RMS), 6/16 of the matrix-pipe time.                                              */
 int xsq_model_set_precision(xsq_model* model, int mode);
+/* A/B switch, fp32 inference, non-causal first layer: 4 (or any value but 0 and 2) = layer 1 of a block's FOUR targets in one
+ * tile, 2 = two targets per tile -- the targets read the same whitened magnitude (model.py:244-247), so the operand is
+ * loaded and staged once for several targets' MFMAs (csrc/cdae_l1q.h); 0 (default) = one tile per (block, target) on the
+ * generic engine.  Same bits; measured SLOWER than the default (0.58-0.66 against 0.545 ms: fewer resident waves).    */
+int xsq_model_set_l1_quad(xsq_model* model, int on);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)
  *   Y      out: mask * X, arena for 8*B channels laid out (4 targets, B, 2, ...); NULL (with masks

@@ -272,6 +272,7 @@ class Unmix(nn.Module):
                 1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
             # inside the device guard: bf16 modes allocate and launch on the CURRENT device
             _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
+            _lib.check(_lib.lib.xsq_model_set_l1_quad(out, int(getattr(self, "l1_quad", 0))), "xsq_model_set_l1_quad")
         self._handles[idx] = (ver, out)
         return out
 
@@ -285,6 +286,13 @@ class Unmix(nn.Module):
         for idx, (_ver, h) in self._handles.items():
             with torch.cuda.device(idx):       # the split-weight pool is allocated / converted on the model's device
                 _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
+
+    def set_l1_quad(self, on):
+        """A/B switch: 4 (True) / 2 = layer 1 of four / two targets of a block in one tile (csrc/cdae_l1q.h: the targets share
+        their input); 0 (False, default) = one tile per (block, target) on the generic engine.  Same bits; measured slower."""
+        self.l1_quad = 4 if on is True else int(on)
+        for _ver, h in self._handles.values():
+            _lib.check(_lib.lib.xsq_model_set_l1_quad(h, int(self.l1_quad)), "xsq_model_set_l1_quad")
 
     def __del__(self):
         try:
