@@ -81,8 +81,11 @@ int cdae_launch_magnitude(const xsq_model* Mo, const float* X, float* xin, const
 
 // backward of the Wiener-EM iteration (wiener.hip), in place on the gradient arena G.  The pre-filter estimate is
 // either given (Y0, complex arena) or formed from the masks while loading (Y0 == nullptr, masks = real arena).
+// gM (optional, masks form only): the mask gradient is formed in the last pass -- gM = (Re(conj(x) dL/dy0) + gM) m (1 - m),
+// the training step's k_mask_bwd -- and G is then NOT written.
 int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, const float* masks,
-                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream);
+                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream,
+                       float* gM = nullptr);
 // loss forward (loss.hip), optionally with the gradients of both terms written in the same pass (gY / gM non-null)
 int loss_forward_backward(int nblocks, const int32_t* F, const int32_t* T, const float* pred, const float* target,
                           const float* masks, int Bn, int S, double* out, float* gY, float* gM, void* ws, hipStream_t stream);

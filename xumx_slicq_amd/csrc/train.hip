@@ -74,6 +74,16 @@ static const int BN_ROWS = 256;
 struct BnTile { int group, r0, r1; };
 struct BnInfo { int base, n; };
 
+// The BatchNorm output in front of the ReLU, spelled ONCE: the forward pass applies the ReLU to it and the two backward
+// passes re-derive the ReLU's mask from it (a > 0 <=> pre > 0) instead of reading the activation array back -- a third
+// less traffic in both -- which only holds if all three round identically: no contraction left to the compiler here.
+__device__ __forceinline__ float bn_pre(float z, float mean, float inv, float gamma, float beta) {
+#pragma clang fp contract(off)
+    const float zh = (z - mean) * inv;
+    const float t = zh * gamma;
+    return t + beta;
+}
+
 // stage 1, one workgroup per row tile: per channel sum and sum of squares.  A row is 13 float4 (52 channels, 208 B,
 // 16-byte aligned): thread = (row lane tid / 13 of 16, channel quad tid % 13), 16-byte loads, 16 rows of the tile per
 // step (the first form read 4 bytes per lane and walked 64 rows per thread: 0.05 ms per launch of pure latency).
@@ -113,18 +123,36 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
     bn_tile_reduce(s1, s2, part + (int64_t)blockIdx.x * 128);
 }
 
-// stage 2, one 64-thread workgroup per group: batch mean / biased variance, running-stat update (momentum 0.1)
-__global__ __launch_bounds__(64) void k_bn_stats_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
+// stage 2, one workgroup per group: the group's tile partials added in a FIXED order -- tile lane ty (of 16) adds tiles ty,
+// ty + 16, ... in sequence, the 16 lane sums are added pairwise in a fixed tree (bitwise reproducible).  (Round 3: one wave
+// per group walked all tiles, one dependent double load after the other -- 35-70 us per launch for the 108 tiles of the
+// 86-bin block, six launches per step.)
+static const int BN_FL = 16;
+__device__ __forceinline__ void bn_final_sum(const double* __restrict__ part, const BnInfo bi, int c, int ty, double& a, double& b) {
+    __shared__ double sa[BN_FL][64], sb[BN_FL][64];
+    double x = 0.0, y = 0.0;
+    for (int ch = ty; ch < bi.n; ch += BN_FL) { const double* o = part + (int64_t)(bi.base + ch) * 128; x += o[c]; y += o[64 + c]; }
+    sa[ty][c] = x; sb[ty][c] = y;
+    __syncthreads();
+#pragma unroll
+    for (int s = BN_FL / 2; s > 0; s >>= 1) {
+        if (ty < s) { sa[ty][c] += sa[ty + s][c]; sb[ty][c] += sb[ty + s][c]; }
+        __syncthreads();
+    }
+    a = sa[0][c]; b = sb[0][c];
+}
+
+// batch mean / biased variance, running-stat update (momentum 0.1)
+__global__ __launch_bounds__(64 * BN_FL) void k_bn_stats_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
                                                         const BnInfo* __restrict__ info, TrainDims d, int layer,
                                                         float* __restrict__ stats, float* __restrict__ pool, int update_running) {
     const TrainGroup g = groups[blockIdx.x];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
     const int C = layer == 1 ? g.C2 : g.C1;
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    const BnInfo bi = info[blockIdx.x];
-    double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < bi.n; ++ch) { const double* o = part + (int64_t)(bi.base + ch) * 128; a += o[c]; b += o[64 + c]; }
+    const int c = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double a, b;
+    bn_final_sum(part, info[blockIdx.x], c, ty, a, b);
+    if (c >= C || ty != 0) return;
     const double mean = a / (double)M;
     double var = b / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -163,32 +191,43 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float4* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = 4 * q + k;
-        o[k] = c < C ? fmaxf((in[k] - st[c]) * st[64 + c] * pool[pb + c] + pool[pb + C + c], 0.f) : 0.f;
+        o[k] = c < C ? fmaxf(bn_pre(in[k], st[c], st[64 + c], pool[pb + c], pool[pb + C + c]), 0.f) : 0.f;
     }
     a[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward, step 1 (two stages like the statistics): per channel sum(g_bn) and sum(g_bn * zhat), g_bn = g_a * [a > 0]
-__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ z, const float* __restrict__ a,
-                                                         const float* __restrict__ ga, const TrainGroup* __restrict__ groups,
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ z, const float* __restrict__ ga,
+                                                         const TrainGroup* __restrict__ groups,
                                                          const BnTile* __restrict__ tiles, TrainDims d, int layer,
-                                                         const float* __restrict__ stats, double* __restrict__ part) {
+                                                         const float* __restrict__ stats, const float* __restrict__ pool,
+                                                         double* __restrict__ part) {
     const BnTile t = tiles[blockIdx.x];
     const TrainGroup g = groups[t.group];
     const int64_t off = layer == 1 ? act2_off(g, d) : act1_off(g, d);
     const float4* z4 = reinterpret_cast<const float4*>(z + off);
-    const float4* a4 = reinterpret_cast<const float4*>(a + off);
     const float4* g4 = reinterpret_cast<const float4*>(ga + off);
     const int tid = threadIdx.x, rl = tid / BN_Q, q = tid - rl * BN_Q;
     const float* st = stats + ((int64_t)t.group * 3 + layer) * 256;
+    const int C = layer == 1 ? g.C2 : g.C1;
+    const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     if (tid < BN_RL * BN_Q) {
         const float4 mean = *reinterpret_cast<const float4*>(st + 4 * q), inv = *reinterpret_cast<const float4*>(st + 64 + 4 * q);
+        float gam[4], bet[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // pad channels: gamma = beta = 0 -> pre = 0 -> masked, as the stored zero was
+            const int c = 4 * q + k;
+            gam[k] = c < C ? pool[pb + c] : 0.f;
+            bet[k] = c < C ? pool[pb + C + c] : 0.f;
+        }
         for (int m = t.r0 + rl; m < t.r1; m += BN_RL) {
             const int64_t i = (int64_t)m * BN_Q + q;
-            const float4 zv = z4[i], av = a4[i], gv = g4[i];
-            const float g0 = av.x > 0.f ? gv.x : 0.f, g1 = av.y > 0.f ? gv.y : 0.f;
-            const float g2 = av.z > 0.f ? gv.z : 0.f, g3 = av.w > 0.f ? gv.w : 0.f;
+            const float4 zv = z4[i], gv = g4[i];
+            const float g0 = bn_pre(zv.x, mean.x, inv.x, gam[0], bet[0]) > 0.f ? gv.x : 0.f;
+            const float g1 = bn_pre(zv.y, mean.y, inv.y, gam[1], bet[1]) > 0.f ? gv.y : 0.f;
+            const float g2 = bn_pre(zv.z, mean.z, inv.z, gam[2], bet[2]) > 0.f ? gv.z : 0.f;
+            const float g3 = bn_pre(zv.w, mean.w, inv.w, gam[3], bet[3]) > 0.f ? gv.w : 0.f;
             s1[0] += g0; s1[1] += g1; s1[2] += g2; s1[3] += g3;
             s2[0] += (double)g0 * (double)((zv.x - mean.x) * inv.x);
             s2[1] += (double)g1 * (double)((zv.y - mean.y) * inv.y);
@@ -199,17 +238,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     bn_tile_reduce(s1, s2, part + (int64_t)blockIdx.x * 128);
 }
 
-__global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
+__global__ __launch_bounds__(64 * BN_FL) void k_bn_bwd_final(const double* __restrict__ part, const TrainGroup* __restrict__ groups,
                                                       const BnInfo* __restrict__ info, TrainDims d, int layer,
                                                       float* __restrict__ stats, float* __restrict__ gpool) {
     const TrainGroup g = groups[blockIdx.x];
     const int64_t M = (int64_t)d.Bn * (layer == 1 ? g.F2 : g.F1) * (layer == 1 ? d.T2 : d.T1);
     const int C = layer == 1 ? g.C2 : g.C1;
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    const BnInfo bi = info[blockIdx.x];
-    double sg = 0.0, sgz = 0.0;
-    for (int ch = 0; ch < bi.n; ++ch) { const double* o = part + (int64_t)(bi.base + ch) * 128; sg += o[c]; sgz += o[64 + c]; }
+    const int c = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double sg, sgz;
+    bn_final_sum(part, info[blockIdx.x], c, ty, sg, sgz);
+    if (c >= C || ty != 0) return;
     float* st = bn_slot(stats, blockIdx.x, layer);
     st[128 + c] = (float)(sg / (double)M);
     st[192 + c] = (float)(sgz / (double)M);
@@ -219,7 +257,7 @@ __global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ 
 }
 
 // backward, step 2 (flat, in place on ga): g_z = gamma * invstd * (g_bn - mean(g_bn) - zhat * mean(g_bn * zhat))
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float4* __restrict__ z, const float4* __restrict__ a,
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float4* __restrict__ z,
                                                        float4* __restrict__ ga, const TrainGroup* __restrict__ groups,
                                                        const int* __restrict__ frow, int rows_per_f, int64_t nquads, int layer,
                                                        const float* __restrict__ stats, const float* __restrict__ pool) {
@@ -232,17 +270,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float4* __restrict__
     const int C = layer == 1 ? g.C2 : g.C1;
     const int64_t pb = layer == 0 ? g.p_bn1 : (layer == 1 ? g.p_bn2 : g.p_bn3);
     const float* st = stats + ((int64_t)gid * 3 + layer) * 256;
-    const float4 zv = z[i], av = a[i], gv = ga[i];
-    const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, ai[4] = {av.x, av.y, av.z, av.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float4 zv = z[i], gv = ga[i];
+    const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = 4 * q + k;
         o[k] = 0.f;
         if (c < C) {
+            const float gamma = pool[pb + c];
             const float zh = (zi[k] - st[c]) * st[64 + c];
-            const float gb = ai[k] > 0.f ? gi[k] : 0.f;
-            o[k] = pool[pb + c] * st[64 + c] * (gb - st[128 + c] - zh * st[192 + c]);
+            const float gb = bn_pre(zi[k], st[c], st[64 + c], gamma, pool[pb + C + c]) > 0.f ? gi[k] : 0.f;     // the ReLU's mask, re-derived
+            o[k] = gamma * st[64 + c] * (gb - st[128 + c] - zh * st[192 + c]);
         }
     }
     ga[i] = make_float4(o[0], o[1], o[2], o[3]);
@@ -880,17 +919,17 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, z1, z2, z3, X, Y, masks, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     if ((rc = cdae_launch_layer(Mo, 1, a, stream))) return rc;                       // z1
     { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, Tr->d_groups, wt.d_bt1, d, 0, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, Tr->d_params, apply_update); }
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, Tr->d_params, apply_update); }
     { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (float4*)a1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     a.act1 = a1; a.act2 = z2;
     if ((rc = cdae_launch_layer(Mo, 2, a, stream))) return rc;                       // z2 from a1
     { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, Tr->d_groups, wt.d_bt2, d, 1, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, Tr->d_params, apply_update); }
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, Tr->d_params, apply_update); }
     { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (float4*)a2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     a.act2 = a2; a.act3 = z3;
     if ((rc = cdae_launch_layer(Mo, 3, a, stream))) return rc;                       // z3 from a2
     { XSQ_PROF("train_bn_stats", stream); hipLaunchKernelGGL(k_bn_stats_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, Tr->d_groups, wt.d_bt1, d, 2, part);
-      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, Tr->d_params, apply_update); }
+      hipLaunchKernelGGL(k_bn_stats_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, Tr->d_params, apply_update); }
     { XSQ_PROF("train_bn_relu_apply", stream); hipLaunchKernelGGL(k_bn_relu_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (float4*)a3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     a.act3 = a3;
     // model.py:264-268: the offline model filters the mix-phase estimate (phase.py:18-69).  Layer 4 then stores the
@@ -901,9 +940,10 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
         return rc;
     // ---- loss + its gradients (one pass) ------------------------------------------------------------
     if ((rc = loss_forward_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Y, Yt, masks, Bn, S, d_loss, gY, gM, loss_ws, stream))) return rc;
-    if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, nullptr, masks, gY, Bn, S, 5000, Bn, wst, wbst, stream)))
+    // (Wiener-EM: the last pass of its backward forms the mask gradient itself -- no gradient arena written and re-read)
+    if (wiener && (rc = wiener_em_backward(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), X, nullptr, masks, gY, Bn, S, 5000, Bn, wst, wbst, stream, gM)))
         return rc;
-    { XSQ_PROF("train_mask_bwd", stream); hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d); }
+    if (!wiener) { XSQ_PROF("train_mask_bwd", stream); hipLaunchKernelGGL(k_mask_bwd, dim3(grid1(maxP).x, G), dim3(256), 0, stream, (const float2*)X, (const float2*)gY, masks, gM, Tr->d_groups, d); }
     // ---- backward -----------------------------------------------------------------------------------
     float* gp = Tr->d_grads;
     { XSQ_PROF("train_l4_bias_grad", stream); hipLaunchKernelGGL(k_l4_bias_partial, dim3(2 * Bn, G), dim3(256), 0, stream, gM, Tr->d_groups, d, part);
@@ -924,27 +964,27 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
     if ((rc = cdae_launch_layer(Mo, 1, bw, stream, "train_l4_dgrad_gemm"))) return rc;
     bw.xin8 = nullptr;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, a3, g3, Tr->d_groups, wt.d_bt1, d, 2, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (const float4*)a3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z3, g3, Tr->d_groups, wt.d_bt1, d, 2, stats, Tr->d_params, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 2, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     XSQ_HIP(fork(1));
     { XSQ_PROF("train_l3_wgrad", ws_);
       hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
     if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, a2, g2, Tr->d_groups, wt.d_bt2, d, 1, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (const float4*)a2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt2), dim3(256), 0, stream, z2, g2, Tr->d_groups, wt.d_bt2, d, 1, stats, Tr->d_params, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi2, d, 1, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     XSQ_HIP(fork(2));
     { XSQ_PROF("train_l2_wgrad", ws_);
       hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
     if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
-    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, a1, g1, Tr->d_groups, wt.d_bt1, d, 0, stats, part);
-      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, gp); }
-    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (const float4*)a1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
+    { XSQ_PROF("train_bn_bwd_reduce", stream); hipLaunchKernelGGL(k_bn_bwd_partial, dim3(wt.nbt1), dim3(256), 0, stream, z1, g1, Tr->d_groups, wt.d_bt1, d, 0, stats, Tr->d_params, part);
+      hipLaunchKernelGGL(k_bn_bwd_final, dim3(G), dim3(64 * BN_FL), 0, stream, part, Tr->d_groups, wt.d_bi1, d, 0, stats, gp); }
+    { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     XSQ_HIP(fork(3));
     { XSQ_PROF("train_l1_wgrad", ws_);
       hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);

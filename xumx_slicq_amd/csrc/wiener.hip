@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restri
                                                            const float* __restrict__ Mk,
                                                            float2* __restrict__ G, const WRow* __restrict__ rows,
                                                            const float* __restrict__ stats, const float* __restrict__ bstats,
-                                                           int Bn, int S, int win_len) {
+                                                           int Bn, int S, int win_len, float* __restrict__ gM = nullptr) {
     const WRow r = rows[blockIdx.y];
     const int64_t N = (int64_t)S * r.T;
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -526,10 +526,22 @@ __global__ __launch_bounds__(256) void k_wiener_bwd_apply(const float2* __restri
         const float h00 = bs[4 * j], h11 = bs[4 * j + 1];
         const float2 h01 = make_float2(bs[4 * j + 2], bs[4 * j + 3]);
         const float2 a = cmul(h01, y[j][1]), b = cmulc(y[j][0], h01);
-        G[yi[j]] = make_float2((P.gv[j] * y[j][0].x + h00 * y[j][0].x + a.x) * inv_ma2,
-                               (P.gv[j] * y[j][0].y + h00 * y[j][0].y + a.y) * inv_ma2);
-        G[yi[j] + (int64_t)r.F * N] = make_float2((P.gv[j] * y[j][1].x + b.x + h11 * y[j][1].x) * inv_ma2,
-                                                  (P.gv[j] * y[j][1].y + b.y + h11 * y[j][1].y) * inv_ma2);
+        const float2 g0 = make_float2((P.gv[j] * y[j][0].x + h00 * y[j][0].x + a.x) * inv_ma2,
+                                      (P.gv[j] * y[j][0].y + h00 * y[j][0].y + a.y) * inv_ma2);
+        const float2 g1 = make_float2((P.gv[j] * y[j][1].x + b.x + h11 * y[j][1].x) * inv_ma2,
+                                      (P.gv[j] * y[j][1].y + b.y + h11 * y[j][1].y) * inv_ma2);
+        const int64_t i0 = yi[j], i1 = yi[j] + (int64_t)r.F * N;
+        if (gM) {
+            // training step: the gradient of the pre-filter estimate y0 = m x goes straight on through the product and the
+            // sigmoid (train.hip: k_mask_bwd) -- d/dm = Re(conj(x) g) on top of the mask-sum gradient already in gM, times
+            // m (1 - m) -- instead of being stored (64 B per point) and read back by a second pass
+            const float m0 = Mk[i0], m1 = Mk[i1];
+            gM[i0] = (x0.x * g0.x + x0.y * g0.y + gM[i0]) * m0 * (1.f - m0);
+            gM[i1] = (x1.x * g1.x + x1.y * g1.y + gM[i1]) * m1 * (1.f - m1);
+        } else {
+            G[i0] = g0;
+            G[i1] = g1;
+        }
     }
 }
 
@@ -622,7 +634,8 @@ static int check_table(const char* who, int nblocks, const int32_t* F, const int
 // backward of xsq_wiener_em: `stats` is the workspace the forward call left behind, G holds dL/d(out) on entry
 // and dL/d(y0) on return, Y0 is the pre-filter estimate.  bstats: another workspace of the same size.
 int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const float* X, const float* Y0, const float* masks,
-                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream) {
+                       float* G, int Bn, int S, int win_len, int batch_group, const void* stats, void* bstats, hipStream_t stream,
+                       float* gM) {
     if (batch_group <= 0) batch_group = Bn;
     WTable t;
     int rc;
@@ -636,7 +649,7 @@ int wiener_em_backward(int nblocks, const int32_t* F, const int32_t* T, const fl
     { XSQ_PROF("wiener_bwd_apply", stream);
     hipLaunchKernelGGL(k_wiener_bwd_apply, dim3((unsigned)((t.max_frames + 255) / 256), t.nrows), dim3(256), 0, stream,
                        (const float2*)X, (const float2*)Y0, Y0 ? nullptr : masks, (float2*)G, t.d_rows, (const float*)stats,
-                       (const float*)bstats, Bn, S, win_len); }
+                       (const float*)bstats, Bn, S, win_len, (Y0 == nullptr && masks) ? gM : nullptr); }
     XSQ_HIP(hipGetLastError());
     return XSQ_OK;
 }

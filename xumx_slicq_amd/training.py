@@ -128,15 +128,16 @@ class Trainer:
         main = torch.cuda.current_stream(self.device)
         side = self.__dict__.setdefault("_side", None) or torch.cuda.Stream(device=self.device)
         self._side = side
+        # (straight to the arenas: the module API's list of 70 block views per transform -- built, checked back into an arena
+        #  and record_stream'ed one by one -- cost ~0.3 ms of host time per step during which the device sat idle,
+        #  profiles/r07h_timeline_train.txt)
+        eng = self.nsgt.nsgt.nsgt
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            Yt = self.nsgt(y_targets)
-        Xc = self.nsgt(x)
+            Ytg, lead_t, S_t = eng.forward(y_targets)
+        X, lead, S = eng.forward(x)
         main.wait_stream(side)
-        for t in Yt:
-            t.record_stream(main)
-        X, lead, S = self.table.as_arena(list(Xc))
-        Ytg, lead_t, S_t = self.table.as_arena(list(Yt))
+        Ytg.record_stream(main)
         if len(lead) != 2 or lead[1] != 2 or lead_t != (4, lead[0], 2) or S != S_t:
             raise ValueError(f"expected x (B, 2, N) and y_targets (4, B, 2, N); got arenas {lead} / {lead_t}")
         return self.step_arena(X, Ytg, lead[0], S, apply_update, wait)
