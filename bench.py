@@ -707,7 +707,16 @@ def bench_testset(args, sep, dev, world, rank, dist):
     gather = not args.no_gather
     if world == 1 and args.gather_at_1:
         gather = "always"
-    dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange=args.exchange)
+    exchange_note = None
+    try:
+        dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange=args.exchange)
+    except Exception as e:      # e.g. the library's own RCCL communicator could not be created: say so and use the all-gather form
+        if args.exchange != "sendrecv":
+            raise
+        exchange_note = "sendrecv-inplace unavailable (%s: %s); fell back to allgather+place" % (type(e).__name__, str(e)[:300])
+        print("bench.py: " + exchange_note, file=sys.stderr)
+        args.exchange = "allgather"
+        dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange="allgather")
     gather = dmx.gather
     for q in dmx.plan.rounds:
         for p in q[rank]:
@@ -810,6 +819,8 @@ def bench_testset(args, sep, dev, world, rank, dist):
         "roofline_mfma": mfma,
     }
     if collective:
+        if exchange_note:
+            collective["exchange_note"] = exchange_note
         result["collective"] = collective
     if variants:
         result["variants"] = variants
