@@ -533,6 +533,9 @@ struct xsq_train {
     unsigned char* d_trainable = nullptr;
     int *d_map_pool = nullptr, *d_map_mean = nullptr, *d_map_scale = nullptr;
     int* d_map_bwd = nullptr;               // canonical pool -> weights of the data-gradient operators (same slots as the forward pool)
+    bool pools_valid = false;               // the two GEMM pools hold the current parameters (re-gathered behind every update)
+    mutable std::mutex size_mu;
+    mutable std::map<std::pair<int, int>, std::pair<size_t, size_t>> size_cache;   // (B, S) -> (reduction scratch doubles, weight-gradient partial floats)
     float* d_pool_bwd = nullptr;
     int64_t step = 0;
     std::vector<int32_t> Fv, Tv;
@@ -600,6 +603,16 @@ static size_t wg_partial_floats(const xsq_train* Tr, int Bn, int S) {
     std::vector<WgTile> a, b; std::vector<WgGroupInfo> ia, ib;
     wg_build(Tr, Bn, S, &a, &ia, &b, &ib);
     return std::max(a.size() * 64 * WgL23Op::NTL, b.size() * 64 * WgL14Op::NTL);
+}
+
+// both sizes walk every group's tile list on the host (~0.1 ms): once per shape, not three times per step
+static std::pair<size_t, size_t> train_sizes(const xsq_train* Tr, int Bn, int S) {
+    std::lock_guard<std::mutex> lk(Tr->size_mu);
+    auto it = Tr->size_cache.find({Bn, S});
+    if (it != Tr->size_cache.end()) return it->second;
+    const std::pair<size_t, size_t> v{part_doubles(Tr, Bn, S), wg_partial_floats(Tr, Bn, S)};
+    Tr->size_cache[{Bn, S}] = v;
+    return v;
 }
 
 static int wg_tables(xsq_train* Tr, int Bn, int S, xsq_train::WgTables* out) {
@@ -839,6 +852,7 @@ int xsq_train_write(xsq_train* Tr, int what, const float* host_in) {
     XSQ_REQUIRE(Tr && host_in && (what == 0 || what == 2 || what == 3), "xsq_train_write: bad argument (what = 0, 2 or 3)");
     XSQ_HIP(hipDeviceSynchronize());
     XSQ_HIP(hipMemcpy(train_pool(Tr, what), host_in, (size_t)Tr->nparams * 4, hipMemcpyHostToDevice));
+    if (what == 0) Tr->pools_valid = false;        // the GEMM pools are re-gathered by the next step
     return XSQ_OK;
 }
 
@@ -857,8 +871,8 @@ size_t xsq_train_workspace(const xsq_train* Tr, int Bn, int S, int wiener) {
     const size_t n2 = (size_t)Bn * 2 * S * Mo->sumFT, n8 = 4 * n2;
     const size_t a1 = (size_t)CS * Bn * T1 * 4 * Mo->sumF1, a2 = (size_t)CS * Bn * T2 * 4 * Mo->sumF2;
     size_t b = alt(n2 * 4) + 6 * alt(a1 * 4) + 3 * alt(a2 * 4) + 2 * alt(n8 * 4) + 2 * alt(n8 * 8);
-    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt(part_doubles(Tr, Bn, S) * 8)
-         + alt(wg_partial_floats(Tr, Bn, S) * 4);
+    const auto sz = train_sizes(Tr, Bn, S);
+    b += alt((size_t)Tr->ngroups * 3 * 256 * 4) + 2 * alt((size_t)Tr->sumF * 4) + alt(sz.first * 8) + alt(sz.second * 4);
     b += xsq_loss_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S) + alt((size_t)Tr->nblocks * 16) + 4096;
     if (wiener) b += 2 * alt(xsq_wiener_workspace(Tr->nblocks, Tr->Fv.data(), Tr->Tv.data(), Bn, S, 5000)) + 4096;
     return b;
@@ -889,7 +903,7 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     void* wst = wiener ? take(wst_bytes) : nullptr;
     void* wbst = wiener ? take(wst_bytes) : nullptr;
     float* stats = (float*)take((size_t)Tr->ngroups * 3 * 256 * 4);
-    double* part = (double*)take(part_doubles(Tr, Bn, S) * 8);
+    double* part = (double*)take(train_sizes(Tr, Bn, S).first * 8);
     xsq_train::WgTables wt;
     if (int rcw = wg_tables(Tr, Bn, S, &wt)) return rcw;
     float* wpart = (float*)take(std::max((size_t)wt.n23 * 64 * WgL23Op::NTL, (size_t)wt.n14 * 64 * WgL14Op::NTL) * 4);
@@ -899,8 +913,16 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
 
     auto grid1 = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     // ---- parameters -> GEMM layouts -------------------------------------------------------------
-    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_pool, Mo->d_pool, Tr->pool_floats); }
-    { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_bwd, Tr->d_pool_bwd, Tr->pool_floats); }
+    auto gather_pools = [&]() {
+        { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_pool, Mo->d_pool, Tr->pool_floats); }
+        { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->pool_floats), dim3(256), 0, stream, Tr->d_params, Tr->d_map_bwd, Tr->d_pool_bwd, Tr->pool_floats); }
+        Tr->pools_valid = true;
+    };
+    // the weights in GEMM layout: gathered here only on the first step or after the parameters were written from outside --
+    // otherwise the gather of step k + 1 was issued BEHIND the update of step k (below), where it runs while the host looks at
+    // the loss and prepares the next batch (the device idles there: profiles/r07h_timeline_train.txt) instead of in front
+    // of the first GEMM
+    if (!Tr->pools_valid) gather_pools();
     { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_mean, mean, Tr->sumF); }
     { XSQ_PROF("train_gather", stream); hipLaunchKernelGGL(k_gather, grid1(Tr->sumF), dim3(256), 0, stream, Tr->d_params, Tr->d_map_scale, scale, Tr->sumF); }
     // ---- forward ----------------------------------------------------------------------------------
@@ -1010,6 +1032,9 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     const int slot = (int)(ticket % xsq_train::LOSS_RING);
     XSQ_HIP(hipMemcpyAsync(Tr->h_loss + (size_t)slot * Tr->nblocks * 2, d_loss, (size_t)Tr->nblocks * 16, hipMemcpyDeviceToHost, stream));
     XSQ_HIP(hipEventRecord(Tr->ev_loss[slot], stream));
+    // the next step's weights in GEMM layout (see above): BEHIND the loss event, so that a caller who waits for the loss --
+    // the step and its update are complete by then -- does not wait for them
+    if (apply_update) gather_pools();
     // loss_out given: wait here, as loss.item() does every step in the reference (training.py:110)
     return loss_out ? xsq_train_loss(Tr, ticket, loss_out) : XSQ_OK;
 }

@@ -97,9 +97,12 @@ class Trainer:
         ``wait=False``: returns a ``PendingLoss`` without waiting for the device (the next step can be issued before
         this one's loss is looked at; the reference's ``loss.item()`` every step, training.py:110, is ``wait=True``)."""
         with torch.cuda.device(self.device):
-            need = _lib.lib.xsq_train_workspace(self._h, B, S, 1 if self.wiener else 0)
-            if need == 0:
-                raise _lib.XsqError("xsq_train_workspace: bad shape")
+            need = self.__dict__.setdefault("_need", {}).get((B, S))
+            if need is None:
+                need = _lib.lib.xsq_train_workspace(self._h, B, S, 1 if self.wiener else 0)
+                if need == 0:
+                    raise _lib.XsqError("xsq_train_workspace: bad shape")
+                self._need[(B, S)] = need
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
