@@ -755,3 +755,28 @@ def test_layer1_quad_tiles_are_bitwise_the_per_target_tiles(seps, name):
     for b, mb in outs:
         assert torch.equal(a, b)
         assert all(torch.equal(p, q) for p, q in zip(ma, mb))
+
+
+def test_evaluation_harness_scores_with_the_real_separator(seps, oracle_plan, seeded_sd):
+    """evaluation.py:16-44 with the accelerated Separator on a MultiTrack-shaped object (audio (T, C), rate, targets): the
+    estimates are the separator's stems, and the per-target scores equal those of the CPU oracle's stems on the same track
+    (museval / MUSDB18-HQ / trained weights are absent offline: the metric is the labelled global SDR)."""
+    import types
+    from oracle import separator as osep
+    from xumx_slicq_amd.evaluation import global_sdr, separate_and_evaluate
+    n = 60000
+    stems = {name: 0.25 * synth_audio(n, seed=300 + i)[0] for i, name in enumerate(["bass", "vocals", "other", "drums"])}     # (2, n)
+    mix = sum(stems.values())
+    track = types.SimpleNamespace(audio=mix.T.numpy(), rate=44100,
+                                  targets={k: types.SimpleNamespace(audio=v.T.numpy()) for k, v in stems.items()})
+    sep = seps["offline_wiener"]
+    res = separate_and_evaluate(sep, track, device="cuda")
+    assert res["metric"] in ("global-sdr", "museval-bsseval-v4")
+    want = sep(mix[None].cuda()).cpu()
+    for t, name in enumerate(sep.sources):
+        assert np.array_equal(res["estimates"][name], want[t, 0].numpy().T)
+    if res["metric"] == "global-sdr":
+        ref = osep.separate(oracle_plan, seeded_sd, mix[None], causal=False, wiener=True)
+        for t, name in enumerate(sep.sources):
+            s_ref = global_sdr(stems[name].T.numpy(), ref[t, 0].numpy().T)
+            assert np.isfinite(res["scores"][name]) and abs(res["scores"][name] - s_ref) < 1e-3, (name, res["scores"][name], s_ref)

@@ -30,6 +30,7 @@ _ACCELERATED = "hip-rocm"
 
 class Separator(nn.Module):
     sources = ["bass", "vocals", "other", "drums"]      # separator.py:48
+    accepts_item_lists = True                           # demix_into takes a list of per-item tensors (sharding.ShardedDemixer)
 
     @classmethod
     def load(cls, chunk_size: int = 2621440, model_path: Optional[str] = None,
@@ -172,28 +173,61 @@ class Separator(nn.Module):
         arena, lead, S = eng.table.as_arena(list(Ylist))
         eng.backward(arena, offs.numel(), S, length, out=out, row_offsets=offs)
 
+    def _input_rows(self, items):
+        """Input row table (device int64, element offsets from items[0]) of a list of equally shaped (nb_samples, 2, n) fp32
+        tensors on one device, or None when the list has to be packed: xsq_demix_pass then reads every work item where it
+        lies -- chunk views of different tracks -- instead of through a torch.cat copy (84 MB per stacked pass of four
+        full chunks).  Cached by the tensors' addresses and strides."""
+        t0 = items[0]
+        if len(items) < 2 or self._native_mode(t0) is None:
+            return None
+        for t in items:
+            if (t.dim() != 3 or t.shape != t0.shape or t.dtype != torch.float32 or t.device != t0.device or t.stride(-1) != 1
+                    or (t.data_ptr() - t0.data_ptr()) % 4):
+                return None
+        key = tuple((t.data_ptr(), t.stride(0), t.stride(1)) for t in items)
+        cache = self.__dict__.setdefault("_xrows", {})
+        hit = cache.get(key)
+        if hit is None:
+            base = t0.data_ptr()
+            rows = [(t.data_ptr() - base) // 4 + b * t.stride(0) + c * t.stride(1)
+                    for t in items for b in range(t.shape[0]) for c in range(2)]
+            if len(cache) > 4096:
+                cache.clear()
+            hit = cache[key] = torch.tensor(rows, dtype=torch.int64, device=t0.device)
+        return hit
+
     @torch.no_grad()
-    def demix_into(self, audio: Tensor, out: Tensor, row_offsets: Tensor, group: int = 1):
+    def demix_into(self, audio, out: Tensor, row_offsets: Tensor, group: int = 1):
         """One pass over ``audio`` (k * group, 2, n): k independent work items of n <= chunk_size samples each
         (chunks of any tracks -- no state crosses the reference's chunk loop, separator.py:153-229), ``group``
-        = nb_samples of an item.  The stems of packed channel (target, item*group + b, c) land at
-        out.view(-1)[row_offsets[target, item*group + b, c] : + n] -- the hard concat of separator.py:231 by
-        placement.  The Wiener window maximum keeps its per-item scope (quirk A13) through ``group``.
-        Building block of ``sharding.ShardedDemixer``; ``forward`` is the single-track case."""
+        = nb_samples of an item; or a LIST of k tensors (group, 2, n), read in place.  The stems of packed channel
+        (target, item*group + b, c) land at out.view(-1)[row_offsets[target, item*group + b, c] : + n] -- the hard concat
+        of separator.py:231 by placement.  The Wiener window maximum keeps its per-item scope (quirk A13) through
+        ``group``.  Building block of ``sharding.ShardedDemixer``; ``forward`` is the single-track case."""
+        x_rows, keep = None, None
+        if isinstance(audio, (list, tuple)):
+            keep = list(audio)
+            x_rows = self._input_rows(keep)
+            if x_rows is None:
+                audio = keep[0] if len(keep) == 1 else torch.cat(keep, dim=0)
+            else:
+                audio = keep[0]
         if audio.dim() != 3 or audio.shape[1] != 2:
             raise ValueError(f"audio must be (items * nb_samples, 2, n); got {tuple(audio.shape)}")
+        B = audio.shape[0] * (len(keep) if x_rows is not None else 1)
         n = audio.shape[-1]
         self._packed_fft()
         if n > self.chunk_size:
             raise ValueError(f"work items are at most chunk_size = {self.chunk_size} samples (got {n})")
-        if tuple(row_offsets.shape) != (4, audio.shape[0], 2) or row_offsets.dtype != torch.int64:
-            raise ValueError(f"row_offsets must be int64 (4, {audio.shape[0]}, 2); got {tuple(row_offsets.shape)}")
+        if tuple(row_offsets.shape) != (4, B, 2) or row_offsets.dtype != torch.int64:
+            raise ValueError(f"row_offsets must be int64 (4, {B}, 2); got {tuple(row_offsets.shape)}")
         min_samples = int(self.nsgt.nsgt.sllen / 2) + 1
         wiener = self._native_mode(audio)
-        if wiener is not None and out.is_contiguous() and out.dtype == torch.float32 and audio.shape[0] % max(1, group) == 0:
+        if wiener is not None and out.is_contiguous() and out.dtype == torch.float32 and B % max(1, group) == 0:
             # one C call per pass (xsq_demix_pass): the zero padding of a short item is a slice count, not a copy
             from . import _lib
-            if audio.dtype != torch.float32 or not audio.is_contiguous():
+            if x_rows is None and (audio.dtype != torch.float32 or not audio.is_contiguous()):
                 audio = audio.contiguous().float()
             dev = audio.device
             offs = row_offsets if row_offsets.is_contiguous() else row_offsets.contiguous()
@@ -201,7 +235,7 @@ class Separator(nn.Module):
                 model = self.xumx_model._model(dev)
                 d = self.nsgt.nsgt.nsgt.demixer(dev)
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                B, n_pad = audio.shape[0], max(n, min_samples)
+                n_pad = max(n, min_samples)
                 key = ("pass", B, n_pad, wiener, self.xumx_model._version(), dev.index)
                 nbytes = self.__dict__.setdefault("_nsizes", {}).get(key)
                 if nbytes is None:
@@ -210,10 +244,12 @@ class Separator(nn.Module):
                         raise _lib.XsqError("xsq_demix_pass_workspace: " + _lib.last_error())
                     self._nsizes[key] = nbytes
                 ws = self._native_ws(dev, stream, "pass", nbytes)
-                _lib.check(_lib.lib.xsq_demix_pass(d, model, audio.data_ptr(), None, B, n, n_pad, int(group), wiener,
-                                                   out.data_ptr(), offs.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                           "xsq_demix_pass")
+                _lib.check(_lib.lib.xsq_demix_pass(d, model, audio.data_ptr(), x_rows.data_ptr() if x_rows is not None else None,
+                                                   B, n, n_pad, int(group), wiener, out.data_ptr(), offs.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), stream), "xsq_demix_pass")
             return
+        if x_rows is not None:
+            audio = torch.cat(keep, dim=0)
         if n < min_samples:
             audio = torch.cat([audio, torch.zeros((*audio.shape[:-1], min_samples - n), device=audio.device,
                                                   dtype=audio.dtype)], dim=-1)
