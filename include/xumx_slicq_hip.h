@@ -349,7 +349,8 @@ int xsq_train_set_precision(xsq_train* t, int mode);
  *   norbert/__init__.py:257); the remaining chunks run one by one, on `tail_stream` beside the
  *   stacked passes when overlap_tail != 0 and tail_stream != stream (forked / joined with events: capturable in a
  *   HIP graph).  workspace / tail_workspace: xsq_separator_workspace bytes each (the tail one may be NULL when nothing
- *   runs on the tail stream).  Same bits as the chunk-by-chunk loop.                                              */
+ *   runs on the tail stream).  Same bits as the chunk-by-chunk loop.  A demixer serves ONE call at a time (its fork / join
+ *   events and the workspaces are per call); concurrent callers use one demixer each.                              */
 typedef struct xsq_demixer xsq_demixer;
 int xsq_demixer_create(xsq_demixer** out, xsq_plan* plan);
 int xsq_demixer_destroy(xsq_demixer* d);
