@@ -211,10 +211,11 @@ def pmc_issue(kernel, tag=None):
 
 
 def cpu_baseline(threads, full=False):
-    """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this box's host cores.  Default:
-    a bounded sample, one 30 s clip through the same configuration (~3 s of host time).  `full` (--cpu-baseline-full):
-    the bench's own 240 s track -- the same workload as `value` (~2 min of host time; the oracle's literal chunk loop,
-    4 full chunks + the tail)."""
+    """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this box's host cores.  Default
+    (`full`): the bench's own 240 s track -- the same workload as `value`, the oracle's literal chunk loop over 4 full
+    chunks + the tail, ~40 s of host time on 16 threads (6.3 x real time, profiles/r07u_bench_cpu_baseline_full.json).
+    --cpu-baseline-clip: one 30 s clip through the same configuration (~3 s; reads ~1.7x faster per audio-second: its working
+    set is a tenth of a chunk's)."""
     import torch
     from oracle import separator as osep
     from oracle import slicqt as oslicqt
@@ -344,8 +345,10 @@ def main():
     ap.add_argument("--stack", type=int, default=4, help="testset50: work items per round / stacked pass")
     ap.add_argument("--wiener", action="store_true", help="BASELINE configs[2]: Wiener-EM on (default off = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="time the CPU oracle on the whole 240 s track (the workload of `value`; ~2 min of host time) instead of a 30 s clip")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--cpu-baseline-clip", action="store_true",
+                    help="time the CPU oracle on a 30 s clip (~3 s of host time) instead of the whole 240 s track (the workload of "
+                         "`value`: ~40 s of host time on 16 threads)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3"],
                     help="arithmetic of the convolution contractions for the headline value (default: exact fp32)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements outside the timed region")
@@ -530,7 +533,7 @@ def bench_track(args, sep, dev, world, rank, dist):
     if variants:
         result["variants"] = variants
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1), full=args.cpu_baseline_full)
+        result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1), full=not args.cpu_baseline_clip)
     return result
 
 
