@@ -364,6 +364,13 @@ int xsq_separator_forward(xsq_demixer* d, xsq_model* model, const float* audio, 
                           int max_stack, int wiener, int overlap_tail, float* out, void* workspace,
                           size_t workspace_bytes, void* tail_workspace, size_t tail_workspace_bytes, void* stream,
                           void* tail_stream);
+/* The schedule xsq_separator_forward follows for a call shape, as pure host arithmetic (no device needed): pass i ->
+ * passes[8 i ..] = (first sample of its first chunk, samples per chunk, chunks stacked, first sample index of the batch,
+ * samples of the batch in this pass, 1 = may run on the tail stream, index of the first pass of its set, 1 = the set
+ * shares a Wiener-EM window-maximum table).  L = slice length, coefs_per_slice = sum F_b T_b; max_item_slices <= 0: the
+ * library's own cap.  Returns the number of passes (may exceed max_passes: call again), negative on error.            */
+int xsq_separator_schedule(int L, int64_t coefs_per_slice, int nb_samples, int64_t N, int64_t chunk_size, int max_stack,
+                           int wiener, int max_item_slices, int64_t* passes, int max_passes);
 /* Test hook: cap on B * S (stacked items x slices) of one pass, normally what the 32-bit arena offsets of the band
  * kernels allow (7168); a smaller value forces the batch split on small shapes.  <= 0 restores the default.        */
 int xsq_demixer_set_max_rows(xsq_demixer* d, int max_item_slices);

@@ -91,6 +91,7 @@ _SIGS = {
     "xsq_demixer_create": (C.c_int, [C.POINTER(_vp), _vp]),
     "xsq_demixer_destroy": (C.c_int, [_vp]),
     "xsq_demixer_set_max_rows": (C.c_int, [_vp, C.c_int]),
+    "xsq_separator_schedule": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int]),
     "xsq_demix_pass_workspace": (C.c_size_t, [_vp, _vp, C.c_int, C.c_int64, C.c_int]),
     "xsq_demix_pass": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "xsq_separator_workspace": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -140,8 +140,58 @@ static int run_prepass(xsq_demixer* d, xsq_model* Mo, const float* x, const Pass
     return xsq_wiener_window_max(P->nblocks, d->F.data(), d->T.data(), X, p.B, S, 5000, p.group, ext + p.ext_off, stream);
 }
 
-// The schedule of one call shape: stacked passes over the full chunks (at most max_stack (chunk, sample) pairs and
-// max_item_slices item-slices per pass), then the remaining chunks one by one (the tail passes).
+// ---- the schedule of one call shape, pure host arithmetic (no device call: tests/test_abi_cpu.py drives it through
+// xsq_separator_schedule): stacked passes over the full chunks (at most max_stack (chunk, sample) pairs and `cap`
+// item-slices per pass), then the remaining chunks one by one (the tail passes); a batch too large for one pass is split
+// over sample ranges, and under Wiener-EM the passes of such a set share a table of window maxima.
+struct SchedPass {
+    int64_t start, n;        // first sample of the first chunk of the pass; samples per chunk that exist
+    int k, b0, nbb;          // chunks stacked, first sample index, samples
+    int tail;                // 1: may run on the tail stream
+    int set_first, set_count;
+    int needs_ext;           // 1: the set shares a window-maximum table (Wiener-EM, set_count > 1)
+};
+
+static inline int slices_of(int64_t n, int h) { return (int)(((n + h - 1) / h + 1) / 2 + 1); }      // nsgt/slicing.py:47-72
+
+static void build_schedule(int L, int nb, int64_t N, int64_t cs, int max_stack, int wiener, int cap, std::vector<SchedPass>* out) {
+    const int h = L / 4;
+    const int64_t min_samples = L / 2 + 1;                         // separator.py:162
+    auto close_set = [&](size_t first) {
+        const int count = (int)(out->size() - first);
+        for (size_t i = first; i < out->size(); ++i) {
+            (*out)[i].set_first = (int)first; (*out)[i].set_count = count; (*out)[i].needs_ext = (wiener && count > 1) ? 1 : 0;
+        }
+    };
+    const int64_t full = N / cs;
+    const int S_full = slices_of(std::max(cs, min_samples), h);
+    // samples per pass: the whole batch when one chunk of it fits a launch, else the largest share that does
+    const int nbb_max = std::max(1, std::min(nb, cap / std::max(1, S_full)));
+    const int per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(max_stack / std::max(1, nbb_max), cap / ((int64_t)nbb_max * S_full)));
+    int64_t start = 0;
+    while (full - start / cs >= 2 && per_pass >= 2) {
+        const int k = (int)std::min<int64_t>(per_pass, full - start / cs);
+        const size_t first = out->size();
+        for (int b0 = 0; b0 < nb; b0 += nbb_max) out->push_back(SchedPass{start, cs, k, b0, std::min(nbb_max, nb - b0), 0, 0, 1, 0});
+        close_set(first);
+        start += (int64_t)k * cs;
+    }
+    const bool stacked = !out->empty();
+    for (; start < N; start += cs) {
+        const int64_t n = std::min(cs, N - start);
+        const int S_n = slices_of(std::max(n, min_samples), h);      // the sample split of a short chunk follows its own slice count
+        const int nbb_n = std::max(1, std::min(nb, cap / std::max(1, S_n)));
+        const size_t first = out->size();
+        for (int b0 = 0; b0 < nb; b0 += nbb_n) out->push_back(SchedPass{start, n, 1, b0, std::min(nbb_n, nb - b0), stacked ? 1 : 0, 0, 1, 0});
+        close_set(first);
+    }
+    bool any_ext = false;
+    for (const SchedPass& p : *out) any_ext = any_ext || p.needs_ext;
+    if (any_ext)                             // split sets under Wiener-EM run in order on the caller's stream
+        for (SchedPass& p : *out) p.tail = 0;
+}
+
+// The schedule with its device tables and workspace sizes.
 static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t N, int64_t cs, int max_stack, int wiener,
                             ForwardPlan** out) {
     xsq_plan* P = d->plan;
@@ -151,61 +201,35 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     const int64_t min_samples = P->L / 2 + 1;                      // separator.py:162
     const int cap = d->max_item_slices > 0 ? d->max_item_slices : default_max_item_slices(P);
     ForwardPlan fp;
+    std::vector<SchedPass> sched;
+    build_schedule(P->L, nb, N, cs, max_stack, wiener, cap, &sched);
     std::vector<std::vector<int64_t>> xr, orw;
-    auto add_pass = [&](int64_t start, int k, int b0, int nbb, int64_t n, int tail) {
+    for (const SchedPass& sp : sched) {
         PassPlan p;
-        p.n = n; p.n_pad = std::max(n, min_samples); p.B = k * nbb; p.group = nbb; p.tail = tail;
+        p.n = sp.n; p.n_pad = std::max(sp.n, min_samples); p.B = sp.k * sp.nbb; p.group = sp.nbb; p.tail = sp.tail;
+        p.set_first = sp.set_first; p.set_count = sp.set_count;
         std::vector<int64_t> xrow((size_t)2 * p.B), orow((size_t)8 * p.B);
-        for (int j = 0; j < k; ++j)
-            for (int b = 0; b < nbb; ++b)
+        for (int j2 = 0; j2 < sp.k; ++j2)
+            for (int b = 0; b < sp.nbb; ++b)
                 for (int c = 0; c < 2; ++c) {
-                    const int item = j * nbb + b;
-                    xrow[(size_t)item * 2 + c] = ((int64_t)(b0 + b) * 2 + c) * N + start + j * cs;
+                    const int item = j2 * sp.nbb + b;
+                    xrow[(size_t)item * 2 + c] = ((int64_t)(sp.b0 + b) * 2 + c) * N + sp.start + j2 * cs;
                     for (int t = 0; t < 4; ++t)
-                        orow[((size_t)t * p.B + item) * 2 + c] = (((int64_t)t * nb + b0 + b) * 2 + c) * N + start + j * cs;
+                        orow[((size_t)t * p.B + item) * 2 + c] = (((int64_t)t * nb + sp.b0 + b) * 2 + c) * N + sp.start + j2 * cs;
                 }
         xr.push_back(xrow); orw.push_back(orow);
         fp.passes.push_back(p);
-    };
-    const int64_t full = N / cs;
-    const int S_full = xsq_plan_num_slices(P, std::max(cs, min_samples));
-    // samples per pass: the whole batch when one chunk of it fits a launch, else the largest share that does
-    int nbb_max = std::max(1, std::min(nb, cap / std::max(1, S_full)));
-    // a set of passes over sample ranges of the same chunks; under Wiener-EM it gets a shared table of window maxima
-    auto close_set = [&](size_t first, int64_t n_pad, int k) {
-        const int count = (int)(fp.passes.size() - first);
-        int64_t off = -1;
-        if (wiener && count > 1) {
-            off = (int64_t)fp.ext_floats;
-            fp.ext_floats += (size_t)xsq_wiener_num_windows(P->nblocks, d->F.data(), d->T.data(), k, xsq_plan_num_slices(P, n_pad), 5000, 1);
-        }
-        for (size_t i = first; i < fp.passes.size(); ++i) {
-            fp.passes[i].ext_off = off; fp.passes[i].set_first = (int)first; fp.passes[i].set_count = count;
-        }
-    };
-    int64_t start = 0;
-    std::vector<std::pair<int, int>> parts;                        // (b0, nbb) sample ranges
-    for (int b0 = 0; b0 < nb; b0 += nbb_max) parts.push_back({b0, std::min(nbb_max, nb - b0)});
-    const int per_pass = (int)std::max<int64_t>(1, std::min<int64_t>(max_stack / std::max(1, nbb_max), cap / ((int64_t)nbb_max * S_full)));
-    while (full - start / cs >= 2 && per_pass >= 2) {
-        const int k = (int)std::min<int64_t>(per_pass, full - start / cs);
-        const size_t first = fp.passes.size();
-        for (auto& pr : parts) add_pass(start, k, pr.first, pr.second, cs, 0);
-        close_set(first, std::max(cs, min_samples), k);
-        start += (int64_t)k * cs;
     }
-    const bool stacked = !fp.passes.empty();
-    for (; start < N; start += cs) {
-        const int64_t n = std::min(cs, N - start);
-        // the sample split of a short chunk follows its own slice count
-        const int S_n = xsq_plan_num_slices(P, std::max(n, min_samples));
-        const int nbb_n = std::max(1, std::min(nb, cap / std::max(1, S_n)));
-        const size_t first = fp.passes.size();
-        for (int b0 = 0; b0 < nb; b0 += nbb_n) add_pass(start, 1, b0, std::min(nbb_n, nb - b0), n, stacked ? 1 : 0);
-        close_set(first, std::max(n, min_samples), 1);
+    // the window-maximum tables of the split sets (one per set, shared by its passes)
+    for (size_t i = 0; i < sched.size(); ++i) {
+        if (!sched[i].needs_ext) continue;
+        if ((int)i == sched[i].set_first) {
+            const int64_t off = (int64_t)fp.ext_floats;
+            fp.ext_floats += (size_t)xsq_wiener_num_windows(P->nblocks, d->F.data(), d->T.data(), sched[i].k,
+                                                            xsq_plan_num_slices(P, fp.passes[i].n_pad), 5000, 1);
+            for (int q = 0; q < sched[i].set_count; ++q) fp.passes[i + q].ext_off = off;
+        }
     }
-    if (fp.ext_floats)                       // split sets under Wiener-EM run in order on the caller's stream
-        for (auto& p : fp.passes) p.tail = 0;
     size_t total = 0;
     for (auto& p : fp.passes) total += (size_t)10 * p.B;
     std::vector<int64_t> host(total);
@@ -255,6 +279,23 @@ int xsq_demixer_destroy(xsq_demixer* d) {
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     delete d;
     return XSQ_OK;
+}
+
+int xsq_separator_schedule(int L, int64_t coefs_per_slice, int nb, int64_t N, int64_t cs, int max_stack, int wiener,
+                           int max_item_slices, int64_t* passes, int max_passes) {
+    XSQ_REQUIRE(L > 0 && L % 4 == 0 && coefs_per_slice > 0 && nb > 0 && N > 0 && cs > 0 && max_stack > 0 && (passes || max_passes == 0),
+                "xsq_separator_schedule: bad argument");
+    const int64_t lim = ((1ll << 31) - 1) / (16 * std::max<int64_t>(coefs_per_slice, L / 2 + 1));
+    const int dflt = (int)std::min<int64_t>(lim, 65535 / 8);
+    const int cap = max_item_slices > 0 ? std::min(max_item_slices, dflt) : dflt;
+    std::vector<SchedPass> sched;
+    build_schedule(L, nb, N, cs, max_stack, wiener ? 1 : 0, cap, &sched);
+    for (size_t i = 0; i < sched.size() && (int)i < max_passes; ++i) {
+        const SchedPass& p = sched[i];
+        int64_t* o = passes + 8 * i;
+        o[0] = p.start; o[1] = p.n; o[2] = p.k; o[3] = p.b0; o[4] = p.nbb; o[5] = p.tail; o[6] = p.set_first; o[7] = p.needs_ext;
+    }
+    return (int)sched.size();
 }
 
 int xsq_demixer_set_max_rows(xsq_demixer* d, int max_item_slices) {
