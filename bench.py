@@ -847,6 +847,16 @@ def collective_block(dmx, dist, world, rank, dev, step_ms, other_ms, gather):
           "pci": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None), "host": socket.gethostname()}
     devices = [None] * world
     dist.all_gather_object(devices, me)
+    # every rank must end a gathered step holding the SAME bits of every track: an exact integer checksum of this rank's stems
+    # (the flat per-track allocation read as int32) against the other ranks' -- what the exchange is for, checked where it ran
+    replicas = None
+    if dmx.gather:
+        dmx.run()
+        torch.cuda.synchronize()
+        mine = int(dmx.flat.view(torch.int32).sum(dtype=torch.int64).item())
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        replicas = {"stems_checksum_int32_sum": sums[0], "identical_on_all_ranks": all(v == sums[0] for v in sums)}
     if rank != 0:
         return None
     acct = dmx.plan.exchange_bytes() if dmx.gather else {"collectives_per_step": 0, "bytes_in_per_rank_per_step": 0,
@@ -865,6 +875,7 @@ def collective_block(dmx, dist, world, rank, dev, step_ms, other_ms, gather):
     return {"backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged functional path, not a measurement of xGMI)"),
             "world": world, "devices": devices, "nccl_version": ver,
             "exchange": "sendrecv-inplace" if getattr(dmx, "exchange", "allgather") == "sendrecv" else "allgather+place",
+            "replicas": replicas,
             "op": EXCHANGE_WHAT[getattr(dmx, "exchange", "allgather")],
             **acct,
             "step_ms_with_gather": round(with_ms, 3) if with_ms is not None else None,
