@@ -49,3 +49,28 @@ def test_committed_profiles_fill_the_traffic_and_counter_fields():
     fft = bench.pmc_issue("slice_irfft_ola")
     assert fft is not None and fft["mfma_busy"] == 0.0 and fft["valu_issue"] > 0.4     # a vector-ALU kernel
     assert bench.pmc_traffic("no_such_kernel") is None and bench.pmc_issue("no_such_kernel") is None
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed bench line (profiles/*_bench.json, written by bench.py on an MI355X) against the contract: the
+    metric and unit are BASELINE.json's, the workload is named, value = audio-seconds / wall-seconds of the timed steps,
+    the roofline and cpu_baseline objects carry their fields, and the line says which bound the step ran at."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r0*_bench.json")))
+    d = json.load(open(files[-1]))
+    assert d["metric"] == base["metric"] == bench.METRIC and d["unit"] == "x real-time"
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - bench.TRACK_SAMPLES / bench.FS / (d["ms_per_step"] * 1e-3)) < 0.002 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["host_enqueue_ms"] < 0.5 * d["ms_per_step"]            # GPU-bound: the host issues a step in a fraction of its time
+    assert abs(d["gpu_span_ms"]["mean"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    for k in ("wiener", "train_step", "bf16x6", "bf16x3", "hip_graph"):
+        assert k in d["variants"]
