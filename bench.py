@@ -361,6 +361,8 @@ def main():
                     help="testset50: how the stems reach every rank -- sendrecv (default): every rank keeps the same flat per-track "
                          "layout, kernels write their rows in place, one grouped RCCL send/recv per pass moves rows owner -> peers "
                          "(xsq_exchange_rows); allgather: in-place all_gather_into_tensor per pass + one placement launch per exchange")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="testset50: skip the bitwise check of sampled tracks against Separator.forward (outside the timed region)")
     ap.add_argument("--no-gather", action="store_true",
                     help="testset50: headline without the all-gather (default: with it; the other one is a variant)")
     args = ap.parse_args()
@@ -421,6 +423,8 @@ def main():
         result = bench_testset(args, sep, dev, world, rank, dist)
     if world > 1:
         dist.barrier()
+    from xumx_slicq_amd.sharding import close_row_exchanges
+    close_row_exchanges()                 # the library's own RCCL communicator(s): before the process group goes
     if dist.is_initialized():
         dist.destroy_process_group()
     sys.stdout.flush()
@@ -700,6 +704,7 @@ def bench_testset(args, sep, dev, world, rank, dist):
     lengths = testset_lengths(args.tracks)
     total_s = sum(lengths) / FS
     cache = {}
+    requested_exchange = args.exchange
 
     def get_chunk(it):          # resident in HBM before timing starts; a rank only materialises its own items
         key = (it.track, it.chunk)
@@ -707,24 +712,25 @@ def bench_testset(args, sep, dev, world, rank, dist):
             cache[key] = synth_audio_device(it.length, seed=20260101 + 64 * it.track + it.chunk, device=dev)
         return cache[key]
 
+    def get_chunk_fresh(it):    # the same audio, not kept (the verification reads whole tracks once)
+        return synth_audio_device(it.length, seed=20260101 + 64 * it.track + it.chunk, device=dev)
+
     gather = not args.no_gather
     if world == 1 and args.gather_at_1:
         gather = "always"
-    exchange_note = None
-    try:
-        dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange=args.exchange)
-    except Exception as e:      # e.g. the library's own RCCL communicator could not be created: say so and use the all-gather form
-        if args.exchange != "sendrecv":
-            raise
-        exchange_note = "sendrecv-inplace unavailable (%s: %s); fell back to allgather+place" % (type(e).__name__, str(e)[:300])
-        print("bench.py: " + exchange_note, file=sys.stderr)
-        args.exchange = "allgather"
-        dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange="allgather")
+    # sendrecv needs the library's own RCCL communicator.  Whether it is usable is decided by ALL ranks together (an all-reduce
+    # of every rank's local outcome inside RowExchange / ShardedDemixer.settle): either every rank exchanges in place or every
+    # rank falls back to all-gather + placement, and the `collective` block says which and why.
+    dmx = ShardedDemixer(sep, lengths, get_chunk, dev, gather=gather, stack=args.stack, exchange=args.exchange, fallback=True)
     gather = dmx.gather
     for q in dmx.plan.rounds:
         for p in q[rank]:
             get_chunk(p.item)
     torch.cuda.synchronize()
+    exchange_note = dmx.settle()          # first exchange as a warm-up step; its outcome is a collective decision too
+    if exchange_note:
+        print("bench.py: " + exchange_note, file=sys.stderr)
+    args.exchange = dmx.exchange
 
     prof_all = instrumented_warmup(dmx.run, args.warmup)
     dom = max(prof_all, key=lambda k: prof_all[k][0]) if prof_all else None
@@ -734,13 +740,14 @@ def bench_testset(args, sep, dev, world, rank, dist):
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     _lib.profile_filter(None)
+    verified = verify_testset(dmx, sep, lengths, get_chunk_fresh, dist, world, rank, dev) if not args.no_verify else None
 
     variants = {}
     other_ms = None
     if not args.no_variants:
         # (a) the same step with the other exchange setting
         if world > 1:
-            other = ShardedDemixer(sep, lengths, get_chunk, dev, gather=not gather, stack=args.stack, exchange=args.exchange)
+            other = ShardedDemixer(sep, lengths, get_chunk, dev, gather=not gather, stack=args.stack, exchange=args.exchange, fallback=True)
             for _ in range(max(1, args.warmup)):
                 other.run()
             dto, _ = timed_steps(other.run, args.steps, world, dist, dev)
@@ -753,14 +760,21 @@ def bench_testset(args, sep, dev, world, rank, dist):
         # (a2) the same step through the OTHER exchange (A/B of the two forms of the waveform concat)
         if (world > 1 or dmx.gather) and gather:
             alt_name = "allgather" if args.exchange == "sendrecv" else "sendrecv"
-            alt = ShardedDemixer(sep, lengths, get_chunk, dev, gather=("always" if world == 1 else True), stack=args.stack, exchange=alt_name)
-            for _ in range(max(1, args.warmup)):
-                alt.run()
-            dta, _ = timed_steps(alt.run, args.steps, world, dist, dev)
-            variants["exchange_" + alt_name] = {
-                "what": "the same step with exchange = %s (%s)" % (alt_name, EXCHANGE_WHAT[alt_name]),
-                "value": round(args.steps * total_s / dta, 2), "unit": "x real-time", "ms_per_step": round(dta / args.steps * 1e3, 3)}
-            del alt
+            from xumx_slicq_amd.sharding import ExchangeUnavailable
+            try:            # (raised on every rank together or on none: RowExchange decides collectively)
+                alt = ShardedDemixer(sep, lengths, get_chunk, dev, gather=("always" if world == 1 else True), stack=args.stack, exchange=alt_name)
+                alt.settle()
+            except ExchangeUnavailable as e:
+                alt = None
+                variants["exchange_" + alt_name] = {"what": "exchange = %s not available on every rank: %s" % (alt_name, str(e)[:200])}
+            if alt is not None:
+                for _ in range(max(1, args.warmup)):
+                    alt.run()
+                dta, _ = timed_steps(alt.run, args.steps, world, dist, dev)
+                variants["exchange_" + alt_name] = {
+                    "what": "the same step with exchange = %s (%s)" % (alt_name, EXCHANGE_WHAT[alt_name]),
+                    "value": round(args.steps * total_s / dta, 2), "unit": "x real-time", "ms_per_step": round(dta / args.steps * 1e3, 3)}
+                del alt
         # (b) the whole set on rank 0 alone: the single-GPU rate on the SAME workload
         if world > 1:
             dist.barrier()
@@ -821,13 +835,53 @@ def bench_testset(args, sep, dev, world, rank, dist):
         "roofline_hbm": hbm,
         "roofline_mfma": mfma,
     }
+    if verified is not None:
+        result["verified"] = verified
     if collective:
-        if exchange_note:
-            collective["exchange_note"] = exchange_note
+        collective["exchange_requested"] = requested_exchange
+        collective["exchange_note"] = exchange_note or "the requested exchange ran on every rank (collective decision: construction and first exchange succeeded everywhere)"
         result["collective"] = collective
     if variants:
         result["variants"] = variants
     return result
+
+
+def verify_testset(dmx, sep, lengths, get_chunk, dist, world, rank, dev, k=4):
+    """Outside the timed region: K sampled tracks of the step's result against `Separator.forward` of the whole track on
+    this rank -- bitwise (the sharded path stacks items of DIFFERENT tracks per pass and writes them through row offsets
+    into one flat allocation of > 2^32 floats; per-track forward stacks a track's own chunks).  The sample holds the first
+    and the last track, the track whose span of the flat allocation crosses 2^32 elements, and the longest one.  A rank
+    that holds only its own items (no gather) compares those spans.  Every rank checks; the line reports the AND."""
+    import torch
+    from xumx_slicq_amd.sharding import all_ranks_ok, chunk_items
+    nt = len(lengths)
+    cross = next((t for t in range(nt) if dmx.track_off[t] < (1 << 32) <= dmx.track_off[t + 1]), None)
+    pick = []
+    for t in (0, nt - 1, cross, max(range(nt), key=lambda i: lengths[i])):
+        if t is not None and t not in pick:
+            pick.append(t)
+    pick = pick[:k]
+    whole = dmx.gather or world == 1
+    mine = {(p.item.track, p.item.chunk) for rnd in dmx.plan.rounds for p in rnd[dmx.rank]}
+    ok, worst = True, 0.0
+    for t in pick:
+        items = chunk_items([lengths[t]], sep.chunk_size)
+        x = torch.cat([get_chunk(type(it)(t, it.chunk, it.start, it.length)) for it in items], dim=-1)
+        ref = sep(x)
+        got = dmx.out[t]
+        for it in items:
+            if whole or (t, it.chunk) in mine:
+                a, b = got[..., it.start:it.start + it.length], ref[..., it.start:it.start + it.length]
+                if not torch.equal(a, b):
+                    ok = False
+                    worst = max(worst, float((a - b).abs().max()))
+        del x, ref
+    torch.cuda.synchronize()
+    agree = all_ranks_ok(ok, None, dev, world) if world > 1 else ok
+    return {"tracks": pick, "bitwise": bool(agree), "against": "Separator.forward of the whole track on the checking rank",
+            "scope": "whole tracks on every rank" if whole else "the spans of each rank's own items",
+            "track_crossing_2^32_flat_elements": cross, "flat_elements": int(dmx.track_off[-1]),
+            "max_abs_diff_this_rank": worst}
 
 
 EXCHANGE_WHAT = {"sendrecv": "sendrecv-inplace: same flat per-track layout on every rank, kernels write their rows in place, one grouped "

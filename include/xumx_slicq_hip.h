@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define XSQ_ABI_VERSION 1
+#define XSQ_ABI_VERSION 2   /* 2 (round 5): xsq_exchange_rows takes the buffer lengths; *_indirect entry points */
 
 typedef struct xsq_plan xsq_plan;
 typedef struct xsq_model xsq_model;
@@ -116,6 +116,13 @@ int xsq_slicqt_forward_xin(xsq_plan* plan, const float* x, int BC, int64_t n, fl
 int xsq_slicqt_forward_rows(xsq_plan* plan, const float* x, const int64_t* x_row_offsets, int BC, int64_t n,
                             int64_t n_pad, float* coef, float* xin, const float* mean, const float* scale, int split,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same call with the input's base pointer read from DEVICE memory when the kernel runs: x_slot != NULL -> the rows
+ * start at *x_slot + x_row_offsets[r] (x is then ignored and may be NULL).  A HIP graph captured around the call follows
+ * whatever tensor the caller points the slot at before each replay (an 8-byte device write) -- the graphed form of the
+ * `separator(audio)` call timed at inference.py:28-31 needs no copy of the input into a static buffer.               */
+int xsq_slicqt_forward_rows_indirect(xsq_plan* plan, const float* x, const float* const* x_slot, const int64_t* x_row_offsets,
+                                     int BC, int64_t n, int64_t n_pad, float* coef, float* xin, const float* mean,
+                                     const float* scale, int split, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- inverse sliCQT -----------------------------------------------------------
  * Replaces INSGT_SL.forward (transforms.py:154-178) -> NSGT_sliced.backward
@@ -236,17 +243,19 @@ int xsq_place_rows(const float* src, float* dst, const int64_t* table, int nrows
  *   xsq_comm_create     ncclCommInitRank on the CURRENT device -- collective over the ranks
  *   xsq_exchange_rows   rows: HOST int64[nrows][4] = (owner rank, src float offset, dst float offset, length), the same
  *                       table on every rank; the owner sends src + src_off to every peer, every other rank receives into
- *                       dst + dst_off (src == dst and equal offsets: in place).  One ncclGroupStart ... ncclGroupEnd on
- *                       `stream`, asynchronous.  self_loop != 0 (tests, group of one): the owner also sends to ITSELF and
- *                       receives into dst -- src and dst must then not overlap.                                       */
+ *                       dst + dst_off (src == dst and equal offsets: in place).  src_len / dst_len: floats behind src / dst --
+ *                       every row's spans are checked against them before anything is queued.  Grouped ncclSend / ncclRecv
+ *                       on `stream`, asynchronous; a group is closed every XSQ_EXCHANGE_GROUP_ROWS rows (default ~1024
+ *                       point-to-point operations), at the same rows on every rank.  self_loop != 0 (tests, group of
+ *                       one): the owner also sends to ITSELF and receives into dst -- src and dst must then not overlap. */
 typedef struct xsq_comm xsq_comm;
 int xsq_comm_load(const char* librccl_path);
 int xsq_comm_version(void);                                                /* ncclGetVersion code, -1 on error */
 int xsq_comm_unique_id(void* id128);
 int xsq_comm_create(xsq_comm** out, const void* id128, int world, int rank);
 int xsq_comm_destroy(xsq_comm* comm);
-int xsq_exchange_rows(xsq_comm* comm, const float* src, float* dst, const int64_t* rows, int nrows, int self_loop,
-                      void* stream);
+int xsq_exchange_rows(xsq_comm* comm, const float* src, int64_t src_len, float* dst, int64_t dst_len, const int64_t* rows,
+                      int nrows, int self_loop, void* stream);
 
 /* The same EM iteration fed by the MASKS (real arena, 8*B channels: what xsq_cdae_forward writes with Y = NULL): the
  * initial estimate y0 = mask * x (model.py:262-264 -> phase.py:96-113; == mask * X) is formed
@@ -364,6 +373,13 @@ int xsq_separator_forward(xsq_demixer* d, xsq_model* model, const float* audio, 
                           int max_stack, int wiener, int overlap_tail, float* out, void* workspace,
                           size_t workspace_bytes, void* tail_workspace, size_t tail_workspace_bytes, void* stream,
                           void* tail_stream);
+/* xsq_separator_forward with the audio's base pointer in a DEVICE slot (audio_slot: device address of one `const float*`),
+ * read by the first kernel of every pass when it RUNS: the call can be captured once in a HIP graph and replayed on any
+ * (nb, 2, N) tensor of the captured shape after an 8-byte write to the slot (Separator.forward_graphed).              */
+int xsq_separator_forward_indirect(xsq_demixer* d, xsq_model* model, const float* const* audio_slot, int nb, int64_t N,
+                                   int64_t chunk_size, int max_stack, int wiener, int overlap_tail, float* out,
+                                   void* workspace, size_t workspace_bytes, void* tail_workspace,
+                                   size_t tail_workspace_bytes, void* stream, void* tail_stream);
 /* The schedule xsq_separator_forward follows for a call shape, as pure host arithmetic (no device needed): pass i ->
  * passes[8 i ..] = (first sample of its first chunk, samples per chunk, chunks stacked, first sample index of the batch,
  * samples of the batch in this pass, 1 = may run on the tail stream, index of the first pass of its set, 1 = the set

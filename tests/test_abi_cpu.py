@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/xumx_slicq_hip.h but not exported"
         assert n in _lib.EXPORTED, f"{n} has no ctypes signature in _lib.py"
-    assert _lib.lib.xsq_abi_version() == 1
+    assert _lib.lib.xsq_abi_version() == 2
 
 
 def test_null_arguments_are_rejected_not_crashed():

@@ -286,9 +286,23 @@ def test_hip_graph_replay_matches_eager(seps):
             ea, eb = sep(a).clone(), sep(b).clone()
             ga = sep.forward_graphed(a).clone()
             gb = sep.forward_graphed(b).clone()        # replay of the cached graph with new input
+            # round 5: the replay reads the caller's tensor through a device pointer slot (xsq_separator_forward_indirect) --
+            # no static input buffer, the slot follows the tensor (a, b, a again, a tensor inside a larger allocation)
+            (entry,) = sep._graphs.values()
+            assert entry[1] is None and entry[4] is not None and int(entry[4].item()) == b.data_ptr()
+            ga2 = sep.forward_graphed(a).clone()
+            big = torch.zeros(3, 2, 150000, device="cuda")
+            big[1] = b[0]
+            gb2 = sep.forward_graphed(big[1:2]).clone()
+            assert len(sep._graphs) == 1
+            sep.native = False                          # the module-API schedule keeps the static-input form
+            gm = sep.forward_graphed(b).clone()
+            assert len(sep._graphs) == 2
         finally:
             sep.chunk_size = 2621440
-        assert torch.equal(ea, ga) and torch.equal(eb, gb)
+            sep.__dict__.pop("native", None)
+            sep.drop_graphs()
+        assert torch.equal(ea, ga) and torch.equal(eb, gb) and torch.equal(ea, ga2) and torch.equal(eb, gb2) and torch.equal(eb, gm)
 
 
 @pytest.mark.gpu

@@ -182,3 +182,66 @@ def test_single_process_without_process_group():
     out = demix_sharded(fake_separate, tracks, chunk_size=400)
     ref = torch.cat([fake_separate(tracks[0][..., s:s + 400]) for s in range(0, 1500, 400)], dim=-1)
     assert torch.equal(out[0], ref)
+
+
+def _fault_worker(rank, world, port, q, fault):
+    """One rank fails a LOCAL step of the exchange's construction (XSQ_FAULT_INJECT); the decision has to come out the same
+    on both ranks: both raise ExchangeUnavailable (no fallback) or both end up on the all-gather form (fallback) -- and the
+    run after the decision is still bitwise the sequential result."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = (rank, "not run")
+    try:
+        from xumx_slicq_amd.sharding import ExchangeUnavailable, all_ranks_ok, close_row_exchanges
+        g = torch.Generator().manual_seed(0)
+        tracks = [torch.randn(1, 2, n, generator=g) for n in (2500, 700, 1301, 64)]
+        ref = _sequential(tracks)
+        get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+        lens = [x.shape[-1] for x in tracks]
+        notes = []
+        assert all_ranks_ok(True) is True and all_ranks_ok(rank != 1) is False        # MIN over the ranks
+        os.environ["XSQ_FAULT_INJECT"] = fault
+        try:
+            ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv")
+            notes.append("no-fallback: did not raise")
+        except ExchangeUnavailable:
+            pass
+        dmx = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv", fallback=True)
+        if dmx.exchange != "allgather" or not dmx.exchange_note:
+            notes.append(f"fallback: exchange={dmx.exchange} note={dmx.exchange_note}")
+        note = dmx.settle()
+        got = dmx.run()
+        if not all(torch.equal(got[t], ref[t]) for t in ref):
+            notes.append("fallback run differs")
+        os.environ["XSQ_FAULT_INJECT"] = ""
+        ok = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv", fallback=True)
+        if ok.exchange != "sendrecv" or ok.exchange_note is not None or ok.settle() is not None:
+            notes.append(f"healthy: exchange={ok.exchange} note={ok.exchange_note}")
+        got = ok.run()
+        if not all(torch.equal(got[t], ref[t]) for t in ref):
+            notes.append("healthy run differs")
+        close_row_exchanges()
+        res = (rank, "ok" if not notes else "; ".join(notes) + f" ({note})")
+    except Exception as e:                                  # noqa: BLE001
+        res = (rank, f"{type(e).__name__}: {e}")
+    finally:
+        q.put(res)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fault", ["load:1", "load:0", "init:1"])
+def test_exchange_fallback_is_a_collective_decision(fault):
+    """a rank-local failure while the in-place exchange is set up must not leave the ranks in
+    different modes.  Rank 0 or rank 1 fails before the id broadcast / at communicator creation."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fault_worker, args=(r, 2, port, q, fault)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, "ok"), (1, "ok")], res

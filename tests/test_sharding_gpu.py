@@ -130,6 +130,8 @@ def _worker(rank, world, port, q, backend="gloo", gather=True, exchange="sendrec
         res = (rank, f"{type(e).__name__}: {e}")
     finally:
         q.put(res)
+        from xumx_slicq_amd.sharding import close_row_exchanges
+        close_row_exchanges()
         dist.destroy_process_group()
 
 

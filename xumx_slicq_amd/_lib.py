@@ -56,6 +56,7 @@ _SIGS = {
     "xsq_slicqt_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_forward_xin": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_forward_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "xsq_slicqt_forward_rows_indirect": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_slicqt_inverse": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "xsq_slicqt_inverse_rows": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
@@ -96,12 +97,13 @@ _SIGS = {
     "xsq_demix_pass": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "xsq_separator_workspace": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "xsq_separator_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
+    "xsq_separator_forward_indirect": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "xsq_comm_load": (C.c_int, [C.c_char_p]),
     "xsq_comm_version": (C.c_int, []),
     "xsq_comm_unique_id": (C.c_int, [_vp]),
     "xsq_comm_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "xsq_comm_destroy": (C.c_int, [_vp]),
-    "xsq_exchange_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "xsq_exchange_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int, _vp]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),
     "xsq_profile_filter": (C.c_int, [C.c_char_p]),

@@ -41,6 +41,10 @@ struct PassPlan {
 struct ForwardPlan {
     std::vector<PassPlan> passes;
     int64_t* d_tables = nullptr;     // one allocation behind all d_xrows / d_orows
+    int64_t* h_tables = nullptr;     // pinned host copy: uploaded with hipMemcpyAsync on the first call's stream (no host stall per new shape)
+    size_t table_words = 0;
+    bool uploaded = false;
+    uint64_t last_use = 0;           // LRU stamp (xsq_demixer::clock)
     size_t main_bytes = 0, tail_bytes = 0;
     size_t ext_floats = 0;           // window-maximum tables of the split sets (zeroed at the start of every call)
 };
@@ -54,7 +58,11 @@ struct xsq_demixer {
     int max_item_slices = 0;
     std::vector<int32_t> F, T;
     std::mutex mu;
+    // schedules + device row tables per call shape, least-recently-used bound: a test set of distinct track lengths would
+    // otherwise leave one device allocation per length behind
     std::map<std::vector<int64_t>, ForwardPlan> plans;
+    uint64_t clock = 0;
+    static constexpr size_t kMaxPlans = 64;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -93,7 +101,7 @@ static int pass_layout(xsq_demixer* d, const xsq_model* Mo, int B, int64_t n_pad
     return XSQ_OK;
 }
 
-static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t* x_rows, int B, int64_t n, int64_t n_pad,
+static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const float* const* x_slot, const int64_t* x_rows, int B, int64_t n, int64_t n_pad,
                     int group, int wiener, float* out, const int64_t* out_rows, void* ws, size_t ws_bytes, hipStream_t stream,
                     const float* ext_max = nullptr) {
     xsq_plan* P = d->plan;
@@ -114,7 +122,8 @@ static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t
     if ((rc = xsq_model_whitening(Mo, &mean, &scale, &split))) return rc;
     // the analysis kernels write the whitened magnitude into the head of the CDAE workspace (xsq_cdae_forward_xin, xin_ready)
     float* xin = (float*)(w + L.cdae);
-    if ((rc = xsq_slicqt_forward_rows(P, x, x_rows, 2 * B, n, n_pad, X, xin, mean, scale, split, w + L.fwd, L.fwd_bytes, stream))) return rc;
+    if ((rc = xsq_slicqt_forward_rows_indirect(P, x, x_slot, x_rows, 2 * B, n, n_pad, X, xin, mean, scale, split, w + L.fwd, L.fwd_bytes, stream)))
+        return rc;
     if ((rc = xsq_cdae_forward_xin(Mo, X, B, S, nullptr, masks, w + L.cdae, L.cdae_bytes, stream, 1))) return rc;
     if (!wiener)
         return xsq_slicqt_inverse_masked(P, masks, X, 8 * B, 2 * B, S, n, out, out_rows, w + L.inv, L.inv_bytes, stream);
@@ -125,7 +134,7 @@ static int run_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t
 }
 
 // One pass of a split batch, first half: its mix transform and the window maxima of its samples folded into the set's table.
-static int run_prepass(xsq_demixer* d, xsq_model* Mo, const float* x, const PassPlan& p, void* ws, size_t ws_bytes, float* ext,
+static int run_prepass(xsq_demixer* d, xsq_model* Mo, const float* x, const float* const* x_slot, const PassPlan& p, void* ws, size_t ws_bytes, float* ext,
                        hipStream_t stream) {
     xsq_plan* P = d->plan;
     PassLayout L;
@@ -135,7 +144,8 @@ static int run_prepass(xsq_demixer* d, xsq_model* Mo, const float* x, const Pass
     const int S = xsq_plan_num_slices(P, p.n_pad);
     char* w = (char*)ws;
     float* X = (float*)(w + L.X);
-    if ((rc = xsq_slicqt_forward_rows(P, x, p.d_xrows, 2 * p.B, p.n, p.n_pad, X, nullptr, nullptr, nullptr, 0, w + L.fwd, L.fwd_bytes, stream)))
+    if ((rc = xsq_slicqt_forward_rows_indirect(P, x, x_slot, p.d_xrows, 2 * p.B, p.n, p.n_pad, X, nullptr, nullptr, nullptr, 0, w + L.fwd, L.fwd_bytes,
+                                               stream)))
         return rc;
     return xsq_wiener_window_max(P->nblocks, d->F.data(), d->T.data(), X, p.B, S, 5000, p.group, ext + p.ext_off, stream);
 }
@@ -197,7 +207,18 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     xsq_plan* P = d->plan;
     const std::vector<int64_t> key{nb, N, cs, max_stack, wiener, d->max_item_slices, Mo->causal};
     auto it = d->plans.find(key);
-    if (it != d->plans.end()) { *out = &it->second; return XSQ_OK; }
+    if (it != d->plans.end()) { it->second.last_use = ++d->clock; *out = &it->second; return XSQ_OK; }
+    if (d->plans.size() >= xsq_demixer::kMaxPlans) {
+        // evict the least recently used shape.  Its tables may still be read by kernels in flight (any stream): wait for the
+        // device once -- this happens once per kMaxPlans NEW shapes, never in a steady loop over known shapes.
+        auto victim = d->plans.begin();
+        for (auto p = d->plans.begin(); p != d->plans.end(); ++p)
+            if (p->second.last_use < victim->second.last_use) victim = p;
+        XSQ_HIP(hipDeviceSynchronize());
+        (void)hipFree(victim->second.d_tables);
+        (void)hipHostFree(victim->second.h_tables);
+        d->plans.erase(victim);
+    }
     const int64_t min_samples = P->L / 2 + 1;                      // separator.py:162
     const int cap = d->max_item_slices > 0 ? d->max_item_slices : default_max_item_slices(P);
     ForwardPlan fp;
@@ -232,21 +253,27 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     }
     size_t total = 0;
     for (auto& p : fp.passes) total += (size_t)10 * p.B;
-    std::vector<int64_t> host(total);
     XSQ_HIP(hipMalloc(&fp.d_tables, std::max<size_t>(total, 1) * sizeof(int64_t)));
+    if (hipHostMalloc(&fp.h_tables, std::max<size_t>(total, 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(fp.d_tables);
+        set_error("xsq_separator_forward: hipHostMalloc of %zu table words failed", total);
+        return XSQ_ERR_HIP;
+    }
+    fp.table_words = total;
+    int64_t* host = fp.h_tables;
     size_t o = 0;
     for (size_t i = 0; i < fp.passes.size(); ++i) {
         PassPlan& p = fp.passes[i];
-        p.d_xrows = fp.d_tables + o; std::copy(xr[i].begin(), xr[i].end(), host.begin() + o); o += xr[i].size();
-        p.d_orows = fp.d_tables + o; std::copy(orw[i].begin(), orw[i].end(), host.begin() + o); o += orw[i].size();
+        p.d_xrows = fp.d_tables + o; std::copy(xr[i].begin(), xr[i].end(), host + o); o += xr[i].size();
+        p.d_orows = fp.d_tables + o; std::copy(orw[i].begin(), orw[i].end(), host + o); o += orw[i].size();
         PassLayout L;
         int rc = pass_layout(d, Mo, p.B, p.n_pad, wiener, &L);
-        if (rc) { (void)hipFree(fp.d_tables); return rc; }
+        if (rc) { (void)hipFree(fp.d_tables); (void)hipHostFree(fp.h_tables); return rc; }
         size_t& dst = p.tail ? fp.tail_bytes : fp.main_bytes;
         dst = std::max(dst, L.total);
     }
     fp.main_bytes += al256(fp.ext_floats * 4);
-    XSQ_HIP(hipMemcpy(fp.d_tables, host.data(), total * sizeof(int64_t), hipMemcpyHostToDevice));
+    fp.last_use = ++d->clock;
     auto ins = d->plans.emplace(key, fp);
     *out = &ins.first->second;
     return XSQ_OK;
@@ -274,7 +301,7 @@ int xsq_demixer_create(xsq_demixer** out, xsq_plan* plan) {
 
 int xsq_demixer_destroy(xsq_demixer* d) {
     if (!d) return XSQ_OK;
-    for (auto& kv : d->plans) (void)hipFree(kv.second.d_tables);
+    for (auto& kv : d->plans) { (void)hipFree(kv.second.d_tables); (void)hipHostFree(kv.second.h_tables); }
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     delete d;
@@ -317,7 +344,7 @@ int xsq_demix_pass(xsq_demixer* d, xsq_model* Mo, const float* x, const int64_t*
     XSQ_REQUIRE(B > 0 && n > 0 && n_pad >= n, "xsq_demix_pass: B=%d n=%lld n_pad=%lld", B, (long long)n, (long long)n_pad);
     if (group <= 0) group = B;
     XSQ_REQUIRE(B % group == 0, "xsq_demix_pass: group=%d does not divide B=%d", group, B);
-    return run_pass(d, Mo, x, x_rows, B, n, n_pad, group, wiener, out, out_rows, ws, ws_bytes, (hipStream_t)stream);
+    return run_pass(d, Mo, x, nullptr, x_rows, B, n, n_pad, group, wiener, out, out_rows, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int xsq_separator_workspace(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t N, int64_t cs, int max_stack, int wiener,
@@ -334,10 +361,30 @@ int xsq_separator_workspace(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     return XSQ_OK;
 }
 
+static int separator_forward_impl(xsq_demixer* d, xsq_model* Mo, const float* audio, const float* const* x_slot, int nb, int64_t N, int64_t cs,
+                                  int max_stack, int wiener, int overlap_tail, float* out, void* ws, size_t ws_bytes, void* tail_ws,
+                                  size_t tail_ws_bytes, void* stream_, void* tail_stream_);
+
 int xsq_separator_forward(xsq_demixer* d, xsq_model* Mo, const float* audio, int nb, int64_t N, int64_t cs, int max_stack,
                           int wiener, int overlap_tail, float* out, void* ws, size_t ws_bytes, void* tail_ws,
                           size_t tail_ws_bytes, void* stream_, void* tail_stream_) {
-    XSQ_REQUIRE(d && Mo && audio && out && ws, "xsq_separator_forward: null argument");
+    XSQ_REQUIRE(audio, "xsq_separator_forward: null argument");
+    return separator_forward_impl(d, Mo, audio, nullptr, nb, N, cs, max_stack, wiener, overlap_tail, out, ws, ws_bytes, tail_ws, tail_ws_bytes,
+                                  stream_, tail_stream_);
+}
+
+int xsq_separator_forward_indirect(xsq_demixer* d, xsq_model* Mo, const float* const* audio_slot, int nb, int64_t N, int64_t cs,
+                                   int max_stack, int wiener, int overlap_tail, float* out, void* ws, size_t ws_bytes, void* tail_ws,
+                                   size_t tail_ws_bytes, void* stream_, void* tail_stream_) {
+    XSQ_REQUIRE(audio_slot, "xsq_separator_forward_indirect: null argument");
+    return separator_forward_impl(d, Mo, nullptr, audio_slot, nb, N, cs, max_stack, wiener, overlap_tail, out, ws, ws_bytes, tail_ws,
+                                  tail_ws_bytes, stream_, tail_stream_);
+}
+
+static int separator_forward_impl(xsq_demixer* d, xsq_model* Mo, const float* audio, const float* const* x_slot, int nb, int64_t N, int64_t cs,
+                                  int max_stack, int wiener, int overlap_tail, float* out, void* ws, size_t ws_bytes, void* tail_ws,
+                                  size_t tail_ws_bytes, void* stream_, void* tail_stream_) {
+    XSQ_REQUIRE(d && Mo && (audio || x_slot) && out && ws, "xsq_separator_forward: null argument");
     XSQ_REQUIRE(nb > 0 && N > 0 && cs > 0 && max_stack > 0, "xsq_separator_forward: nb=%d N=%lld chunk_size=%lld max_stack=%d",
                 nb, (long long)N, (long long)cs, max_stack);
     hipStream_t main = (hipStream_t)stream_, side = (hipStream_t)tail_stream_;
@@ -346,6 +393,10 @@ int xsq_separator_forward(xsq_demixer* d, xsq_model* Mo, const float* audio, int
         std::lock_guard<std::mutex> lk(d->mu);
         int rc = get_forward_plan(d, Mo, nb, N, cs, max_stack, wiener ? 1 : 0, &fp);
         if (rc) return rc;
+        if (!fp->uploaded) {             // first call of this shape: the row tables go up on the call's own stream, in front of its kernels
+            XSQ_HIP(hipMemcpyAsync(fp->d_tables, fp->h_tables, fp->table_words * sizeof(int64_t), hipMemcpyHostToDevice, main));
+            fp->uploaded = true;
+        }
     }
     bool any_tail = false;
     for (const PassPlan& p : fp->passes) any_tail = any_tail || p.tail;
@@ -354,34 +405,48 @@ int xsq_separator_forward(xsq_demixer* d, xsq_model* Mo, const float* audio, int
                 "xsq_separator_forward: workspace too small (%zu / %zu needed, %zu / %zu given)", fp->main_bytes, fp->tail_bytes,
                 ws_bytes, tail_ws_bytes);
     XSQ_REQUIRE(beside || ws_bytes >= std::max(fp->main_bytes, fp->tail_bytes), "xsq_separator_forward: workspace too small for the tail pass");
-    int rc;
+    int rc = XSQ_OK;
+    bool forked = false;
     // The short tail chunks are launch-bound passes, independent of the stacked ones: they go out first, on the side
-    // stream with their own workspace, and fill in beside the big launches; the caller's stream joins at the end.
+    // stream with their own workspace, and fill in beside the big launches; the caller's stream joins at the end -- on the
+    // error paths too: whatever the side stream was given stays ordered in front of the caller's next use of `out`.
+    auto join = [&]() -> int {
+        if (!forked) return XSQ_OK;
+        forked = false;
+        XSQ_HIP(hipEventRecord(d->ev_join, side));
+        XSQ_HIP(hipStreamWaitEvent(main, d->ev_join, 0));
+        return XSQ_OK;
+    };
     if (beside) {
         XSQ_HIP(hipEventRecord(d->ev_fork, main));
         XSQ_HIP(hipStreamWaitEvent(side, d->ev_fork, 0));
+        forked = true;
         for (const PassPlan& p : fp->passes)
-            if (p.tail && (rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, tail_ws, tail_ws_bytes, side)))
-                return rc;
-        XSQ_HIP(hipEventRecord(d->ev_join, side));
+            if (p.tail && (rc = run_pass(d, Mo, audio, x_slot, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, tail_ws, tail_ws_bytes, side)))
+                break;
+        if (rc) { const std::string why = xsq_last_error(); (void)join(); set_error("%s", why.c_str()); return rc; }
     }
     float* ext = (float*)ws;                                  // window-maximum tables of split sets (head of the workspace)
     const size_t ext_bytes = al256(fp->ext_floats * 4);
     char* pws = (char*)ws + ext_bytes;
     const size_t pws_bytes = ws_bytes - ext_bytes;
-    if (fp->ext_floats) XSQ_HIP(hipMemsetAsync(ext, 0, fp->ext_floats * 4, main));
-    for (size_t i = 0; i < fp->passes.size(); ++i) {
+    if (fp->ext_floats && hipMemsetAsync(ext, 0, fp->ext_floats * 4, main) != hipSuccess) {
+        (void)join();
+        set_error("xsq_separator_forward: hipMemsetAsync failed");
+        return XSQ_ERR_HIP;
+    }
+    for (size_t i = 0; i < fp->passes.size() && rc == XSQ_OK; ++i) {
         const PassPlan& p = fp->passes[i];
         if (p.tail && beside) continue;
         if (p.ext_off >= 0 && (int)i == p.set_first)       // first pass of a split set: every pass's maxima first
-            for (int j = 0; j < p.set_count; ++j)
-                if ((rc = run_prepass(d, Mo, audio, fp->passes[i + j], pws, pws_bytes, ext, main))) return rc;
-        if ((rc = run_pass(d, Mo, audio, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, pws, pws_bytes, main,
-                           p.ext_off >= 0 ? ext + p.ext_off : nullptr)))
-            return rc;
+            for (int j = 0; j < p.set_count && rc == XSQ_OK; ++j)
+                rc = run_prepass(d, Mo, audio, x_slot, fp->passes[i + j], pws, pws_bytes, ext, main);
+        if (rc == XSQ_OK)
+            rc = run_pass(d, Mo, audio, x_slot, p.d_xrows, p.B, p.n, p.n_pad, p.group, wiener, out, p.d_orows, pws, pws_bytes, main,
+                          p.ext_off >= 0 ? ext + p.ext_off : nullptr);
     }
-    if (beside) XSQ_HIP(hipStreamWaitEvent(main, d->ev_join, 0));
-    return XSQ_OK;
+    if (rc) { const std::string why = xsq_last_error(); (void)join(); set_error("%s", why.c_str()); return rc; }
+    return join();
 }
 
 }  // extern "C"

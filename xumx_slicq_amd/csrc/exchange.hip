@@ -9,6 +9,7 @@
 // same way _lib.py shares torch's HIP runtime; nothing here links against it.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -48,9 +49,10 @@ static int load_rccl(const char* path) {
     const char* cands[] = {path, getenv("XSQ_RCCL_LIB"), "librccl.so", "librccl.so.1"};
     for (const char* c : cands) {
         if (!c || !*c) continue;
-        // the copy the process already mapped wins (one RCCL per process); else load it
-        h = dlopen(c, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-        if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        // the copy the process already mapped wins (one RCCL per process); else load it -- RTLD_LOCAL either way: every
+        // symbol is reached through dlsym on this handle, nothing of RCCL's is exported process-wide on our account
+        h = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (!h) h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
         tried += std::string(tried.empty() ? "" : ", ") + c;
     }
@@ -136,32 +138,56 @@ int xsq_comm_destroy(xsq_comm* c) {
     return XSQ_OK;
 }
 
-int xsq_exchange_rows(xsq_comm* c, const float* src, float* dst, const int64_t* rows, int nrows, int self_loop, void* stream_) {
-    XSQ_REQUIRE(c && c->comm && src && dst && (rows || nrows == 0) && nrows >= 0, "xsq_exchange_rows: bad argument");
+// Rows per ncclGroupStart / ncclGroupEnd.  The cut is by ROW INDEX, never by operation count: the table is identical on every
+// rank, so every rank closes its groups behind the same rows and the sends of one rank's group k meet the receives of its
+// peers' group k (an owner issues world - 1 sends per row, everybody else one receive: a cut by operations would fall at
+// different rows on different ranks).  Default: ~1024 point-to-point operations per group on the busiest rank.
+static int rows_per_group(int world) {
+    const char* e = getenv("XSQ_EXCHANGE_GROUP_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : std::max(1, 1024 / std::max(1, world - 1));
+}
+
+int xsq_exchange_rows(xsq_comm* c, const float* src, int64_t src_len, float* dst, int64_t dst_len, const int64_t* rows, int nrows,
+                      int self_loop, void* stream_) {
+    XSQ_REQUIRE(c && c->comm && src && dst && (rows || nrows == 0) && nrows >= 0 && src_len >= 0 && dst_len >= 0,
+                "xsq_exchange_rows: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
-    for (int i = 0; i < nrows; ++i)
-        XSQ_REQUIRE(rows[4 * i] >= 0 && rows[4 * i] < c->world && rows[4 * i + 3] >= 0, "xsq_exchange_rows: row %d: owner %lld of %d ranks, length %lld",
-                    i, (long long)rows[4 * i], c->world, (long long)rows[4 * i + 3]);
-    XSQ_NCCL(g_rccl.GroupStart());
-    int rc = XSQ_OK;
-    for (int i = 0; i < nrows && rc == XSQ_OK; ++i) {
-        const int owner = (int)rows[4 * i];
-        const int64_t so = rows[4 * i + 1], dof = rows[4 * i + 2], len = rows[4 * i + 3];
-        if (len == 0) continue;
-        if (owner == c->rank) {
-            for (int peer = 0; peer < c->world && rc == XSQ_OK; ++peer) {
-                if (peer == c->rank && !self_loop) continue;
-                if (g_rccl.Send(src + so, (size_t)len, NCCL_FLOAT32, peer, c->comm, stream) != 0) rc = XSQ_ERR_HIP;
-            }
-            if (self_loop && rc == XSQ_OK && g_rccl.Recv(dst + dof, (size_t)len, NCCL_FLOAT32, c->rank, c->comm, stream) != 0) rc = XSQ_ERR_HIP;
-        } else if (g_rccl.Recv(dst + dof, (size_t)len, NCCL_FLOAT32, owner, c->comm, stream) != 0) {
-            rc = XSQ_ERR_HIP;
-        }
+    // the whole table is checked before the first operation is queued: a bad row must not leave half a group behind
+    for (int i = 0; i < nrows; ++i) {
+        const int64_t owner = rows[4 * i], so = rows[4 * i + 1], dof = rows[4 * i + 2], len = rows[4 * i + 3];
+        XSQ_REQUIRE(owner >= 0 && owner < c->world && len >= 0, "xsq_exchange_rows: row %d: owner %lld of %d ranks, length %lld", i,
+                    (long long)owner, c->world, (long long)len);
+        XSQ_REQUIRE(so >= 0 && so <= src_len - len, "xsq_exchange_rows: row %d: source span [%lld, +%lld) leaves the buffer of %lld floats",
+                    i, (long long)so, (long long)len, (long long)src_len);
+        XSQ_REQUIRE(dof >= 0 && dof <= dst_len - len, "xsq_exchange_rows: row %d: destination span [%lld, +%lld) leaves the buffer of %lld floats",
+                    i, (long long)dof, (long long)len, (long long)dst_len);
     }
-    const int e = g_rccl.GroupEnd();
-    if (rc != XSQ_OK || e != 0) {
-        set_error("xsq_exchange_rows: ncclSend / ncclRecv / ncclGroupEnd failed: %s", e ? g_rccl.GetErrorString(e) : "enqueue error");
-        return XSQ_ERR_HIP;
+    const int per_group = rows_per_group(c->world);
+    for (int g0 = 0; g0 < nrows; g0 += per_group) {
+        const int g1 = std::min(nrows, g0 + per_group);
+        XSQ_NCCL(g_rccl.GroupStart());
+        int rc = XSQ_OK;
+        for (int i = g0; i < g1 && rc == XSQ_OK; ++i) {
+            const int owner = (int)rows[4 * i];
+            const int64_t so = rows[4 * i + 1], dof = rows[4 * i + 2], len = rows[4 * i + 3];
+            if (len == 0) continue;
+            if (owner == c->rank) {
+                for (int peer = 0; peer < c->world && rc == XSQ_OK; ++peer) {
+                    if (peer == c->rank && !self_loop) continue;
+                    if (g_rccl.Send(src + so, (size_t)len, NCCL_FLOAT32, peer, c->comm, stream) != 0) rc = XSQ_ERR_HIP;
+                }
+                if (self_loop && rc == XSQ_OK && g_rccl.Recv(dst + dof, (size_t)len, NCCL_FLOAT32, c->rank, c->comm, stream) != 0) rc = XSQ_ERR_HIP;
+            } else if (g_rccl.Recv(dst + dof, (size_t)len, NCCL_FLOAT32, owner, c->comm, stream) != 0) {
+                rc = XSQ_ERR_HIP;
+            }
+        }
+        const int e = g_rccl.GroupEnd();
+        if (rc != XSQ_OK || e != 0) {
+            set_error("xsq_exchange_rows: ncclSend / ncclRecv / ncclGroupEnd failed in the group of rows [%d, %d): %s", g0, g1,
+                      e ? g_rccl.GetErrorString(e) : "enqueue error");
+            return XSQ_ERR_HIP;
+        }
     }
     return XSQ_OK;
 }

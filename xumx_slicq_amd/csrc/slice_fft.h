@@ -302,7 +302,8 @@ template <int NT, bool PK = false>
 __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __restrict__ x, const float* __restrict__ tw,
                                                               const FftTables T, float2* __restrict__ U,
                                                               int S, int64_t n, int h,
-                                                              const int64_t* __restrict__ xrows = nullptr) {
+                                                              const int64_t* __restrict__ xrows = nullptr,
+                                                              const float* const* __restrict__ xslot = nullptr) {
 #pragma clang fp contract(off)          // fused multiply-adds only where written (fmaf): same bits from every instantiation
     __shared__ float2 Z[FFT_N];
     __shared__ float2 w2s[FFT_R2 * FFT_R3];
@@ -310,8 +311,11 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_rfft(const float* __rest
     const int row = blockIdx.x;
     const int bc = row / S, s = row - bc * S;
     // packed channel bc starts at x + xrows[bc] (a row of the caller's (nb, 2, N) track: the stacked chunks are read in
-    // place, no packing copy) or, without a table, at x + bc * n
-    const float* xr = x + (xrows ? xrows[bc] : (int64_t)bc * n);
+    // place, no packing copy) or, without a table, at x + bc * n.  xslot: the base pointer is read from DEVICE memory
+    // instead (one uniform 8-byte load) -- a captured HIP graph then follows the caller's tensor from replay to replay
+    // without a copy into a static input buffer (Separator.forward_graphed).
+    const float* xb = xslot ? *xslot : x;
+    const float* xr = xb + (xrows ? xrows[bc] : (int64_t)bc * n);
     const int64_t i0 = (int64_t)(2 * s - 2) * h;
     const int part = tid >> 8, m = tid & 255;            // wave-uniform part
     const float2* tw2 = reinterpret_cast<const float2*>(tw);

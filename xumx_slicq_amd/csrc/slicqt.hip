@@ -42,14 +42,15 @@ void set_error(const char* fmt, ...) {
 __global__ __launch_bounds__(256) void k_slice_window(const float* __restrict__ x,
                                                        const float* __restrict__ tw,
                                                        float* __restrict__ seg, int S, int64_t n, int L,
-                                                       int h, const int64_t* __restrict__ xrows = nullptr) {
+                                                       int h, const int64_t* __restrict__ xrows = nullptr,
+                                                       const float* const* __restrict__ xslot = nullptr) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= L) return;
     const int row = blockIdx.y;  // bc*S + s
     const int bc = row / S, s = row - bc * S;
     const int64_t i = (int64_t)(2 * s - 2) * h + p;
     float v = 0.f;
-    if (i >= 0 && i < n) v = tw[p] * x[(xrows ? xrows[bc] : (int64_t)bc * n) + i];
+    if (i >= 0 && i < n) v = tw[p] * (xslot ? *xslot : x)[(xrows ? xrows[bc] : (int64_t)bc * n) + i];
     seg[(int64_t)row * L + p] = v;
 }
 
@@ -866,7 +867,14 @@ int xsq_slicqt_forward_xin(xsq_plan* P, const float* x, int BC, int64_t n, float
 int xsq_slicqt_forward_rows(xsq_plan* P, const float* x, const int64_t* x_rows, int BC, int64_t n, int64_t n_pad, float* coef,
                             float* xin, const float* mean, const float* scale, int split, void* ws, size_t ws_bytes,
                             void* stream_) {
-    XSQ_REQUIRE(P && x && coef && ws, "xsq_slicqt_forward: null argument");
+    XSQ_REQUIRE(x, "xsq_slicqt_forward: null argument");
+    return xsq_slicqt_forward_rows_indirect(P, x, nullptr, x_rows, BC, n, n_pad, coef, xin, mean, scale, split, ws, ws_bytes, stream_);
+}
+
+int xsq_slicqt_forward_rows_indirect(xsq_plan* P, const float* x, const float* const* x_slot, const int64_t* x_rows, int BC, int64_t n,
+                                     int64_t n_pad, float* coef, float* xin, const float* mean, const float* scale, int split,
+                                     void* ws, size_t ws_bytes, void* stream_) {
+    XSQ_REQUIRE(P && (x || x_slot) && coef && ws, "xsq_slicqt_forward: null argument");
     XSQ_REQUIRE(!xin || (mean && scale), "xsq_slicqt_forward_xin: xin needs the mean / scale tables");
     XSQ_REQUIRE(BC > 0 && n > 0 && n_pad >= n, "xsq_slicqt_forward: BC=%d n=%lld n_pad=%lld", BC, (long long)n, (long long)n_pad);
     hipStream_t stream = (hipStream_t)stream_;
@@ -893,15 +901,15 @@ int xsq_slicqt_forward_rows(xsq_plan* P, const float* x, const int64_t* x_rows, 
     if (lds_fft(P)) {
         XSQ_PROF("slice_rfft", stream);
 #if XSQ_PACKED_FFT_KERNELS
-        if (fft_threads(0) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_rfft<512, true>), dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
+        if (fft_threads(0) == 512 && P->packed_fft) hipLaunchKernelGGL((k_slice_rfft<512, true>), dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows, x_slot);
         else
 #endif
-        if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
-        else hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows);
+        if (fft_threads(0) == 512) hipLaunchKernelGGL(k_slice_rfft<512>, dim3(rows), dim3(512), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows, x_slot);
+        else hipLaunchKernelGGL(k_slice_rfft<256>, dim3(rows), dim3(256), 0, stream, x, P->d_tw, fft_tables(P), (float2*)U, S, n, P->h, x_rows, x_slot);
     } else {
         { XSQ_PROF("slice_window", stream);
         hipLaunchKernelGGL(k_slice_window, dim3((P->L + 255) / 256, rows), dim3(256), 0, stream, x, P->d_tw, seg,
-                           S, n, P->L, P->h, x_rows); }
+                           S, n, P->L, P->h, x_rows, x_slot); }
         { XSQ_PROF("rfft_L", stream); rc = run_fft(f, seg, U, fwork, stream); }
         if (rc) return rc;
     }

@@ -101,26 +101,41 @@ class Separator(nn.Module):
         for k in [k for k in cache if k[1] == key[1] and k[8:] != ver]:
             del cache[k]                              # stale: would replay against freed device memory
         entry = cache.get(key)
+        wiener = self._native_mode(audio_big)
+        if wiener is not None and (audio_big.dtype != torch.float32 or not audio_big.is_contiguous()):
+            audio_big = audio_big.contiguous().float()
         if entry is None:
-            static_in = audio_big.clone()
+            # native path: the captured kernels read the input through a DEVICE pointer slot (xsq_separator_forward_indirect),
+            # so a replay follows the caller's tensor -- no copy of the input into a static buffer (85 MB for a 240 s track).
+            # Module-API schedule (an A/B switch off its default): the captured launches hold the input's address, so the
+            # input is copied into a static tensor as before.
+            slot = torch.zeros(1, dtype=torch.int64, device=audio_big.device) if wiener is not None else None
+            static_in = None if slot is not None else audio_big.clone()
+            if slot is not None:
+                slot.fill_(audio_big.data_ptr())
+            call = (lambda: self._forward_native(audio_big, wiener, slot=slot)) if slot is not None else (lambda: self.forward(static_in))
             side = torch.cuda.Stream(device=audio_big.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # warm-up on a side stream: fills the shape-keyed caches
                 for _ in range(2):
-                    self.forward(static_in)
+                    call()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self.forward(static_in)
+                static_out = call()
             # the captured kernels hold raw pointers into the grow-only workspaces: keep those tensors
             # alive with the graph even if a later, larger call replaces them in their owners
             from . import phase
             keep = (list(self.insgt.nsgt.nsgt._ws.values()) + list(self.nsgt.nsgt.nsgt._ws.values())
                     + list(self.xumx_model._ws.values()) + list(phase._WS.values())
                     + list(self.__dict__.get("_nws", {}).values()))
-            entry = cache[key] = (graph, static_in, static_out, keep)
-        graph, static_in, static_out, _keep = entry
-        static_in.copy_(audio_big)
+            entry = cache[key] = [graph, static_in, static_out, keep, slot, audio_big.data_ptr()]
+        graph, static_in, static_out, _keep, slot, last_ptr = entry
+        if slot is None:
+            static_in.copy_(audio_big)
+        elif audio_big.data_ptr() != last_ptr:
+            slot.fill_(audio_big.data_ptr())       # 8 bytes, one small launch on the replay's stream, in front of the replay
+            entry[5] = audio_big.data_ptr()
         graph.replay()
         return static_out
 
@@ -185,7 +200,8 @@ class Separator(nn.Module):
             if (t.dim() != 3 or t.shape != t0.shape or t.dtype != torch.float32 or t.device != t0.device or t.stride(-1) != 1
                     or (t.data_ptr() - t0.data_ptr()) % 4):
                 return None
-        key = tuple((t.data_ptr(), t.stride(0), t.stride(1)) for t in items)
+        # the table has 2 * nb rows per item: nb (and the device) belong to the key, not only the addresses and strides
+        key = (t0.device.index, int(t0.shape[0])) + tuple((t.data_ptr(), t.stride(0), t.stride(1)) for t in items)
         cache = self.__dict__.setdefault("_xrows", {})
         hit = cache.get(key)
         if hit is None:
@@ -193,6 +209,9 @@ class Separator(nn.Module):
             rows = [(t.data_ptr() - base) // 4 + b * t.stride(0) + c * t.stride(1)
                     for t in items for b in range(t.shape[0]) for c in range(2)]
             if len(cache) > 4096:
+                # kernels in flight on either stream may still read an evicted table (the allocator orders reuse on the
+                # allocating stream only): wait for the device before the tables go.  Once per 4096 new item lists.
+                torch.cuda.synchronize(t0.device)
                 cache.clear()
             hit = cache[key] = torch.tensor(rows, dtype=torch.int64, device=t0.device)
         return hit
@@ -290,7 +309,7 @@ class Separator(nn.Module):
             pool.append(torch.cuda.Stream(device=dev))
         return pool[0]
 
-    def _forward_native(self, audio_big: Tensor, wiener: int) -> Tensor:
+    def _forward_native(self, audio_big: Tensor, wiener: int, slot: Optional[Tensor] = None) -> Tensor:
         """``forward`` as ONE C call (xsq_separator_forward, csrc/demix.hip): the stacked full chunks on the caller's
         stream, the tail chunk beside them on a side stream, the input read and the stems written in place through
         row-offset tables cached per call shape.  Per call the host allocates the result and makes one ctypes call."""
@@ -312,9 +331,11 @@ class Separator(nn.Module):
             cs = int(min(self.chunk_size, 1 << 62))
             max_stack = int(getattr(self, "max_stack", 8))
             key = (nb, N, cs, max_stack, wiener, self.xumx_model._version(), dev.index, int(getattr(self, "max_item_slices", 0)))
+            # the cap is sticky state of the native demixer and part of its plan key: set it on EVERY call, not only on a
+            # cache miss here -- after 0 -> 20 -> 0 a cached shape would otherwise run under the stale cap
+            _lib.check(_lib.lib.xsq_demixer_set_max_rows(d, int(getattr(self, "max_item_slices", 0))), "xsq_demixer_set_max_rows")
             sizes = self.__dict__.setdefault("_nsizes", {}).get(key)
             if sizes is None:
-                _lib.check(_lib.lib.xsq_demixer_set_max_rows(d, int(getattr(self, "max_item_slices", 0))), "xsq_demixer_set_max_rows")
                 mb, tb = C.c_size_t(), C.c_size_t()
                 _lib.check(_lib.lib.xsq_separator_workspace(d, model, nb, N, cs, max_stack, wiener, C.byref(mb), C.byref(tb)),
                            "xsq_separator_workspace")
@@ -323,10 +344,11 @@ class Separator(nn.Module):
             ws = self._native_ws(dev, main.cuda_stream, "main", sizes[0] if two else max(sizes))
             wt = self._native_ws(dev, main.cuda_stream, "tail", sizes[1]) if two else None
             out = torch.empty(4, nb, 2, N, dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib.xsq_separator_forward(
-                d, model, audio_big.data_ptr(), nb, N, cs, max_stack, wiener, 1 if two else 0, out.data_ptr(),
-                ws.data_ptr(), ws.numel(), wt.data_ptr() if two else None, wt.numel() if two else 0,
-                main.cuda_stream, side.cuda_stream if two else main.cuda_stream), "xsq_separator_forward")
+            fn, src = ((_lib.lib.xsq_separator_forward, audio_big.data_ptr()) if slot is None
+                       else (_lib.lib.xsq_separator_forward_indirect, slot.data_ptr()))
+            _lib.check(fn(d, model, src, nb, N, cs, max_stack, wiener, 1 if two else 0, out.data_ptr(),
+                          ws.data_ptr(), ws.numel(), wt.data_ptr() if two else None, wt.numel() if two else 0,
+                          main.cuda_stream, side.cuda_stream if two else main.cuda_stream), "xsq_separator_forward")
         return out
 
     @torch.no_grad()

@@ -181,13 +181,59 @@ def all_gather_stems(recv: Tensor, send: Tensor, group=None, async_op: bool = Tr
     return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
 
 
+class ExchangeUnavailable(RuntimeError):
+    """The in-place send / recv exchange cannot be used -- raised on EVERY rank of the group together (the decision is an
+    all-reduce of the ranks' local outcomes), so that callers may fall back to the all-gather form without the ranks
+    ending up in different modes."""
+
+
+def _flag_device(group, dev: torch.device):
+    return dev if (dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
+
+
+def all_ranks_ok(ok: bool, group=None, dev: Optional[torch.device] = None, world: Optional[int] = None) -> bool:
+    """MIN over the ranks of a local success flag (True everywhere or False everywhere).  One small all-reduce over the
+    torch process group; no-op without a group or on a group of one."""
+    if not dist.is_initialized() or (world if world is not None else dist.get_world_size(group)) <= 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_flag_device(group, dev or torch.device("cpu")))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+_ROW_EXCHANGES: Dict[tuple, "RowExchange"] = {}
+
+
+def shared_row_exchange(device: torch.device, group=None, world: Optional[int] = None, rank: Optional[int] = None) -> "RowExchange":
+    """ONE RowExchange (= one RCCL communicator) per (device, process group): every ShardedDemixer of a process shares it
+    (bench.py builds several over the same ranks).  Collective on first use; ``close_row_exchanges()`` destroys them --
+    call it before ``dist.destroy_process_group()``."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index, id(group) if group is not None else None, world, rank)
+    rx = _ROW_EXCHANGES.get(key)
+    if rx is None or rx.closed:
+        rx = _ROW_EXCHANGES[key] = RowExchange(dev, group, world, rank)
+    return rx
+
+
+def close_row_exchanges():
+    for rx in list(_ROW_EXCHANGES.values()):
+        rx.close()
+    _ROW_EXCHANGES.clear()
+
+
 class RowExchange:
     """In-place exchange of stem rows between the ranks: every rank holds the same flat layout, the owner of a row sends it
-    to every peer at the same offset (``xsq_exchange_rows``: one grouped ncclSend / ncclRecv per call on the current
+    to every peer at the same offset (``xsq_exchange_rows``: grouped ncclSend / ncclRecv on the current
     stream -- RCCL over xGMI, one point-to-point link per peer, no packing buffer, no placement pass).  The communicator is
     the library's own (``xsq_comm_create``: ncclCommInitRank with an id handed round through ``torch.distributed``), on
     the RCCL build torch already loaded.  With the ``gloo`` backend -- CPU tests, two ranks sharing the one GPU of a test
-    box -- the same rows travel as host-staged broadcasts (functional path only)."""
+    box -- the same rows travel as host-staged broadcasts (functional path only).
+
+    Construction is COLLECTIVE and ends the same way on every rank: each rank catches its local error (librccl not found,
+    a missing symbol, ncclCommInitRank failing), rank 0 broadcasts the unique id -- or a failure marker -- unconditionally,
+    and an all-reduce (MIN) of the ranks' flags after the id and again after ncclCommInitRank decides; on any failure
+    anywhere every rank raises ``ExchangeUnavailable`` (and frees what it had created)."""
 
     def __init__(self, device: torch.device, group=None, world: Optional[int] = None, rank: Optional[int] = None):
         self.dev, self.group = torch.device(device), group
@@ -195,24 +241,55 @@ class RowExchange:
         self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
         self.backend = dist.get_backend(group) if live else "none"
-        self.comm = None
-        if self.dev.type == "cuda" and self.backend != "gloo":
-            import ctypes as C
-            import os
-            from . import _lib
-            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            _lib.check(_lib.lib.xsq_comm_load(path.encode() if os.path.exists(path) else None), "xsq_comm_load")
-            uid = C.create_string_buffer(128)
-            if self.rank == 0:
-                _lib.check(_lib.lib.xsq_comm_unique_id(uid), "xsq_comm_unique_id")
-            if self.world > 1:
-                box = [uid.raw]
-                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.comm, self.closed = None, False
+        import ctypes as C
+        import os
+        use_rccl = self.dev.type == "cuda" and self.backend != "gloo"
+        several = live and self.world > 1
+        if not use_rccl and not several:
+            return
+        # tests only: XSQ_FAULT_INJECT="load:<rank>" / "init:<rank>" makes that rank fail the local step, so that the
+        # collective decision can be exercised without breaking RCCL (tests/test_sharding_cpu.py)
+        fault = os.environ.get("XSQ_FAULT_INJECT", "")
+        uid, err = C.create_string_buffer(128), None
+        try:                                                   # local step 1: resolve RCCL; rank 0 makes the id
+            if fault == f"load:{self.rank}":
+                raise RuntimeError("injected fault (XSQ_FAULT_INJECT=%s)" % fault)
+            if use_rccl:
+                from . import _lib
+                path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                _lib.check(_lib.lib.xsq_comm_load(path.encode() if os.path.exists(path) else None), "xsq_comm_load")
+                if self.rank == 0:
+                    _lib.check(_lib.lib.xsq_comm_unique_id(uid), "xsq_comm_unique_id")
+        except Exception as e:                                 # noqa: BLE001 -- reported through the collective decision
+            err = e
+        if several:
+            box = [uid.raw if err is None else None]           # the id or a failure marker: ALWAYS broadcast, nobody waits in vain
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if box[0] is None and err is None:
+                err = RuntimeError("rank 0 could not create the RCCL unique id")
+            elif box[0] is not None:
                 uid = C.create_string_buffer(box[0], 128)
-            out = C.c_void_p()
-            with torch.cuda.device(self.dev):
-                _lib.check(_lib.lib.xsq_comm_create(C.byref(out), uid, self.world, self.rank), "xsq_comm_create")
-            self.comm = out
+        if not all_ranks_ok(err is None, group, self.dev, self.world):
+            self.closed = True
+            raise ExchangeUnavailable(f"RCCL not usable on every rank (this rank: {err!r})")
+        out = C.c_void_p()
+        try:                                                   # local step 2: ncclCommInitRank (itself collective: every rank calls it)
+            if fault == f"init:{self.rank}":
+                raise RuntimeError("injected fault (XSQ_FAULT_INJECT=%s)" % fault)
+            if use_rccl:
+                from . import _lib
+                with torch.cuda.device(self.dev):
+                    _lib.check(_lib.lib.xsq_comm_create(C.byref(out), uid, self.world, self.rank), "xsq_comm_create")
+        except Exception as e:                                 # noqa: BLE001
+            err = e
+        if not all_ranks_ok(err is None, group, self.dev, self.world):
+            if out.value:
+                from . import _lib
+                _lib.lib.xsq_comm_destroy(out)
+            self.closed = True
+            raise ExchangeUnavailable(f"ncclCommInitRank did not succeed on every rank (this rank: {err!r})")
+        self.comm = out if use_rccl else None
 
     def version(self):
         from . import _lib
@@ -224,8 +301,9 @@ class RowExchange:
         dst = flat if dst is None else dst
         if self.comm is not None:
             from . import _lib
-            _lib.check(_lib.lib.xsq_exchange_rows(self.comm, flat.data_ptr(), dst.data_ptr(), table.ctypes.data, int(table.shape[0]),
-                                                  1 if self_loop else 0, _lib.stream_ptr()), "xsq_exchange_rows")
+            _lib.check(_lib.lib.xsq_exchange_rows(self.comm, flat.data_ptr(), flat.numel(), dst.data_ptr(), dst.numel(),
+                                                  table.ctypes.data, int(table.shape[0]), 1 if self_loop else 0,
+                                                  _lib.stream_ptr()), "xsq_exchange_rows")
             return
         if self.world == 1 and not self_loop:
             return
@@ -241,6 +319,7 @@ class RowExchange:
                 dst[do:do + n].copy_(buf)
 
     def close(self):
+        self.closed = True
         if self.comm is not None:
             from . import _lib
             _lib.lib.xsq_comm_destroy(self.comm)
@@ -345,12 +424,13 @@ class ShardedDemixer:
 
     def __init__(self, separator, track_lengths: Sequence[int], get_chunk: Callable[[WorkItem], Tensor],
                  device: torch.device, group: Optional[dist.ProcessGroup] = None, gather: bool = True,
-                 nb_samples: int = 1, stack: int = 4, solo: bool = False, exchange: str = "sendrecv"):
+                 nb_samples: int = 1, stack: int = 4, solo: bool = False, exchange: str = "sendrecv", fallback: bool = False):
         if exchange not in ("sendrecv", "allgather"):
             raise ValueError(f"exchange must be 'sendrecv' or 'allgather'; got {exchange!r}")
         self.sep, self.get_chunk, self.dev, self.group, self.gather = separator, get_chunk, torch.device(device), group, gather
-        self.exchange = exchange
+        self.exchange, self.fallback, self.exchange_note = exchange, bool(fallback), None
         live = dist.is_initialized() and not solo
+        self._live = live
         self.world = dist.get_world_size(group) if live else 1
         self.rank = dist.get_rank(group) if live else 0
         self.plan = ShardPlan(track_lengths, separator.chunk_size, self.world, nb_samples, stack)
@@ -359,20 +439,38 @@ class ShardedDemixer:
         self.gather = bool(self.gather)
         nb, dt = self.plan.nb, torch.float32
         lens = self.plan.lengths
-        # one flat allocation for all tracks: the kernels address it through element offsets
+        # one flat allocation for all tracks: the kernels address it through element offsets (int64: the 50-track set is
+        # 4.8 G floats, past 2^32 elements)
         self.track_off = [0]
         for n in lens:
             self.track_off.append(self.track_off[-1] + 8 * nb * n)
         self.flat = torch.zeros(self.track_off[-1], dtype=dt, device=self.dev)
         self.out = {t: self.flat[self.track_off[t]:self.track_off[t + 1]].view(4, nb, 2, lens[t]) for t in range(len(lens))}
+        self._place_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self._tail_stream = None
+        self._setup_exchange()
+
+    def _setup_exchange(self):
+        """Buffers and tables of the chosen exchange.  sendrecv needs the library's RCCL communicator: its construction is
+        a collective decision (``RowExchange``) -- with ``fallback`` every rank switches to the all-gather form together
+        and ``exchange_note`` says why; without it every rank raises ``ExchangeUnavailable``."""
+        dt = torch.float32
         self.recv: Dict[tuple, Tensor] = {}       # (round, part) -> (world * width) floats, rank-major
         self.send: Dict[tuple, Tensor] = {}       # this rank's slice of it: what the kernels write (in-place all-gather)
         self._place: Dict[tuple, tuple] = {}      # (round, part) -> (row table on the device, rows, longest row)
         self._xtable: Dict[tuple, object] = {}    # (round, part) -> host table (owner, src offset, dst offset, length) of the in-place exchange
+        self._offs = {}                           # (round, pass) -> row-offset tensor
         self._rowx = None
         if self.gather and self.exchange == "sendrecv":
+            try:
+                self._rowx = shared_row_exchange(self.dev, self.group if self._live else None, self.world, self.rank)
+            except ExchangeUnavailable as e:
+                if not self.fallback:
+                    raise
+                self.exchange_note = "sendrecv-inplace unavailable (%s); every rank fell back to allgather+place" % str(e)[:300]
+                self.exchange = "allgather"
+        if self.gather and self.exchange == "sendrecv":
             # every rank keeps the same flat layout; kernels write their rows in place, rows travel owner -> peers
-            self._rowx = RowExchange(self.dev, group if live else None, self.world, self.rank)
             for key in self.plan.exchanges():
                 self._xtable[key] = self._exchange_table(*key)
         elif self.gather:
@@ -381,9 +479,30 @@ class ShardedDemixer:
                 self.recv[key] = torch.zeros(self.world * w, dtype=dt, device=self.dev)
                 self.send[key] = self.recv[key][self.rank * w:(self.rank + 1) * w]
                 self._place[key] = self._place_table(*key)
-        self._offs = {}       # (round, pass) -> row-offset tensor
-        self._place_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
-        self._tail_stream = None
+
+    def settle(self) -> Optional[str]:
+        """One warm-up step whose OUTCOME the ranks agree on: a rank whose first in-place exchange raised (a refused table,
+        an RCCL enqueue error) reports it through an all-reduce (MIN) instead of leaving its peers in another mode.  With
+        ``fallback`` every rank then rebuilds the all-gather form together; without it every rank raises.  Returns
+        ``exchange_note`` (None = the chosen exchange ran).  (What this cannot catch: a rank that dies INSIDE a grouped
+        exchange its peers have already queued -- their kernels wait on the device, not on the host.)"""
+        if not (self.gather and self.exchange == "sendrecv"):
+            return self.exchange_note
+        err = None
+        try:
+            self.run()
+            if self.dev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
+        except Exception as e:                                 # noqa: BLE001 -- reported through the collective decision
+            err = e
+        if all_ranks_ok(err is None, self.group if self._live else None, self.dev, self.world):
+            return self.exchange_note
+        if not self.fallback:
+            raise ExchangeUnavailable(f"the first in-place exchange failed on at least one rank (this rank: {err!r})")
+        self.exchange_note = "first sendrecv-inplace exchange failed on at least one rank (this rank: %r); every rank fell back to allgather+place" % (err,)
+        self.exchange = "allgather"
+        self._setup_exchange()
+        return self.exchange_note
 
     # element offsets of packed channel (target, item*nb + b, c) for one pass
     def _row_offsets(self, k: int, pi: int, placed: Sequence[PlacedItem]) -> Tensor:
