@@ -621,6 +621,15 @@ def test_full_size_track_matches_the_oracle(seps, oracle_plan, seeded_sd, name, 
         assert rms < RMS_TOL and mx < MAX_TOL, (name, precision, c0, rms, mx)
         worst_rms, worst_max = max(worst_rms, rms), max(worst_max, mx)
     print(f"full-size {name} {precision}: rms {worst_rms:.2e} max {worst_max:.2e}")
+    # the same output against the REFERENCE itself where a committed fixture reaches: chunk 0 and the tail chunk
+    # (tests/golden/stems_fullchunk.npz, oracle/make_golden_fullchunk.py: stride 97)
+    g = load_golden("stems_fullchunk.npz")
+    cs, stride = int(g["chunk_size"]), int(g["stride"])
+    got = torch.cat([est[..., :cs], est[..., 4 * cs:]], dim=-1)[..., ::stride]
+    d = (got - torch.from_numpy(g[name])).double()
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    print(f"full-chunk reference fixture {name} {precision}: rms {rms:.2e} max {mx:.2e}")
+    assert rms < RMS_TOL and mx < MAX_TOL and rms < 1e-6, (name, precision, rms, mx)
 
 
 @pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener", "realtime"])

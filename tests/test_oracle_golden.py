@@ -130,3 +130,27 @@ def test_real_audio_stems_match_reference(oracle_plan, seeded_sd, name, causal, 
         rms = float(d.pow(2).mean().sqrt())
         assert rms < 1e-5 and float(d.abs().max()) < 1e-4, (cs, rms, float(d.abs().max()))
         assert float(ref.pow(2).mean().sqrt()) > 1e-3
+
+
+@pytest.mark.parametrize("name,wiener", [("offline_wiener", True), ("offline_phasemix", False)])
+def test_full_chunk_stems_match_reference(oracle_plan, seeded_sd, name, wiener):
+    """One FULL chunk (2,621,440 samples: S = 292, block 69 = 85,264 frames = 18 Wiener windows, phase.py:43-59, each with
+    its own window maximum, norbert/__init__.py:257) + the 98,240-sample tail chunk through the REFERENCE Separator
+    (oracle/make_golden_fullchunk.py -> stems_fullchunk.npz, stride 97 + checksums): the oracle at the size the GPU path is
+    benchmarked at.  Input = chunk 0 and the tail of bench.py's 240 s track."""
+    g = load_golden("stems_fullchunk.npz")
+    cs, n, stride = int(g["chunk_size"]), int(g["n"]), int(g["stride"])
+    track = synth_audio(10_584_000, seed=int(g["seed"]))
+    x = torch.cat([track[..., :cs], track[..., 4 * cs:]], dim=-1).contiguous()
+    assert x.shape[-1] == n == cs + 98_240
+    a = x.double().flatten()
+    assert np.allclose([float(a.sum()), float((a * a).sum()), float(a.abs().max())], g["input_sums"], rtol=1e-12)
+    est = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=wiener, chunk_size=cs)
+    ref = torch.from_numpy(g[name])
+    d = (est[..., ::stride] - ref).double()
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    print(f"full chunk {name}: oracle vs reference rms {rms:.2e} max {mx:.2e}")
+    assert rms < 1e-6 and mx < 1e-5, (rms, mx)          # measured 5e-8 / 5e-7
+    sums = np.stack([[float(e.double().sum()), float((e.double() ** 2).sum()), float(e.abs().max())] for e in est])
+    assert np.allclose(sums[:, 1], g[f"{name}_sums"][:, 1], rtol=1e-5) and np.allclose(sums[:, 2], g[f"{name}_sums"][:, 2], rtol=1e-4)
+    assert float(ref.pow(2).mean().sqrt()) > 1e-2
