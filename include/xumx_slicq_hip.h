@@ -182,6 +182,12 @@ int xsq_model_set_precision(xsq_model* model, int mode);
  * loaded and staged once for several targets' MFMAs (csrc/cdae_l1q.h); 0 (default) = one tile per (block, target) on the
  * generic engine.  Same bits; measured SLOWER than the default (0.58-0.66 against 0.545 ms: fewer resident waves).    */
 int xsq_model_set_l1_quad(xsq_model* model, int on);
+/* fp32 inference, layers 2 / 3 (the 4-tap time convolutions of model.py:140-170), rows of >= 127 time positions: 1 (default) =
+ * Winograd F(2, 4) along the time taps (csrc/cdae_wino.h: five MFMA products per output pair and channel pair instead of
+ * eight; input transform with integer coefficients in registers, weights transformed on the host in fp64; ~2e-7 RMS of a
+ * layer's output against fp64 where the direct fp32 sum has ~7e-8), 0 = the direct slab kernels (csrc/cdae_slab.h).  The
+ * split-bf16 modes and shorter rows always take the direct kernels.                                                   */
+int xsq_model_set_winograd(xsq_model* model, int on);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)
  *   Y      out: mask * X, arena for 8*B channels laid out (4 targets, B, 2, ...); NULL (with masks

@@ -803,3 +803,38 @@ def test_evaluation_harness_scores_with_the_real_separator(seps, oracle_plan, se
         for t, name in enumerate(sep.sources):
             s_ref = global_sdr(stems[name].T.numpy(), ref[t, 0].numpy().T)
             assert np.isfinite(res["scores"][name]) and abs(res["scores"][name] - s_ref) < 1e-3, (name, res["scores"][name], s_ref)
+
+
+@pytest.mark.parametrize("name,wiener", [("offline_phasemix", False), ("offline_wiener", True)])
+def test_winograd_layers_match_the_direct_kernels_and_the_oracle(seps, oracle_plan, seeded_sd, name, wiener):
+    """Layers 2 / 3 as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h, the fp32 default for rows of >= 127
+    positions) against the direct slab kernels (xsq_model_set_winograd(0)) and against the CPU oracle (model.py:140-170).
+    n = 650,000 samples: S = 74 slices, T1 = 147 (odd: a phantom second output in the last pair of every row), T2 = 144,
+    72 / 74 pairs per row -- every 64-pair tile straddles two (b, f) rows --, two samples per batch, blocks with 1, 3 and 5
+    frequency taps (the slab is re-staged per tap).  Bars: 5e-7 RMS between the two kernels (Winograd's own rounding,
+    measured 1e-7), the stated 1e-4 / 1e-3 and a tighter 1e-6 RMS against the oracle."""
+    from oracle import separator as osep
+    n = 650_000
+    sep = seps[name]
+    x = synth_audio(n, seed=77, nb_samples=2)
+    m = sep.xumx_model
+    try:
+        m.set_winograd(False)
+        direct = sep(x.cuda()).cpu()
+        m.set_winograd(True)
+        wino = sep(x.cuda()).cpu()
+        again = sep(x.cuda()).cpu()
+    finally:
+        m.set_winograd(True)
+    assert torch.equal(wino, again)                                  # deterministic
+    assert not torch.equal(wino, direct)                             # ... and really another kernel
+    d = (wino - direct).double()
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    print(f"winograd vs direct {name}: rms {rms:.2e} max {mx:.2e}")
+    assert rms < 5e-7 and mx < 2e-5, (rms, mx)
+    ref = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=wiener)
+    for tag, est in (("winograd", wino), ("direct", direct)):
+        e = (est - ref).double()
+        rms, mx = float(e.pow(2).mean().sqrt()), float(e.abs().max())
+        print(f"{tag} vs oracle {name}: rms {rms:.2e} max {mx:.2e}")
+        assert rms < RMS_TOL and mx < MAX_TOL and rms < 1e-6, (tag, rms, mx)

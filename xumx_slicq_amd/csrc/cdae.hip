@@ -577,6 +577,7 @@ struct CdaeL4Op {
 
 }  // namespace xsq
 #include "cdae_slab.h"
+#include "cdae_wino.h"
 namespace xsq {
 
 // ------------------------------------------------------------------------------------------
@@ -717,6 +718,44 @@ static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     return XSQ_OK;
 }
 
+// tiles of the Winograd kernels (cdae_wino.h): 64 consecutive output PAIRS of one batch item in the flattened (f, pair) space
+static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(layer + 96, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].kf > Mo->blocks[y].kf; });
+    std::vector<WinoTileDev> t;
+    const int To = layer == 2 ? T2 : T1, P = (To + 1) / 2;
+    for (int b : order) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        for (int tgt = 0; tgt < NT; ++tgt) {
+            const int64_t off1 = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);   // act1 / act3 of the (block, target)
+            const int64_t off2 = (int64_t)CS * Bn * T2 * (4 * (int64_t)d.cumF2 + (int64_t)tgt * d.F2);   // act2
+            WinoTileDev e;
+            e.kf = d.kf; e.P = P;
+            if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.u_off = d.u2[tgt]; }
+            else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.u_off = d.u3[tgt]; }
+            const int perb = e.Fo * P;
+            for (int bi = 0; bi < Bn; ++bi)
+                for (int Q = 0; Q < perb; Q += WN_PAIRS) {
+                    e.Q0 = Q; e.b = bi; e.f0 = Q / P; e.q0 = Q % P;
+                    t.push_back(e);
+                }
+        }
+    }
+    TileTable tt;                    // (d_tiles holds WinoTileDev entries for this key: cast at the launch site)
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc((void**)&tt.d_tiles, t.size() * sizeof(WinoTileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(WinoTileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace xsq
@@ -830,6 +869,24 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                             pool[d.w3[t] + (size_t)co * K2 + (df * 4 + (3 - dt)) * CS + ci] =
                                 (float)((double)w[(((size_t)ci * H1 + co) * kf + df) * 4 + dt] * s);
             }
+            // ---- Winograd F(2, 4) along the time taps (cdae_wino.h): U_j = sum_dt G[j][dt] w[dt] of the FOLDED fp32 weights above
+            //      (what the direct kernels contract with), summed in fp64, as [df][chunk][component][col][k] tiles
+            for (int layer = 2; layer <= 3; ++layer) {
+                const int64_t wsrc = layer == 2 ? d.w2[t] : d.w3[t];
+                const int64_t u = alloc((size_t)kf * WN_UDF);
+                (layer == 2 ? d.u2[t] : d.u3[t]) = u;
+                for (int df = 0; df < kf; ++df)
+                    for (int sc = 0; sc < 4; ++sc)
+                        for (int j = 0; j < 5; ++j)
+                            for (int col = 0; col < CS; ++col)
+                                for (int k = 0; k < (sc < 3 ? 16 : 4); ++k) {
+                                    const int ci = 16 * sc + k;
+                                    double acc = 0.0;
+                                    for (int dt = 0; dt < 4; ++dt)
+                                        acc += WN_G[j][dt] * (double)pool[wsrc + (size_t)col * K2 + (df * 4 + dt) * CS + ci];
+                                    pool[u + (size_t)df * WN_UDF + wino_u_off(sc, j) + (size_t)col * (sc < 3 ? 16 : 4) + k] = (float)acc;
+                                }
+            }
             // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
             //      k = (df*2 + (1 - tap))*52 + c3 (tap 1 first: CdaeL4Op) ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
             w = p; p += (size_t)H1 * 2 * kf * W;
@@ -881,6 +938,12 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
         XSQ_HIP(hipDeviceSynchronize());
     }
     Mo->precision = mode;
+    return XSQ_OK;
+}
+
+int xsq_model_set_winograd(xsq_model* Mo, int on) {
+    XSQ_REQUIRE(Mo, "xsq_model_set_winograd: null model");
+    Mo->winograd = on ? 1 : 0;
     return XSQ_OK;
 }
 
@@ -952,6 +1015,16 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         for (const CdaeBlockDev& d : Mo->blocks)
             XSQ_REQUIRE((int64_t)4 * CS * a.Bn * a.T1 * d.F1 < ((int64_t)1 << 30), "xsq_cdae_forward: B=%d S=%d overflows the 32-bit "
                         "offsets of a block's activations; split the batch", a.Bn, a.S);
+        // fp32: Winograd F(2, 4) along the four time taps (cdae_wino.h) -- 5 instead of 8 MFMA products per output pair;
+        // rows of >= 64 pairs, i.e. To >= 127.  xsq_model_set_winograd(0) / XSQ_CDAE_VARIANT=2048: the direct slab kernels.
+        if (!bf3 && !bf6 && Mo->winograd && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
+            int rcw = get_wino_tiles(Mo, layer, a.Bn, a.S, &tt);
+            if (rcw) return rcw;
+            XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);
+            if (layer == 2) hipLaunchKernelGGL((cdae_wino_kernel<false>), dim3(tt.ntiles), dim3(256), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
+            else hipLaunchKernelGGL((cdae_wino_kernel<true>), dim3(tt.ntiles), dim3(256), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
+            return XSQ_OK;
+        }
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
         if (rc) return rc;
         XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);      // its own event name: one kernel, one name

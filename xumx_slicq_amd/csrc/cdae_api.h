@@ -21,6 +21,7 @@ struct CdaeBlockDev {
     int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
     int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
     int64_t s1[NT], s2[NT], s3[NT], b4[NT];   // float offsets of shift vectors (64) / output bias (2)
+    int64_t u2[NT], u3[NT];                   // Winograd F(2, 4) transformed weights of layers 2 / 3 (cdae_wino.h: kf x WN_UDF floats)
 };
 
 }  // namespace xsq
@@ -28,6 +29,7 @@ struct CdaeBlockDev {
 struct xsq_model {
     int causal = 0;
     int precision = 0;             // 0 fp32 MFMA, 1 split-bf16 MFMA (xsq_model_set_precision)
+    int winograd = 1;              // fp32 layers 2 / 3 as Winograd F(2, 4) along the time taps (cdae_wino.h; xsq_model_set_winograd: 0 = the direct slab kernels)
     int l1_quad = 0;               // A/B switch (xsq_model_set_l1_quad): 4 / 2 = layer 1 of four / two targets of a block in one tile (cdae_l1q.h; measured slower)
     int nblocks = 0;
     int64_t sumFT = 0;             // complex coefficients per channel-slice

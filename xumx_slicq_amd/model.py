@@ -273,6 +273,7 @@ class Unmix(nn.Module):
             # inside the device guard: bf16 modes allocate and launch on the CURRENT device
             _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
             _lib.check(_lib.lib.xsq_model_set_l1_quad(out, int(getattr(self, "l1_quad", 0))), "xsq_model_set_l1_quad")
+            _lib.check(_lib.lib.xsq_model_set_winograd(out, int(getattr(self, "winograd", 1))), "xsq_model_set_winograd")
         self._handles[idx] = (ver, out)
         return out
 
@@ -286,6 +287,13 @@ class Unmix(nn.Module):
         for idx, (_ver, h) in self._handles.items():
             with torch.cuda.device(idx):       # the split-weight pool is allocated / converted on the model's device
                 _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
+
+    def set_winograd(self, on: bool):
+        """fp32 layers 2 / 3 of long rows: True (default) = Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), False =
+        the direct slab kernels (csrc/cdae_slab.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
+        self.winograd = 1 if on else 0
+        for _ver, h in self._handles.values():
+            _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
 
     def set_l1_quad(self, on):
         """A/B switch: 4 (True) / 2 = layer 1 of four / two targets of a block in one tile (csrc/cdae_l1q.h: the targets share
