@@ -32,6 +32,9 @@ def short(n):
     m = re.match(r"void xsq::cdae_slab_kernel<(true|false), (\d)(?:, (?:true|false))?>", n)
     if m:
         return {"0": "slab", "3": "slab", "1": "slab_bf3", "2": "slab_bf6"}[m.group(2)] + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
+    m = re.match(r"void xsq::cdae_wino_kernel<(true|false)>", n)
+    if m:
+        return "wino" + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
     n = re.sub(r"void xsq::grouped_gemm_bf6_kernel<xsq::(\w+)>", r"gemm_bf6<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+)(?:, \d+)*>", r"gemm<\1>", n)
@@ -39,7 +42,7 @@ def short(n):
     return n.split("(")[0][:48]
 
 
-ours = "gemm|slab|band_dft4|k_|fft|bluestein|c2r|r2c"
+ours = "gemm|slab|wino|band_dft4|k_|fft|bluestein|c2r|r2c"
 st = pd.read_csv(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0])
 st["Kernel"] = st["Name"].map(short)
 st = st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"]]

@@ -740,9 +740,13 @@ static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.u_off = d.u2[tgt]; }
             else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.u_off = d.u3[tgt]; }
             const int perb = e.Fo * P;
+            // sub-tiles per workgroup: the shorter a sub-tile's work (one frequency tap), the more of them share one prologue
+            static const int nsub_env = getenv("XSQ_WINO_NSUB") ? atoi(getenv("XSQ_WINO_NSUB")) : 0;
+            const int nsub = !XSQ_WINO_MULTI ? 1 : nsub_env > 0 ? nsub_env : (d.kf == 1 ? 4 : d.kf == 3 ? 2 : 1);
+            e.pad = 0;
             for (int bi = 0; bi < Bn; ++bi)
-                for (int Q = 0; Q < perb; Q += WN_PAIRS) {
-                    e.Q0 = Q; e.b = bi; e.f0 = Q / P; e.q0 = Q % P;
+                for (int Q = 0; Q < perb; Q += WN_PAIRS * nsub) {
+                    e.Q0 = Q; e.b = bi; e.nsub = std::min(nsub, (perb - Q + WN_PAIRS - 1) / WN_PAIRS);
                     t.push_back(e);
                 }
         }
@@ -806,7 +810,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
     *partial = Mo;
     Mo->causal = causal ? 1 : 0; Mo->nblocks = nblocks; Mo->sumFT = PL.sumFT; Mo->table = PL.blocks;
     const double eps = 1e-5;
-    std::vector<float> pool, mean, scale;
+    std::vector<float> pool, upool, mean, scale;
     std::vector<int64_t> cum(P->nblocks + 1, 0);
     std::vector<int> blockF(P->nblocks);
     const float* p = params;
@@ -870,22 +874,21 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                                 (float)((double)w[(((size_t)ci * H1 + co) * kf + df) * 4 + dt] * s);
             }
             // ---- Winograd F(2, 4) along the time taps (cdae_wino.h): U_j = sum_dt G[j][dt] w[dt] of the FOLDED fp32 weights above
-            //      (what the direct kernels contract with), summed in fp64, as [df][chunk][component][col][k] tiles
+            //      (what the direct kernels contract with), summed in fp64, as [df][chunk][component][col < 51][k] tiles
             for (int layer = 2; layer <= 3; ++layer) {
                 const int64_t wsrc = layer == 2 ? d.w2[t] : d.w3[t];
-                const int64_t u = alloc((size_t)kf * WN_UDF);
+                const int64_t u = (int64_t)upool.size();
+                upool.resize(upool.size() + (size_t)kf * WN_UDF, 0.f);
                 (layer == 2 ? d.u2[t] : d.u3[t]) = u;
                 for (int df = 0; df < kf; ++df)
-                    for (int sc = 0; sc < 4; ++sc)
-                        for (int j = 0; j < 5; ++j)
-                            for (int col = 0; col < CS; ++col)
-                                for (int k = 0; k < (sc < 3 ? 16 : 4); ++k) {
-                                    const int ci = 16 * sc + k;
-                                    double acc = 0.0;
-                                    for (int dt = 0; dt < 4; ++dt)
-                                        acc += WN_G[j][dt] * (double)pool[wsrc + (size_t)col * K2 + (df * 4 + dt) * CS + ci];
-                                    pool[u + (size_t)df * WN_UDF + wino_u_off(sc, j) + (size_t)col * (sc < 3 ? 16 : 4) + k] = (float)acc;
-                                }
+                    for (int j = 0; j < 5; ++j)
+                        for (int col = 0; col < WN_COLS; ++col)
+                            for (int ci = 0; ci < CS; ++ci) {
+                                double acc = 0.0;
+                                for (int dt = 0; dt < 4; ++dt)
+                                    acc += WN_G[j][dt] * (double)pool[wsrc + (size_t)col * K2 + (df * 4 + dt) * CS + ci];
+                                upool[u + (size_t)df * WN_UDF + wino_u_off(j, col, ci)] = (float)acc;
+                            }
             }
             // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
             //      k = (df*2 + (1 - tap))*52 + c3 (tap 1 first: CdaeL4Op) ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
@@ -916,6 +919,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
         XSQ_HIP(hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); \
     } while (0)
     UP(Mo->d_pool, pool, float);
+    UP(Mo->d_upool, upool, float);
     Mo->pool_floats = (int64_t)pool.size();
     UP(Mo->d_mean, mean, float);
     UP(Mo->d_scale, scale, float);
@@ -956,7 +960,7 @@ int xsq_model_set_l1_quad(xsq_model* Mo, int on) {
 int xsq_model_destroy(xsq_model* Mo) {
     if (!Mo) return XSQ_OK;
     for (auto& kv : Mo->tiles) (void)hipFree(kv.second.d_tiles);
-    (void)hipFree(Mo->d_pool); (void)hipFree(Mo->d_pool_split); (void)hipFree(Mo->d_mean); (void)hipFree(Mo->d_scale);
+    (void)hipFree(Mo->d_pool); (void)hipFree(Mo->d_upool); (void)hipFree(Mo->d_pool_split); (void)hipFree(Mo->d_mean); (void)hipFree(Mo->d_scale);
     (void)hipFree(Mo->d_blocks); (void)hipFree(Mo->d_cum); (void)hipFree(Mo->d_blockF);
     delete Mo;
     return XSQ_OK;
@@ -1017,7 +1021,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "offsets of a block's activations; split the batch", a.Bn, a.S);
         // fp32: Winograd F(2, 4) along the four time taps (cdae_wino.h) -- 5 instead of 8 MFMA products per output pair;
         // rows of >= 64 pairs, i.e. To >= 127.  xsq_model_set_winograd(0) / XSQ_CDAE_VARIANT=2048: the direct slab kernels.
-        if (!bf3 && !bf6 && Mo->winograd && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
+        if (!bf3 && !bf6 && a.upool && Mo->winograd && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
             int rcw = get_wino_tiles(Mo, layer, a.Bn, a.S, &tt);
             if (rcw) return rcw;
             XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);
@@ -1132,6 +1136,7 @@ int xsq_cdae_forward_xin(xsq_model* Mo, const float* X, int Bn, int S, float* Y,
     CdaeArgs a{Mo->d_blocks, Mo->d_pool, xin, act1, act2, act3, X, Y, masks, Bn, S, T1, T2, Mo->causal, 0, nullptr, nullptr};
     a.split = split;
     a.poolB = split ? Mo->d_pool_split : nullptr;
+    a.upool = Mo->d_upool;
     for (int layer = 1; layer <= 4; ++layer) {
         const int rc = cdae_launch_layer(Mo, layer, a, stream);
         if (rc) return rc;

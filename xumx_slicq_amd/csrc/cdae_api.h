@@ -21,7 +21,7 @@ struct CdaeBlockDev {
     int64_t cumF;         // sum over earlier blocks of F (input_mean / input_scale offset)
     int64_t w1[NT], w2[NT], w3[NT], w4[NT];   // float offsets of the folded weight matrices
     int64_t s1[NT], s2[NT], s3[NT], b4[NT];   // float offsets of shift vectors (64) / output bias (2)
-    int64_t u2[NT], u3[NT];                   // Winograd F(2, 4) transformed weights of layers 2 / 3 (cdae_wino.h: kf x WN_UDF floats)
+    int64_t u2[NT], u3[NT];                   // Winograd F(2, 4) transformed weights of layers 2 / 3 (offsets into xsq_model::d_upool; cdae_wino.h: kf x WN_UDF floats)
 };
 
 }  // namespace xsq
@@ -39,6 +39,8 @@ struct xsq_model {
     xsq::CdaeBlockDev* d_blocks = nullptr;
     float* d_pool = nullptr;       // all folded weights / shifts
     float* d_pool_split = nullptr; // the same pool as (bf16 hi << 16) | bf16 lo words (precision 1)
+    float* d_upool = nullptr;      // Winograd-transformed weights of layers 2 / 3 (cdae_wino.h): their own pool -- the training step
+                                   // regathers d_pool from the canonical parameters every step and never contracts with these
     int64_t pool_floats = 0;
     float* d_mean = nullptr;       // (sumF) input_mean  (stored as -mean by the reference)
     float* d_scale = nullptr;      // (sumF) input_scale (stored as 1/std)
@@ -72,6 +74,7 @@ struct CdaeArgs {
     // same format (shifts / biases are still read from `pool`)
     int split = 0;
     const float* poolB = nullptr;
+    const float* upool = nullptr;  // Winograd-transformed weights of layers 2 / 3 (xsq_model::d_upool; inference only)
 };
 
 
