@@ -210,6 +210,92 @@ def pmc_issue(kernel, tag=None):
             "source": os.path.basename(files[-1])}
 
 
+SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4     # 256 CUs x 4 SIMDs; the clock the fp32 MFMA peak of MI355X_MICROARCH.md is quoted at
+
+
+def issue_bound(plan, B, chunk_lengths, winograd=True):
+    """Per-kernel ISSUE BOUND of the fp32 MFMA kernels for one pass over the given chunks, in ms: on gfx950 an fp32 MFMA and the
+    other vector instructions of a SIMD's waves take turns on one issue port (DESIGN.md "Vector issue": a loop's time is the SUM
+    of its MFMA cycles and ~4 cycles per other vector instruction), so no schedule of the kernel AS COMPILED can beat
+        sum over tiles and waves of (MFMA cycles + 4 x other vector instructions) / (1024 SIMDs x 2.4 GHz).
+    The per-trip and outside-the-loops counts come from the assembly (profiles/isa_budget.json, tools/isa_budget.py); tile and
+    trip counts are the host code's tilings restated here (csrc/cdae.hip get_*_tiles, csrc/slicqt.hip get_dft4_full_tiles).
+    Structural assumptions, where one kernel holds several specialised bodies: layer 4's out-of-loop instructions are
+    estimated (see there); the radix-4 kernel's out-of-loop count is its prologue plus one
+    epilogue block per 16-column block (33 instructions for the synthesis; the rest pro rata for the analysis) and one
+    peeled K-step.  Returns {event name: (bound_ms, mfma_cycle_share)} -- None without the committed budget."""
+    import math
+    path = os.path.join(ROOT, "profiles", "isa_budget.json")
+    if not os.path.exists(path):
+        return None
+    K = json.load(open(path))["kernels"]
+    from xumx_slicq_amd.weights import freq_filter
+    Lg = plan.Lg.astype("int64")
+    split = int(os.environ.get("XSQ_D4_MIN_LG", 24))
+    tot = {}
+
+    def add(name, waves, mfma, valu):
+        m, v = tot.get(name, (0.0, 0.0))
+        tot[name] = (m + waves * mfma, v + waves * 4.0 * valu)
+
+    def engine(name, key, M, ncols_tiles, ksteps, waves=4):
+        """generic tile engine: 128-row tiles, the loop of the assembly covers two 16-value K-steps"""
+        k = K[key]
+        lp = k["loops"][0]
+        tiles = math.ceil(M / 128) * ncols_tiles
+        add(name, tiles * waves, k["outside"]["mfma_cycles"] + lp["mfma_cycles"] * ksteps / 2.0, k["outside"]["valu"] + lp["valu"] * ksteps / 2.0)
+
+    for n in chunk_lengths:
+        n = max(n, plan.L // 2 + 1)
+        S = plan.num_slices(n)
+        T1, T2 = 2 * S - 1, 2 * S - 4
+        for (_, F, T) in plan.blocks:
+            kf = freq_filter(F)
+            F1, F2 = F - kf + 1, F - 2 * kf + 2
+            # layer 1: one 52-column tile per 128 rows and target; K = 2 kf T padded to 16
+            engine("cdae_l1_gemm", "gemm<CdaeL1Op>", B * F1 * T1, 4, math.ceil(2 * kf * T / 16))
+            # layers 2 / 3
+            for name, To, Fo, key_w, key_s, key_g in (("cdae_l2", T2, F2, "cdae_wino<L2>", "cdae_slab<L2>", "gemm<CdaeL2Op>"),
+                                                    ("cdae_l3", T1, F1, "cdae_wino<L3>", "cdae_slab<L3>", "gemm<CdaeL3Op>")):
+                if winograd and (To + 1) // 2 >= 64:
+                    k = K[key_w]
+                    tiles = 4 * B * math.ceil(Fo * ((To + 1) // 2) / 64)
+                    add(name + "_slab", tiles * 4, k["outside"]["mfma_cycles"] + kf * k["loops"][0]["mfma_cycles"], k["outside"]["valu"] + kf * k["loops"][0]["valu"])
+                elif To >= 86:
+                    k = K[key_s]
+                    tiles = 4 * B * math.ceil(Fo * To / 256)
+                    add(name + "_slab", tiles * 8, k["outside"]["mfma_cycles"] + kf * k["loops"][0]["mfma_cycles"], k["outside"]["valu"] + kf * k["loops"][0]["valu"])
+                else:
+                    engine(name + "_gemm", key_g, B * Fo * To, 4, kf * 13)
+            # layer 4: N = T columns in tiles of 64 with a last tile of 16 / 32 / 48 / 64; K = kf * 104 padded to 16
+            k4 = K["gemm<CdaeL4Op>"]
+            loops = {lp["mfma_cycles"] // 32: lp for lp in k4["loops"]}           # columns of the class -> its loop (512 cycles = 16 columns, ...)
+            ks4 = math.ceil(kf * 104 / 16)
+            for n0 in range(0, T, 64):
+                w = min(64, 16 * math.ceil((T - n0) / 16))
+                lp = loops[w]
+                tiles = 4 * math.ceil(B * F * 2 * S / 128)
+                # out of the loop: the binary holds four width classes x two epilogues (masks only | estimates as well); what the
+                # separator's path runs is ~200 instructions of prologue and the masks-only epilogue, 6 per element (sigmoid 5 +
+                # store), w / 2 elements per lane -- an estimate, the static count (8,476 over all bodies) cannot tell them apart
+                add("cdae_l4_gemm", tiles * 4, 16.0 * w + lp["mfma_cycles"] * (ks4 - 1) / 2.0, 200.0 + 6.0 * w / 2 + lp["valu"] * ks4 / 2.0)
+        # band kernels: rows = channel-slices; radix-4 bands in 32-row tiles of 4 waves, K-steps of 8 complex, 256 MFMA cycles per
+        # 16-column block and K-step; short bands on the dense engine (N = 2 Lg columns, K = 2 Lg)
+        for name, key, rows, eblk in (("band_analysis_dft4", "band_dft4<forward>", 2 * B * S, None), ("band_synthesis_dft4", "band_dft4<inverse,masked>", 8 * B * S, 33)):
+            k = K[key]
+            lp = k["loops"][0]
+            e = eblk if eblk is not None else (k["outside"]["valu"] - 300) / 10.0
+            for lg in Lg[Lg >= split]:
+                m = int(lg) // 4
+                ncb, ksteps = math.ceil(2 * m / 16), math.ceil(m / 8)
+                tiles = math.ceil(rows / 32)
+                add(name, tiles * 4, 256.0 * ncb * ksteps, k["outside"]["valu"] - (10 - ncb) * e + lp["valu"] * (ksteps - 1))
+        for name, key, rows in (("band_analysis_gemm", "gemm<BandFwdOp>", 2 * B * S), ("band_synthesis_gemm", "gemm<BandInvOp>", 8 * B * S)):
+            for lg in Lg[Lg < split]:
+                engine(name, key, rows, math.ceil(2 * int(lg) / 64), math.ceil(2 * int(lg) / 16))
+    return {k: ((m + v) / (SIMDS * PEAK_CLOCK_GHZ * 1e9) * 1e3, m / (m + v)) for k, (m, v) in tot.items()}
+
+
 def cpu_baseline(threads, full=False):
     """The CPU oracle (a port of the reference, pinned to it by tests/golden) timed on this box's host cores.  Default
     (`full`): the bench's own 240 s track -- the same workload as `value`, the oracle's literal chunk loop over 4 full
@@ -239,6 +325,19 @@ def cpu_baseline(threads, full=False):
                       "240 s track at 1.87 x real-time on 8 cores of the build container, BASELINE.md section 2)"}
 
 
+def roofline_issue_table(bound, prof_step, steps_in_prof):
+    """`roofline_issue`: every fp32 MFMA kernel's measured time against its issue bound (issue_bound above)."""
+    out = []
+    if not bound:
+        return out
+    for k, (ms, _launches) in sorted(prof_step.items(), key=lambda kv: -kv[1][0]):
+        if k in bound and ms > 0:
+            tb, share = bound[k]
+            out.append({"kernel": k, "ms_per_step": round(ms / steps_in_prof, 4), "t_issue_bound_ms": round(tb, 4),
+                        "frac_of_issue_bound": round(tb / (ms / steps_in_prof), 4), "mfma_share_of_issue_cycles": round(share, 3)})
+    return out
+
+
 def roofline_tables(work, prof_step, steps_in_prof, wiener=False):
     """Per-kernel fractions from one fully instrumented step: HBM-bound kernels against 8 TB/s, matrix kernels
     against the fp32 MFMA peak.  achieved = algorithmic work of the step's launches / their summed duration."""
@@ -260,6 +359,27 @@ def roofline_tables(work, prof_step, steps_in_prof, wiener=False):
                          "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "algorithmic_flops_per_step": int(amount), "pmc": pmc_issue(k, "wiener" if wiener else None)})
     return hbm, mfma
+
+
+def executed_mfma_flops(plan, B, chunk_lengths, kernel, winograd):
+    """Flops the matrix pipe EXECUTES per step under `kernel` where they differ from the algorithmic count of SURVEY.md 8(d):
+    layers 2 / 3 as Winograd F(2, 4) along the time taps -- 5 products per output pair, input channel (52 stored) and matrix
+    column (48 of the 50 / 51 channels; the rest on the vector ALU) instead of 8 per pair, real channel and column."""
+    if kernel not in ("cdae_l2_slab", "cdae_l3_slab") or not winograd:
+        return None
+    from xumx_slicq_amd.weights import freq_filter
+    total = 0
+    for n in chunk_lengths:
+        S = plan.num_slices(max(n, plan.L // 2 + 1))
+        T1, T2 = 2 * S - 1, 2 * S - 4
+        To = T2 if kernel == "cdae_l2_slab" else T1
+        if (To + 1) // 2 < 64:
+            continue
+        for (_, F, T) in plan.blocks:
+            kf = freq_filter(F)
+            Fo = F - 2 * kf + 2 if kernel == "cdae_l2_slab" else F - kf + 1
+            total += 4 * B * Fo * ((To + 1) // 2) * kf * 5 * 52 * 48 * 2
+    return total
 
 
 def dominant_roofline(dom, prof, work, steps, dt, precision="fp32", wiener=False):
@@ -512,6 +632,17 @@ def bench_track(args, sep, dev, world, rank, dist):
     work = algorithmic_work(plan, 1, my_items, args.wiener)
     roofline = dominant_roofline(dom, prof, work, args.steps, dt, args.precision, args.wiener) if dom else None
     hbm, mfma = roofline_tables(work, prof_all, nwarm, args.wiener)
+    wino = bool(getattr(sep.xumx_model, "winograd", 1)) and not (int(os.environ.get("XSQ_CDAE_VARIANT", "0")) & 2048) and args.precision == "fp32"
+    issue = roofline_issue_table(issue_bound(plan, 1, my_items, winograd=wino) if args.precision == "fp32" else None, prof_all, nwarm)
+    if roofline and issue:
+        for row in issue:
+            if row["kernel"] == roofline["kernel"]:
+                roofline["issue_bound"] = {"t_issue_bound_ms": row["t_issue_bound_ms"],
+                                           "frac_of_issue_bound": round(row["t_issue_bound_ms"] / (roofline["avg_launch_ms"] * roofline["launches"] / args.steps), 4)}
+        executed = executed_mfma_flops(plan, 1, my_items, roofline["kernel"], wino)
+        if executed:
+            roofline["mfma_flops_executed_per_launch"] = int(executed * args.steps / roofline["launches"])
+            roofline["frac_by_executed_flops"] = round(executed * args.steps / roofline["launches"] / (roofline["avg_launch_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
     kernels = {k: {"ms_per_step": round(v[0] / nwarm, 4), "launches_per_step": v[1] / nwarm}
                for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
     result = {
@@ -531,6 +662,10 @@ def bench_track(args, sep, dev, world, rank, dist):
         "roofline": roofline,
         "roofline_hbm": hbm,
         "roofline_mfma": mfma,
+        "roofline_issue": issue,
+        "roofline_issue_note": "fp32 MFMAs and the other vector instructions of a SIMD share one issue port on gfx950: t_issue_bound = sum over tiles "
+                               "and waves of (MFMA cycles + 4 x other vector instructions) / (1024 SIMDs x 2.4 GHz), instruction counts from the assembly "
+                               "(profiles/isa_budget.json, tools/isa_budget.py); frac_of_issue_bound = t_issue_bound / measured",
         "kernels_source": "last warm-up step: all kernels instrumented and the tail pass serialised behind the stacked pass (clean per-kernel times; their sum exceeds ms_per_step, whose timed region overlaps the two passes and instruments the roofline kernel only)",
         "kernels": kernels,
     }

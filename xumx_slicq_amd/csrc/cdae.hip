@@ -680,9 +680,9 @@ static int get_l1q_tiles(xsq_model* Mo, int Bn, int S, int ntg, TileTable* out) 
 }
 
 // tiles of the slab kernels (cdae_slab.h): 256 consecutive rows inside one batch item, all 64 columns
-static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int max_kf = 1 << 30) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(layer + 64, Bn, S);
+    auto key = std::make_tuple(layer + 64 + (max_kf < (1 << 30) ? 1000 * max_kf : 0), Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
@@ -692,6 +692,7 @@ static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     std::vector<SlabTileDev> t;
     for (int b : order) {
         const CdaeBlockDev& d = Mo->blocks[b];
+        if (d.kf > max_kf) continue;
         const int64_t perb = layer == 2 ? (int64_t)d.F2 * T2 : (int64_t)d.F1 * T1;
         for (int tgt = 0; tgt < NT; ++tgt) {
             const int64_t off1 = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);   // act1 / act3 of the (block, target)
@@ -719,9 +720,9 @@ static int get_slab_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
 }
 
 // tiles of the Winograd kernels (cdae_wino.h): 64 consecutive output PAIRS of one batch item in the flattened (f, pair) space
-static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out, int min_kf = 0) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(layer + 96, Bn, S);
+    auto key = std::make_tuple(layer + 96 + 1000 * min_kf, Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
@@ -732,6 +733,7 @@ static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     const int To = layer == 2 ? T2 : T1, P = (To + 1) / 2;
     for (int b : order) {
         const CdaeBlockDev& d = Mo->blocks[b];
+        if (d.kf < min_kf) continue;
         for (int tgt = 0; tgt < NT; ++tgt) {
             const int64_t off1 = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);   // act1 / act3 of the (block, target)
             const int64_t off2 = (int64_t)CS * Bn * T2 * (4 * (int64_t)d.cumF2 + (int64_t)tgt * d.F2);   // act2
@@ -1022,11 +1024,20 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         // fp32: Winograd F(2, 4) along the four time taps (cdae_wino.h) -- 5 instead of 8 MFMA products per output pair;
         // rows of >= 64 pairs, i.e. To >= 127.  xsq_model_set_winograd(0) / XSQ_CDAE_VARIANT=2048: the direct slab kernels.
         if (!bf3 && !bf6 && a.upool && Mo->winograd && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
-            int rcw = get_wino_tiles(Mo, layer, a.Bn, a.S, &tt);
+            // XSQ_WINO_MIN_KF (A/B): blocks with fewer frequency taps stay on the direct kernel (their tiles are short: a
+            // prologue per 64 pairs and tap), the Winograd kernel takes the rest
+            static const int min_kf = getenv("XSQ_WINO_MIN_KF") ? atoi(getenv("XSQ_WINO_MIN_KF")) : 0;
+            int rcw = get_wino_tiles(Mo, layer, a.Bn, a.S, &tt, min_kf);
             if (rcw) return rcw;
             XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);
             if (layer == 2) hipLaunchKernelGGL((cdae_wino_kernel<false>), dim3(tt.ntiles), dim3(256), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
             else hipLaunchKernelGGL((cdae_wino_kernel<true>), dim3(tt.ntiles), dim3(256), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
+            if (min_kf > 1) {
+                TileTable ts;
+                if ((rcw = get_slab_tiles(Mo, layer, a.Bn, a.S, &ts, min_kf - 1))) return rcw;
+                if (layer == 2) hipLaunchKernelGGL((cdae_slab_kernel<false, 3, true>), dim3(ts.ntiles), dim3(512), 0, stream, a, (const SlabTileDev*)ts.d_tiles, ts.ntiles);
+                else hipLaunchKernelGGL((cdae_slab_kernel<true, 3, true>), dim3(ts.ntiles), dim3(512), 0, stream, a, (const SlabTileDev*)ts.d_tiles, ts.ntiles);
+            }
             return XSQ_OK;
         }
         int rc = get_slab_tiles(Mo, layer, a.Bn, a.S, &tt);
