@@ -626,6 +626,7 @@ def bench_track(args, sep, dev, world, rank, dist):
         if not args.wiener:
             variants["wiener"] = variant_wiener(args, dev, track, plan, my_items)
         variants["train_step"] = variant_train_step(args, sep, dev)
+        variants["train_step_bf16"] = variant_train_step(args, sep, dev, precision="bf16")
     if rank != 0:
         return None
     audio_s = world * args.steps * TRACK_SAMPLES / FS
@@ -765,7 +766,7 @@ def variant_wiener(args, dev, track, plan, my_items):
             "kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}}
 
 
-def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
+def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0, precision="fp32"):
     """BASELINE configs[4] (SURVEY config 5): one training.loop step -- train-mode forward, ComplexMSE + MaskSum,
     backward incl. the differentiable Wiener-EM, AdamW -- on a batch of 16 two-second chunks, offline model."""
     import contextlib
@@ -776,7 +777,7 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
     from xumx_slicq_amd.training import Trainer
     with contextlib.redirect_stdout(sys.stderr):
         sept = seeded_separator(realtime=False, device=dev)
-    tr = Trainer(sept.xumx_model, (sept.nsgt, sept.insgt, sept.cnorm), device=dev)
+    tr = Trainer(sept.xumx_model, (sept.nsgt, sept.insgt, sept.cnorm), device=dev, precision=precision)
     n = int(seq_dur * FS)
     y_t = torch.stack([0.5 * synth_audio(n, seed=700 + j, nb_samples=batch) for j in range(4)]).to(dev)
     x = y_t.sum(0)
@@ -817,7 +818,9 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
     flops = 3 * fwd
     return {"what": "BASELINE configs[4]: training.py step, CDAE fwd+bwd with the X-UMX combined loss (ComplexMSE 14 "
                     "combinations + MaskSum), differentiable Wiener-EM, AdamW; batch = 16 chunks of 2 s (S = 11), offline "
-                    "model, fp32; incl. the five forward sliCQTs (mix + 4 targets) of the batch",
+                    "model, %s; incl. the five forward sliCQTs (mix + 4 targets) of the batch"
+                    % ("fp32" if precision == "fp32" else "forward / data-gradient contractions on bf16-rounded operands (one v_mfma_f32_32x32x16_bf16 per "
+                       "product, fp32 accumulate: the arithmetic of the reference's bf16 autocast convolutions, training.py:473-476), everything else fp32"),
             "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(batch / dt, 1), "steps_per_s": round(1.0 / dt, 2),
             "ms_per_step_pipelined": round(dtp * 1e3, 3),
             "loss_readback": "ms_per_step: looked at after every step, as loss.item() in training.py:110; "
@@ -827,7 +830,10 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0):
                           "(3 x %.1f GFLOP); BatchNorm, loss, Wiener-EM, sliCQTs and AdamW are not counted" % (fwd / 1e9),
             "achieved_tflops": round(flops / dt / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
             "frac": round(flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "parity": "tests/test_training.py::test_hip_training_step_at_config_size_matches_the_oracle (this batch, fp32 and bf16x6)",
+            "frac_note": "of the fp32 MFMA peak (the weight gradients and, in the fp32 arm, everything run there; the bf16 arm's forward / data-gradient "
+                         "contractions run on the bf16 pipe, 16x that peak)",
+            "parity": ("tests/test_training.py::test_hip_training_step_at_config_size_matches_the_oracle (this batch, fp32 and bf16x6)" if precision == "fp32"
+                       else "tests/test_training.py::test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread (reference autograd under bf16 autocast)"),
             "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
             "dominant_kernel": {"kernel": dom, "ms_per_step": kern[dom], "share_of_step": round(kern[dom] / (dt * 1e3), 4)},
             "kernels_ms": dict(list(kern.items())[:12])}

@@ -343,3 +343,53 @@ def test_pending_loss_equals_the_waited_step_and_expires_after_four_steps():
         tr_b.step(x, y_t, wait=False)
     with pytest.raises(_lib.XsqError):
         old.result()                                                  # five steps later its ring slot has been reused
+
+
+@pytest.mark.gpu
+def test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread(oracle_plan, seeded_sd):
+    """BASELINE configs[4] as written: "training.py step ... bf16".  The reference runs forward + loss under
+    torch.autocast("cpu", dtype=torch.bfloat16) (training.py:66-108,473-476); tests/golden/training_step_bf16.npz
+    (oracle/make_golden_train_bf16.py, the reference's own autograd) holds that step on fixture A's batch next to the same
+    step in fp32.  The reference's bf16 step is NOT close to its fp32 step -- loss terms 2.4e-4 apart, per-tensor gradients
+    7.6 % apart in the median, ~100 % at the 90th percentile -- so the tolerances of the bf16 arm (Trainer(precision=
+    "bf16"): forward / data-gradient operands rounded to bf16, one MFMA per product, fp32 everything else) come from that
+    spread, not from a guess:
+      * both loss terms within 1e-3 of the autocast reference's and of the fp32 reference's (4x the reference's own gap);
+      * over all trainable tensors, the arm's relative distance to the fp32 gradients (the oracle's autograd, pinned to the
+        reference at 2e-3 by fixture A) has a median and a 90th percentile no larger than 1.25x the autocast reference's own;
+      * twelve full gradient tensors lie within 2.5x their own fp32-vs-autocast distance (+ 2 % of the tensor's norm) of the
+        autocast reference's."""
+    import numpy as np
+    from oracle import loss as oloss
+    g = load_golden("training_step_bf16.npz")
+    x, y_t = _inputs(int(g["n"]))
+    sep, tr = _trainer(False, precision="bf16")
+    loss, mse, msk = tr.step(x, y_t, apply_update=False)
+    grads = tr.gradients()
+    for ref in ("bf16", "fp32"):
+        assert abs(mse - float(g[f"{ref}_mse"])) < 1e-3 * float(g["fp32_mse"]), (ref, mse, float(g[f"{ref}_mse"]))
+        assert abs(msk - float(g[f"{ref}_mask"])) < 1e-3 * float(g["fp32_mask"]), (ref, msk, float(g[f"{ref}_mask"]))
+    _, _, _, grads_o = oloss.training_gradients(oracle_plan, seeded_sd, x, y_t, causal=False, wiener=True)
+    names = [str(k) for k in g["param_names"]]
+    rel_ref = dict(zip(names, g["rel_diff_bf16_vs_fp32"].tolist()))
+    norm32 = dict(zip(names, g["fp32_grad_norms"].tolist()))
+    mine, theirs = [], []
+    for k in names:
+        if norm32[k] <= 1e-6:
+            continue
+        want = grads_o[k].double()
+        mine.append(float((grads[k].cpu().double() - want).norm() / want.norm()))
+        theirs.append(rel_ref[k])
+    mine, theirs = np.asarray(mine), np.asarray(theirs)
+    print(f"\n[bf16 arm] relative distance to the fp32 gradients over {len(mine)} tensors: median {np.median(mine):.3e} "
+          f"(reference autocast {np.median(theirs):.3e}), 90 % {np.quantile(mine, 0.9):.3e} ({np.quantile(theirs, 0.9):.3e}); "
+          f"loss {mse:.6f} / {msk:.6f} against autocast {float(g['bf16_mse']):.6f} / {float(g['bf16_mask']):.6f}")
+    assert np.median(mine) <= 1.25 * np.median(theirs) and np.quantile(mine, 0.9) <= 1.25 * np.quantile(theirs, 0.9)
+    assert np.median(mine) > 1e-4                    # ... and it IS the bf16 arithmetic (the fp32 arm sits at ~1e-6 here)
+    for key in g.files:
+        if not key.startswith("bf16_grad::"):
+            continue
+        k = key.split("::", 1)[1]
+        ref16 = torch.from_numpy(g[key]).double()
+        d = float((grads[k].cpu().double() - ref16).norm())
+        assert d <= (2.5 * rel_ref[k] + 0.02) * norm32[k] + 1e-7, (k, d, rel_ref[k], norm32[k])

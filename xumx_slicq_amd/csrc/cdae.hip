@@ -1005,7 +1005,8 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block; split the batch", a.Bn, a.S);
     if (layer == 4 && a.gx8) layer = 6;
     const bool bf3 = a.split != 0;      // set by xsq_cdae_forward (inference only); operands are in the split format
-    const bool bf6 = Mo->precision == 2;       // fp32 operands, cut in the kernel (any operator / epilogue: also the training step)
+    const bool bf1 = Mo->precision == 3;       // training only (xsq_train_set_precision mode 1): operands rounded to bf16, one MFMA per product
+    const bool bf6 = Mo->precision == 2 || bf1; // fp32 operands, cut (or rounded) in the kernel (any operator / epilogue: also the training step)
     // Diagnostic A/B switches (default 0 = the product configuration; results stay correct in every setting):
     //   1 bf16x3 generic engine with 256-row tiles      2 ... with 32-value K-steps      4 no slab kernels at all
     //   8 no slab kernels on the fp32 path              64 fp32 slab kernels padded to 64 columns (MODE 0)
@@ -1070,7 +1071,8 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     if (rc) return rc;
 #define XSQ_LAUNCH(OP, MT_, XW_)                                                                                    \
     do {                                                                                                            \
-        if (bf6) hipLaunchKernelGGL((grouped_gemm_bf6_kernel<OP>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);           \
+        if (bf1) hipLaunchKernelGGL((grouped_gemm_bf6_kernel<OP, true>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);      \
+        else if (bf6) hipLaunchKernelGGL((grouped_gemm_bf6_kernel<OP>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);      \
         else if (!bf3 && xw) hipLaunchKernelGGL((grouped_gemm_kernel<OP, 1, XW_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
         else if (!bf3) hipLaunchKernelGGL((grouped_gemm_kernel<OP, MT_>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles);         \
         else if (variant & 2) hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 2>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \

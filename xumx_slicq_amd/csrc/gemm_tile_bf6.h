@@ -27,7 +27,18 @@ __device__ __forceinline__ void bf6_cut2(float x, float y, unsigned& p1, unsigne
     p3 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sy), __builtin_bit_cast(unsigned, sx), 0x07060302u);
 }
 
-template <class Op>
+// two values -> one word of two bf16, rounded to nearest even: what torch.autocast(dtype=bfloat16) makes of a conv operand
+// (/root/reference/xumx_slicq_v2/training.py:473-476).  (Inputs are finite activations / weights: no NaN handling.)
+__device__ __forceinline__ unsigned bf16_rne2(float x, float y) {
+    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
+    const unsigned rx = ux + 0x7fffu + ((ux >> 16) & 1u), ry = uy + 0x7fffu + ((uy >> 16) & 1u);
+    return __builtin_amdgcn_perm(ry, rx, 0x07060302u);
+}
+
+// PLAIN = true: the "bf16" training arm (xsq_train_set_precision mode 1, BASELINE configs[4] as written): both operands
+// rounded ONCE to bf16 (round to nearest even) between the global load and the LDS write, ONE v_mfma_f32_32x32x16_bf16 per
+// 16-value K-step and 32 x 32 block, fp32 accumulation -- the arithmetic of the reference's bf16 autocast convolutions.
+template <class Op, bool PLAIN = false>
 __global__ __launch_bounds__(256) void grouped_gemm_bf6_kernel(Op op, const TileDev* __restrict__ tiles, int ntiles) {
     static_assert(!aux_of<Op>::on, "operators with an aux stream run on the fp32 engine");
 #ifndef XSQ_BF6_LD
@@ -68,6 +79,10 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf6_kernel(Op op, const Tile
         }
     };
     auto put = [&](unsigned* row, const float4& v) {       // plane p: words [8p + 2q, 8p + 2q + 1], q = s_kq/4
+        if constexpr (PLAIN) {
+            *reinterpret_cast<uint2*>(row + (s_kq >> 1)) = make_uint2(bf16_rne2(v.x, v.y), bf16_rne2(v.z, v.w));
+            return;
+        }
         unsigned a1, a2, a3, b1, b2, b3;
         bf6_cut2(v.x, v.y, a1, a2, a3);
         bf6_cut2(v.z, v.w, b1, b2, b3);
@@ -100,6 +115,12 @@ __global__ __launch_bounds__(256) void grouped_gemm_bf6_kernel(Op op, const Tile
     auto mfma_step = [&](int buf) {
         const unsigned* As = As0 + buf * BM * LD;
         const unsigned* Bs = Bs0 + buf * BN * LD;
+        if constexpr (PLAIN) {
+            const bf16x8_t a1 = frag(&As[a_frag]), p1 = frag(&Bs[b_frag]);
+            XSQ_MF(a1, p1, acc0);
+            if (wide) { const bf16x8_t q1 = frag(&Bs[b_frag + 32 * LD]); XSQ_MF(a1, q1, acc1); }
+            return;
+        }
         const bf16x8_t a1 = frag(&As[a_frag]), a2 = frag(&As[a_frag + 8]), a3 = frag(&As[a_frag + 16]);
         const bf16x8_t p1 = frag(&Bs[b_frag]), p2 = frag(&Bs[b_frag + 8]), p3 = frag(&Bs[b_frag + 16]);
         if (wide) {

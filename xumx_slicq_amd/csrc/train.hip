@@ -646,8 +646,8 @@ extern "C" {
 
 int xsq_train_set_precision(xsq_train* T, int mode) {
     XSQ_REQUIRE(T && T->model, "xsq_train_set_precision: null handle");
-    XSQ_REQUIRE(mode == 0 || mode == 2, "xsq_train_set_precision: mode %d (0 = fp32, 2 = bf16x6)", mode);
-    T->model->precision = mode;
+    XSQ_REQUIRE(mode == 0 || mode == 1 || mode == 2, "xsq_train_set_precision: mode %d (0 = fp32, 1 = bf16, 2 = bf16x6)", mode);
+    T->model->precision = mode == 1 ? 3 : mode;      // (3: plain bf16 operands, training only -- mode 1 of the MODEL is the split-bf16 inference format)
     return XSQ_OK;
 }
 

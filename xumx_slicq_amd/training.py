@@ -73,12 +73,13 @@ class Trainer:
             _lib.check(_lib.lib.xsq_train_create(C.byref(self._h), len(self.table), self._F.ctypes.data,
                                                  self._T.ctypes.data, 1 if self.causal else 0,
                                                  params.ctypes.data, params.size), "xsq_train_create")
-        if precision not in ("fp32", "bf16x6"):
-            raise ValueError(f"precision {precision!r}: the training step offers 'fp32' and 'bf16x6'")
+        if precision not in ("fp32", "bf16x6", "bf16"):
+            raise ValueError(f"precision {precision!r}: the training step offers 'fp32', 'bf16x6' and 'bf16'")
         self.precision = precision
         from .model import note_precision
         note_precision(self, precision)          # bf16x6: no packed-fp32 slice FFT in this process meanwhile
-        _lib.check(_lib.lib.xsq_train_set_precision(self._h, 2 if precision == "bf16x6" else 0), "xsq_train_set_precision")
+        # "bf16": the reference's autocast arithmetic for the convolutions (training.py:473-476): operands rounded to bf16, fp32 accumulate
+        _lib.check(_lib.lib.xsq_train_set_precision(self._h, {"fp32": 0, "bf16": 1, "bf16x6": 2}[precision]), "xsq_train_set_precision")
         self._ws = None
         self.steps = 0
 
