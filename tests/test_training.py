@@ -390,6 +390,8 @@ def test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread(or
         if not key.startswith("bf16_grad::"):
             continue
         k = key.split("::", 1)[1]
+        if norm32[k] <= 1e-6:                     # (a tensor whose gradient is rounding noise in fp32 already: input_mean of block 0)
+            continue
         ref16 = torch.from_numpy(g[key]).double()
         d = float((grads[k].cpu().double() - ref16).norm())
         assert d <= (2.5 * rel_ref[k] + 0.02) * norm32[k] + 1e-7, (k, d, rel_ref[k], norm32[k])

@@ -28,11 +28,12 @@ __device__ __forceinline__ void bf6_cut2(float x, float y, unsigned& p1, unsigne
 }
 
 // two values -> one word of two bf16, rounded to nearest even: what torch.autocast(dtype=bfloat16) makes of a conv operand
-// (/root/reference/xumx_slicq_v2/training.py:473-476).  (Inputs are finite activations / weights: no NaN handling.)
+// (/root/reference/xumx_slicq_v2/training.py:473-476).
 __device__ __forceinline__ unsigned bf16_rne2(float x, float y) {
-    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
-    const unsigned rx = ux + 0x7fffu + ((ux >> 16) & 1u), ry = uy + 0x7fffu + ((uy >> 16) & 1u);
-    return __builtin_amdgcn_perm(ry, rx, 0x07060302u);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));      // v_cvt_pk_bf16_f32 (gfx950): one instruction per pair
 }
 
 // PLAIN = true: the "bf16" training arm (xsq_train_set_precision mode 1, BASELINE configs[4] as written): both operands
