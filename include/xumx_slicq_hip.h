@@ -177,11 +177,6 @@ int xsq_model_destroy(xsq_model* model);
  *      product, one fp32 rounding -- measured as close to the torch-cpu reference as mode 0
  *      (1.1e-7 RMS), 6/16 of the matrix-pipe time.                                              */
 int xsq_model_set_precision(xsq_model* model, int mode);
-/* A/B switch, fp32 inference, non-causal first layer: 4 (or any value but 0 and 2) = layer 1 of a block's FOUR targets in one
- * tile, 2 = two targets per tile -- the targets read the same whitened magnitude (model.py:244-247), so the operand is
- * loaded and staged once for several targets' MFMAs (csrc/cdae_l1q.h); 0 (default) = one tile per (block, target) on the
- * generic engine.  Same bits; measured SLOWER than the default (0.58-0.66 against 0.545 ms: fewer resident waves).    */
-int xsq_model_set_l1_quad(xsq_model* model, int on);
 /* fp32 inference, layers 2 / 3 (the 4-tap time convolutions of model.py:140-170), rows of >= 127 time positions: 1 (default) =
  * Winograd F(2, 4) along the time taps (csrc/cdae_wino.h: five MFMA products per output pair and channel pair instead of
  * eight; input transform with integer coefficients in registers, weights transformed on the host in fp64; ~2e-7 RMS of a

@@ -65,7 +65,6 @@ _SIGS = {
     "xsq_model_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, _vp, C.c_int, _vp, C.c_int64]),
     "xsq_model_destroy": (C.c_int, [_vp]),
     "xsq_model_set_precision": (C.c_int, [_vp, C.c_int]),
-    "xsq_model_set_l1_quad": (C.c_int, [_vp, C.c_int]),
     "xsq_model_set_winograd": (C.c_int, [_vp, C.c_int]),
     "xsq_cdae_workspace": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "xsq_cdae_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),

@@ -584,7 +584,6 @@ namespace xsq {
 // host
 // ------------------------------------------------------------------------------------------
 }  // namespace xsq
-#include "cdae_l1q.h"
 namespace xsq {
 
 static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 VGPR -> 2 waves per SIMD (L3 1.51 -> 1.74 ms)
@@ -645,35 +644,6 @@ static int get_cdae_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     tt.ntiles = (int)t.size();
     XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
     XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
-    Mo->tiles[key] = tt;
-    *out = tt;
-    return XSQ_OK;
-}
-
-// tiles of the four-target layer-1 kernel (cdae_l1q.h): 128 rows of a BLOCK (TileDev.group = block index), longest K first
-static int get_l1q_tiles(xsq_model* Mo, int Bn, int S, int ntg, TileTable* out) {
-    std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(1 + 512 * ntg, Bn, S);
-    auto it = Mo->tiles.find(key);
-    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
-    const int T1 = Mo->causal ? 2 * S : 2 * S - 1;
-    std::vector<int> order(Mo->nblocks);
-    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        return Mo->blocks[x].kf * Mo->blocks[x].T > Mo->blocks[y].kf * Mo->blocks[y].T; });
-    std::vector<TileDev> t;
-    for (int b : order) {
-        const int64_t M = (int64_t)Bn * Mo->blocks[b].F1 * T1;
-        for (int64_t m0 = 0; m0 < M; m0 += L1Q_BM)
-            for (int tg0 = 0; tg0 < NT; tg0 += ntg) t.push_back(TileDev{b, (int)m0, tg0, 0});
-    }
-    TileTable tt;
-    int rc = [&] { tt.ntiles = (int)t.size(); tt.d_tiles = nullptr;
-                   if (t.empty()) return (int)XSQ_OK;
-                   XSQ_HIP(hipMalloc(&tt.d_tiles, t.size() * sizeof(TileDev)));
-                   XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(TileDev), hipMemcpyHostToDevice));
-                   return (int)XSQ_OK; }();
-    if (rc) return rc;
     Mo->tiles[key] = tt;
     *out = tt;
     return XSQ_OK;
@@ -953,12 +923,6 @@ int xsq_model_set_winograd(xsq_model* Mo, int on) {
     return XSQ_OK;
 }
 
-int xsq_model_set_l1_quad(xsq_model* Mo, int on) {
-    XSQ_REQUIRE(Mo, "xsq_model_set_l1_quad: null model");
-    Mo->l1_quad = on;           // 0 per-target tiles, 2 two targets per tile, else four
-    return XSQ_OK;
-}
-
 int xsq_model_destroy(xsq_model* Mo) {
     if (!Mo) return XSQ_OK;
     for (auto& kv : Mo->tiles) (void)hipFree(kv.second.d_tiles);
@@ -1052,17 +1016,6 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw && late) XSQ_SLAB_LATE(true); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
 #undef XSQ_SLAB_LATE
 #undef XSQ_SLAB
-        return XSQ_OK;
-    }
-    if (layer == 1 && xw && !a.causal && Mo->l1_quad && !(variant & 1024)) {
-        // fp32 inference, non-causal first layer: the four targets of a block share their input -- one tile computes all
-        // four (cdae_l1q.h; XSQ_CDAE_VARIANT=1024 restores the per-target tiles of the generic engine, same bits)
-        const int ntg = Mo->l1_quad == 2 ? 2 : 4;
-        int rc = get_l1q_tiles(Mo, a.Bn, a.S, ntg, &tt);
-        if (rc) return rc;
-        XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream);
-        if (ntg == 4) hipLaunchKernelGGL((cdae_l1_quad_kernel<CdaeL1Op, CdaeGroup, 4>), dim3(tt.ntiles), dim3(256), 0, stream, a, tt.d_tiles, tt.ntiles);
-        else hipLaunchKernelGGL((cdae_l1_quad_kernel<CdaeL1Op, CdaeGroup, 2>), dim3(tt.ntiles), dim3(256), 0, stream, a, tt.d_tiles, tt.ntiles);
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity

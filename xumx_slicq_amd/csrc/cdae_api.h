@@ -30,7 +30,6 @@ struct xsq_model {
     int causal = 0;
     int precision = 0;             // 0 fp32 MFMA, 1 split-bf16 MFMA (xsq_model_set_precision)
     int winograd = 1;              // fp32 layers 2 / 3 as Winograd F(2, 4) along the time taps (cdae_wino.h; xsq_model_set_winograd: 0 = the direct slab kernels)
-    int l1_quad = 0;               // A/B switch (xsq_model_set_l1_quad): 4 / 2 = layer 1 of four / two targets of a block in one tile (cdae_l1q.h; measured slower)
     int nblocks = 0;
     int64_t sumFT = 0;             // complex coefficients per channel-slice
     std::vector<xsq::BlockHost> table;

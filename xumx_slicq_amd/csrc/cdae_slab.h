@@ -1,20 +1,22 @@
-// Layers 2 and 3 of the CDAE on the split-bf16 matrix path, with the input slab of a tile held ONCE in LDS.
+// Layers 2 and 3 of the CDAE as DIRECT 4-tap convolutions, with the input slab of a tile held ONCE in LDS.
+//
+// Which kernel runs where (cdae.hip: cdae_launch_layer):
+//   fp32 (the default precision), rows of >= 127 positions : cdae_wino.h (Winograd F(2, 4) along the time taps) -- NOT this file
+//   fp32, rows of 86..126 positions, or xsq_model_set_winograd(0) : cdae_slab_kernel<., 3, true> below (MODE 3, exact fp32)
+//   bf16x6 / bf16x3 (opt-in, xsq_model_set_precision 2 / 1), rows >= 86 : MODE 2 / MODE 1 below
+//   shorter rows, and the training step (raw epilogues) : the generic tile engine (gemm_tile*.h)
 //
 // Both layers are (kf x 4)-tap convolutions over channels-last activations (model.py:140-170; layer 3 is the
 // transposed convolution written as a gather, cdae.hip).  Seen as an implicit GEMM, row (f, t) of the A
 // operand is, for every df, the run of 4 x 52 consecutive words that starts at position t of input row
-// f +- df: rows t and t + 1 share three of their four positions.  The generic engine (gemm_tile_bf3.h) loads
-// every row's run separately -- each activation crosses the L2 -> LDS path 4 kf times, and with three bf16
-// MFMAs per product that path, not the matrix pipe, bounds the kernel (measured: ~8 TB/s of operand traffic
-// at 25 % of the pipe).  Here a tile is 256 consecutive output rows of one batch item; for each df its
-// DISTINCT input positions (256 + 3 per touched (b, f) row) are copied once, coalesced, into LDS as two
-// planes (hi bf16 | lo bf16), and every MFMA A fragment is read straight out of that image at
-// (row position * 52 + k): the 4x overlap is served by LDS.  B (the weights of this df, 64 x 208 words)
-// streams through a double-buffered LDS tile shared by the 8 waves of the workgroup.
-//   L2 -> LDS traffic per 256 rows and df:  A 54 KB + B 53 KB   (generic engine, 2 x 128 rows: 212 + 106 KB)
-//   LDS: 2 x 27.9 KB slab planes + two B tiles (7.3 KB; 10.6 KB for bf16x6) -> two 512-thread workgroups per CU.
-// Plane row stride is 52 bf16 = 104 B: the 32 lanes of a ds_read_b64 fragment read hit 32 distinct even
-// banks (26 r mod 64), conflict-free; B tile rows are 36 words (conflict-free ds_read_b128, gemm_tile_bf3.h).
+// f +- df: rows t and t + 1 share three of their four positions.  The generic engine loads every row's run
+// separately -- each activation crosses the L2 -> LDS path 4 kf times.  Here a tile is 256 consecutive output rows of
+// one batch item; for each df its DISTINCT input positions (256 + 3 per touched (b, f) row) are copied once,
+// coalesced, into LDS -- one fp32 plane (MODE 0 / 2 / 3; row stride 52 words) or two bf16 planes hi | lo (MODE 1) --
+// and every MFMA A fragment is read straight out of that image: the 4x overlap is served by LDS.  B (the weights of
+// this df, 52 x 208 words) streams through a double-buffered LDS tile shared by the 8 waves of the workgroup.
+//   L2 -> LDS traffic per 256 rows and df:  A 54 KB + B 43 KB   (generic engine, 2 x 128 rows: 212 + 106 KB)
+//   LDS: 55.7 KB of slab + two B tiles (7.3 KB; 10.6 KB for bf16x6) -> two 512-thread workgroups per CU.
 #pragma once
 #include "cdae_api.h"
 #include "gemm_tile_bf3.h"

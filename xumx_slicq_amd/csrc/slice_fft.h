@@ -434,10 +434,6 @@ __device__ unsigned long long g_fft_stamps[FFT_STAMP_ROWS * 8];
 #define XSQ_STAMP(i) do { } while (0)
 #endif
 
-#ifndef XSQ_FFT_EARLY_PREV
-#define XSQ_FFT_EARLY_PREV 0      // A/B: 1 = the adding launch requests its partner sums in front of FFT steps 2 / 3
-#endif
-
 struct OlaArgs {
     float* y;
     const int64_t* row_off;
@@ -727,24 +723,11 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
     constexpr int NIT = (FFT_N + NT - 1) / NT;
     const bool interior = al8 && i0 >= 0 && i0 + FFT_L <= O.length;
     float2* const y2 = reinterpret_cast<float2*>(yr + i0);
-#if XSQ_FFT_EARLY_PREV
-    // adding launch: the partner sums (stored by the even launch, long complete) are requested HERE, in front of steps 2 / 3,
-    // and arrive while those run -- at the end of the row the read-modify-write is then add + store
-    float2 prev[NIT];
-    if (interior && O.parity) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int nn = tid + NT * it;
-            prev[it] = (nn < FFT_N && (2 * nn < 2 * O.h ? add_lo : add_hi)) ? y2[nn] : make_float2(0.f, 0.f);
-        }
-    }
-#endif
     if (!(XSQ_ABLATE & 64)) fft_steps_2_3<+1, NT, PK>(Z, T.w1, w2s, tid);
     XSQ_STAMP(4);
     if (XSQ_ABLATE & 128) return;
     if (interior) {
         // interior slice, 8-byte aligned: all loads of the partner sums first, then all stores
-#if !XSQ_FFT_EARLY_PREV
         float2 prev[NIT];
         if (O.parity) {
 #pragma unroll
@@ -753,7 +736,6 @@ __global__ __launch_bounds__(NT, NT / 128) void k_slice_irfft(const float2* __re
                 prev[it] = (nn < FFT_N && (2 * nn < 2 * O.h ? add_lo : add_hi)) ? y2[nn] : make_float2(0.f, 0.f);
             }
         }
-#endif
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int nn = tid + NT * it;

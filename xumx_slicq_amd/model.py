@@ -272,7 +272,6 @@ class Unmix(nn.Module):
                 1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
             # inside the device guard: bf16 modes allocate and launch on the CURRENT device
             _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
-            _lib.check(_lib.lib.xsq_model_set_l1_quad(out, int(getattr(self, "l1_quad", 0))), "xsq_model_set_l1_quad")
             _lib.check(_lib.lib.xsq_model_set_winograd(out, int(getattr(self, "winograd", 1))), "xsq_model_set_winograd")
         self._handles[idx] = (ver, out)
         return out
@@ -294,13 +293,6 @@ class Unmix(nn.Module):
         self.winograd = 1 if on else 0
         for _ver, h in self._handles.values():
             _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
-
-    def set_l1_quad(self, on):
-        """A/B switch: 4 (True) / 2 = layer 1 of four / two targets of a block in one tile (csrc/cdae_l1q.h: the targets share
-        their input); 0 (False, default) = one tile per (block, target) on the generic engine.  Same bits; measured slower."""
-        self.l1_quad = 4 if on is True else int(on)
-        for _ver, h in self._handles.values():
-            _lib.check(_lib.lib.xsq_model_set_l1_quad(h, int(self.l1_quad)), "xsq_model_set_l1_quad")
 
     def __del__(self):
         try:
