@@ -64,11 +64,13 @@ constexpr int WN_OROWS = WN_PAIRS + 1 * WN_MAXSEG;        // odd-plane rows:  pa
 constexpr int WN_POS = 2 * WN_PAIRS + 3 * WN_MAXSEG;      // slab positions of a tile (134)
 constexpr int WN_SLD = 56;                                // plane row stride in words: 52 channels + 4 pad (14 slots: header comment)
 constexpr int WN_BLD = 24;                                // weight tile row: 16 k | 4 tail k | 4 pad words (6 slots)
-constexpr int WN_BTILE = CS * WN_BLD;                     // words per component tile in LDS
 constexpr int WN_COLS = 51;                               // columns that are staged: 48 on the matrix pipe + up to 3 on the vector ALU
-constexpr int WN_U16 = 5 * WN_COLS * 16;                  // words of chunk 0 / 1 in global memory: [component][col][16 k] = 1020 float4
-constexpr int WN_U20 = 5 * WN_COLS * 20;                  // chunk 2 = channels 32..51: [component][col][20 k] = 1275 float4
-constexpr int WN_UDF = 2 * WN_U16 + WN_U20;               // words per frequency tap
+constexpr int WN_BTILE = WN_COLS * WN_BLD;                // words per component tile in LDS (row = component * 51 + column)
+constexpr int WN_U16 = 5 * WN_COLS * 16;                  // words of a chunk's main part in global memory: [component][col][16 k] = 1020 float4
+constexpr int WN_UT = 5 * WN_COLS * 4;                    // the tail channels 48..51: [component][col][4 k] = 255 float4 (staged with chunk 2)
+constexpr int WN_UDF = 3 * WN_U16 + WN_UT;                // words per frequency tap: three main parts, then the tail
+// (float4 x of a main part lands at LDS row x >> 2, words 4 (x & 3) ..; float4 x of the tail at row x, words 16..19: no division
+//  anywhere in the staging)
 
 // Cook-Toom F(2, 4), points {0, 1, -1, 2, inf}: G (5 x 4), applied to the folded weights on the host (cdae.hip)
 static const double WN_G[5][4] = {{0.5, 0, 0, 0}, {-0.5, -0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6},
@@ -76,7 +78,7 @@ static const double WN_G[5][4] = {{0.5, 0, 0, 0}, {-0.5, -0.5, -0.5, -0.5}, {-1.
 
 // word offset of (component j, column col, input channel ci) inside a frequency tap's block of the transformed weights
 __host__ __device__ constexpr int wino_u_off(int j, int col, int ci) {
-    return ci < 32 ? (ci / 16) * WN_U16 + (j * WN_COLS + col) * 16 + ci % 16 : 2 * WN_U16 + (j * WN_COLS + col) * 20 + (ci - 32);
+    return ci < 48 ? (ci / 16) * WN_U16 + (j * WN_COLS + col) * 16 + ci % 16 : 3 * WN_U16 + (j * WN_COLS + col) * 4 + (ci - 48);
 }
 
 struct WinoTileDev {               // 64 bytes: one scalar load
@@ -170,39 +172,24 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     // 0 / 1 are 1020 float4 (thread tid takes float4 tid + 256 r, r < 4), chunk 2 is 1275 (r < 5); the spare threads load past
     // the descriptor (zeros) and write into pad words nobody reads: no predicate around any load or store.
     const __amdgpu_buffer_rsrc_t ru = buf_rsrc(a.upool + t.u_off, 4u * (unsigned)(kf * WN_UDF));
-    int b_lds[5];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int x = tid + 256 * r;                              // float4 index inside chunk 0 / 1: [component][col][k quad]
-        const int j = x / (4 * WN_COLS), rem = x - j * (4 * WN_COLS);
-        b_lds[r] = x < 5 * 4 * WN_COLS ? j * WN_BTILE + (rem >> 2) * WN_BLD + 4 * (rem & 3) : (x - 5 * 4 * WN_COLS) * WN_BLD + 20;
-    }
-    auto lds2 = [&](int r) {                                       // the same for chunk 2: [component][col][5 k quads]
-        const int x = tid + 256 * r;
-        const int j = x / (5 * WN_COLS), rem = x - j * (5 * WN_COLS), col = rem / 5;
-        return x < 5 * 5 * WN_COLS ? j * WN_BTILE + col * WN_BLD + 4 * (rem - 5 * col) : (x - 5 * 5 * WN_COLS) * WN_BLD + 20;
-    };
-    b_lds[4] = lds2(4);
+    // float4 x = tid + 256 r of a chunk's main part -> LDS row x >> 2, k quad x & 3 (the four spare slots of r = 3 -> pad words);
+    // float4 tid of the tail part (chunk 2 only) -> row tid, words 16..19
+    const int b_lds0 = (tid >> 2) * WN_BLD + 4 * (tid & 3);
     float4 gb[5];
     auto load_chunk = [&](int df, int s) {
         if (XSQ_WINO_ABL & 4) return;
         const int so = 4 * (df * WN_UDF + s * WN_U16);
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            if (r == 4 && s < 2) continue;
-            const int n4 = s < 2 ? WN_U16 / 4 : WN_U20 / 4;
-            const bool in = 256 * (r + 1) <= n4 || tid < n4 - 256 * r;
-            gb[r] = buf_ld4(ru, in ? 16u * (unsigned)(tid + 256 * r) : BUF_OOB, so);
-        }
+        for (int r = 0; r < 4; ++r) gb[r] = buf_ld4(ru, (r < 3 || tid < WN_U16 / 4 - 768) ? 16u * (unsigned)(tid + 256 * r) : BUF_OOB, so);
+        if (s == 2) gb[4] = buf_ld4(ru, tid < WN_UT / 4 ? 16u * (unsigned)tid : BUF_OOB, 4 * (df * WN_UDF + 3 * WN_U16));
     };
     auto store_chunk = [&](int s, int buf) {
         if (XSQ_WINO_ABL & 4) return;
         float* Bw = Bs + buf * 5 * WN_BTILE;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            if (r == 4 && s < 2) continue;
-            *reinterpret_cast<float4*>(&Bw[s < 2 ? b_lds[r] : (r < 4 ? lds2(r) : b_lds[4])]) = gb[r];
-        }
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(&Bw[(r < 3 || tid < WN_U16 / 4 - 768) ? b_lds0 + 64 * r * WN_BLD : (tid - (WN_U16 / 4 - 768)) * WN_BLD + 20]) = gb[r];
+        if (s == 2) *reinterpret_cast<float4*>(&Bw[tid < WN_UT / 4 ? tid * WN_BLD + 16 : 20]) = gb[4];
     };
 
     const int bf = q * WN_BLD + 4 * kq;                          // weight tile: column q of a 16-column block, k-quad kq
