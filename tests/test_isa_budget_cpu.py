@@ -55,3 +55,24 @@ def test_band_kernel_vector_instruction_budget(tmp_path):
         assert k_loop[0] == 2560 and k_loop[1] == 80, loops
         assert k_loop[2] <= budget, (loops, budget)
     assert "v_pk_" not in text          # no packed-fp32 ops (Makefile NOPK; -fno-slp-vectorize stands in for it here)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_committed_instruction_budget_is_the_one_of_the_sources(tmp_path):
+    """profiles/isa_budget.json (what bench.py's `roofline_issue` is computed from) against a fresh run of tools/isa_budget.py
+    over the current sources: the MFMA cycles and other-vector-instruction counts of every kernel's loops, exactly -- a kernel
+    edited without regenerating the budget fails here.  Also holds the Winograd kernels' per-tap budget (195 MFMAs = 6,240
+    cycles) and that they carry no scratch beyond a few spilled words outside the chunk loop."""
+    import json
+    out = tmp_path / "budget.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_budget.py"), str(out)], check=True, capture_output=True, timeout=1500)
+    new = json.load(open(out))["kernels"]
+    old = json.load(open(os.path.join(ROOT, "profiles", "isa_budget.json")))["kernels"]
+    assert sorted(new) == sorted(old)
+    for k in new:
+        a = [(l["mfma_cycles"], l["nmfma"], l["valu"]) for l in new[k]["loops"]]
+        b = [(l["mfma_cycles"], l["nmfma"], l["valu"]) for l in old[k]["loops"]]
+        assert a == b and new[k]["outside"] == old[k]["outside"], (k, a, b)
+    for k in ("cdae_wino<L2>", "cdae_wino<L3>"):
+        (lp,) = new[k]["loops"]
+        assert lp["mfma_cycles"] == 6240 and lp["nmfma"] == 195 and lp["valu"] < 420, lp

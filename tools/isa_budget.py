@@ -9,7 +9,7 @@ and ~4 cycles per other vector instruction, not their maximum).  So the fastest 
 MFMA kernel of the product library the MFMA cycles and other vector instructions (VALU, DPP, v_accvgpr moves; not LDS / memory
 / scalar) of (a) each loop that holds MFMAs, per trip, and (b) everything outside those loops (prologue + epilogue).
 
-    python3 tools/isa_budget.py            -> profiles/isa_budget.json   (committed; tests/test_isa_budget_cpu.py holds it to the sources)
+    python3 tools/isa_budget.py [out.json]   -> profiles/isa_budget.json   (committed; tests/test_isa_budget_cpu.py holds it to the sources)
 """
 import json
 import os
@@ -110,7 +110,7 @@ def main():
     missing = [k for k in WANT if k not in out["kernels"]]
     if missing:
         sys.exit("isa_budget: kernels not found in the assembly: %s" % missing)
-    path = os.path.join(ROOT, "profiles", "isa_budget.json")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_budget.json")
     json.dump(out, open(path, "w"), indent=1)
     for k, v in out["kernels"].items():
         print("%-28s outside: MFMA %5d cyc, vector %4d | " % (k, v["outside"]["mfma_cycles"], v["outside"]["valu"]) +
