@@ -197,6 +197,21 @@ def test_rccl_self_loop_moves_rows_bitwise():
     bad = np.asarray([(3, 0, 0, 4)], dtype=np.int64)
     with pytest.raises(_lib.XsqError, match="owner"):
         rx.exchange(src, bad, dst=dst, self_loop=True)
+    # spans are checked against the buffers before anything is queued: a row that leaves either one is refused
+    for row, what in (((0, 3_000_000 - 3, 0, 4), "source span"), ((0, 0, 3_000_000 - 3, 4), "destination span"), ((0, -1, 0, 4), "source span")):
+        with pytest.raises(_lib.XsqError, match=what):
+            rx.exchange(src, np.asarray([(0, 0, 16, 8), row], dtype=np.int64), dst=dst, self_loop=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, want)                                   # ... and nothing of the refused tables was moved
+    # groups closed every few rows (XSQ_EXCHANGE_GROUP_ROWS is read per call): same bytes
+    os.environ["XSQ_EXCHANGE_GROUP_ROWS"] = "2"
+    try:
+        dst2 = torch.full((3_000_000,), -7.0, device=dev)
+        rx.exchange(src, rows, dst=dst2, self_loop=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dst2, want)
+    finally:
+        del os.environ["XSQ_EXCHANGE_GROUP_ROWS"]
     rx.close()
 
 
