@@ -712,13 +712,10 @@ static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.u_off = d.u2[tgt]; }
             else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.u_off = d.u3[tgt]; }
             const int perb = e.Fo * P;
-            // sub-tiles per workgroup: the shorter a sub-tile's work (one frequency tap), the more of them share one prologue
-            static const int nsub_env = getenv("XSQ_WINO_NSUB") ? atoi(getenv("XSQ_WINO_NSUB")) : 0;
-            const int nsub = !XSQ_WINO_MULTI ? 1 : nsub_env > 0 ? nsub_env : (d.kf == 1 ? 4 : d.kf == 3 ? 2 : 1);
-            e.pad = 0;
+            e.pad0 = e.pad1 = 0;
             for (int bi = 0; bi < Bn; ++bi)
-                for (int Q = 0; Q < perb; Q += WN_PAIRS * nsub) {
-                    e.Q0 = Q; e.b = bi; e.nsub = std::min(nsub, (perb - Q + WN_PAIRS - 1) / WN_PAIRS);
+                for (int Q = 0; Q < perb; Q += WN_PAIRS) {
+                    e.Q0 = Q; e.b = bi;
                     t.push_back(e);
                 }
         }

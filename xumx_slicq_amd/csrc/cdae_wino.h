@@ -30,13 +30,9 @@
 // the vector ALU from the same transformed values (as in the slab kernels).  A frequency tap is three chunks of 16, 16 and
 // 16 + 4 channels; the transformed weights of a chunk -- five components x 51 columns x 16 (20) k, 16 (20) KB -- stream
 // through two LDS buffers: requested at the start of the chunk before, written at its end, ONE barrier per chunk; the next
-// tap's slab is requested during the tap's last chunk and written behind its barrier.  A workgroup runs `nsub` consecutive
-// 64-pair sub-tiles of its (block, target, batch item) -- four where there is one frequency tap, two for three -- and
-// requests the next sub-tile's slab and first weights the same way, during the last chunk of the one before: only the first
-// sub-tile pays the tile entry, the slab's and the weights' round trips in the open (ablation, r08g: the slab loads were 14 %
-// of the launch, the weight stream 15 %, with one sub-tile per workgroup).  (The first form -- a ring of five per-component tiles, a barrier per
-// component step, three workgroups per CU at 168 registers -- spilled its staging registers inside the loop and ran 40 %
-// SLOWER than the direct kernels: profiles/r08_ab_runs.txt, r08b.)
+// tap's slab is requested during the tap's last chunk and written behind its barrier.  (Several consecutive sub-tiles per
+// workgroup, the next one's slab and weights requested during the last chunk of the one before, cost the chunk loop its
+// registers and measured SLOWER -- profiles/r08_ab_runs.txt, r08h / r08i -- and so did a loader-wave form, r08n / r08o: removed.)
 //   LDS: 30.0 KB planes + 2 x 25.0 KB weight tiles = 79.9 KB -> two 256-thread workgroups per CU, 256 registers each.
 #pragma once
 #include "cdae_api.h"
@@ -47,9 +43,6 @@
 #endif
 #ifndef XSQ_WINO_RAW_AHEAD
 #define XSQ_WINO_RAW_AHEAD 1   // 1: the pair's raw positions of chunk s + 1 are read while chunk s computes (20 more registers)
-#endif
-#ifndef XSQ_WINO_MULTI
-#define XSQ_WINO_MULTI 0       // 1: a workgroup runs WinoTileDev.nsub sub-tiles one after the other (measured slower: r08h / r08i)
 #endif
 #ifndef XSQ_WINO_ABL
 #define XSQ_WINO_ABL 0      // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no slab loads, 16 no epilogue stores, 32 no input transform
@@ -85,7 +78,7 @@ struct WinoTileDev {               // 64 bytes: one scalar load
     int Q0, kf, Fo, Fi;            // first pair of the tile (f * P + q inside batch item b)
     int64_t in_off, out_off;       // input / output activations of the (block, target), relative to the layer's arenas
     int64_t shift_off, u_off;      // shift vector inside the pool / transformed weights inside the Winograd pool
-    int b, nsub, pad, P;           // batch item, 64-pair sub-tiles the workgroup runs one after the other, -, pairs per (b, f) row = (To + 1) / 2
+    int b, pad0, pad1, P;          // batch item, -, -, pairs per (b, f) row = (To + 1) / 2
 };
 static_assert(sizeof(WinoTileDev) == 64, "WinoTileDev is meant to be one 64-byte scalar load");
 
@@ -113,7 +106,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     const int q = lane & 15, kq = lane >> 4;
     const WinoTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.Fo), "s"(t.Fi), "s"(t.in_off), "s"(t.out_off), "s"(t.shift_off), "s"(t.u_off),
-                 "s"(t.b), "s"(t.nsub), "s"(t.P));
+                 "s"(t.b), "s"(t.P));
     const int kf = t.kf, Fo = t.Fo, Fi = t.Fi, P = t.P, b = t.b;
     const int To = TRANSPOSED ? a.T1 : a.T2, Ti = TRANSPOSED ? a.T2 : a.T1;
     const float* in = (TRANSPOSED ? a.act2 : a.act1) + t.in_off;
@@ -121,13 +114,13 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     // ---- slab staging: lane = (position lane p0 = tid / 13 of 19, channel quad c4 = tid % 13), load r -> slab position p0 + 19 r.
     // Segment i covers slab positions [A_i, A_i + 2 np_i + 3): local position j' is input position 2 qs_i - PAD + j' of input
     // row f0 + i -+ df and lands in plane j' & 1, row (j' >> 1) + (rows of the segments before).  What does not depend on the
-    // frequency tap -- LDS address, byte offset at df = 0 (or BUF_OOB), segment bit -- is formed once per sub-tile.
+    // frequency tap -- LDS address, byte offset at df = 0 (or BUF_OOB), segment bit -- is formed once per tile.
     constexpr int SPL = 256 / (CS / 4);                          // position lanes (19)
     constexpr int NLD = (WN_POS + SPL - 1) / SPL;                // loads per lane and slab (8)
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(in, 0x40000000u);    // (a (block, target)'s input is < 2^30 bytes: cdae_launch_layer)
     unsigned s_vo[NLD], s_seg = 0;
     unsigned s_lds[NLD / 2];          // two 16-bit float4 indices per word (0xffff: the position does not exist)
-    int s_f0 = 0;                     // (f0 of the sub-tile the staging tables describe)
+    int s_f0 = 0;
     const int s_p0 = tid / (CS / 4), s_c4 = tid - s_p0 * (CS / 4);
     auto setup_staging = [&](int f0, int q0, int npairs, int n0) {
         const bool s_on = tid < SPL * (CS / 4);
@@ -197,7 +190,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     // v_fmac_f32_dpp of a column take it with row_newbcast:i (lane i of every row of 16 to the whole row): a 4-byte LDS read
     // (2 cycles) and one register per column where the 16-byte broadcast read took 4 cycles and four registers
     const int bv = 48 * WN_BLD + 4 * kq + (q & 3);
-    const int pl = wave * 16 + q;                                // this lane's pair of the sub-tile
+    const int pl = wave * 16 + q;                                // this lane's pair of the tile
 
     f32x4 acc[5][3];
     float accv[5][NV];
@@ -228,11 +221,10 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
         }
     };
 
-    // ---- prologue: the first sub-tile's slab of tap 0 and chunk 0 in LDS
-    int Qs = t.Q0;                                               // first pair of the current sub-tile
-    int f0 = Qs / P, q0 = Qs - f0 * P;
-    int npairs = min(WN_PAIRS, Fo * P - Qs);                     // pairs of the sub-tile that exist
-    int n0 = min(npairs, P - q0);                                // ... in segment 0 (row f0); the rest in segment 1 (row f0 + 1)
+    // ---- prologue: the slab of tap 0 and chunk 0 in LDS
+    const int f0 = t.Q0 / P, q0 = t.Q0 - f0 * P;
+    const int npairs = min(WN_PAIRS, Fo * P - t.Q0);             // pairs of the tile that exist
+    const int n0 = min(npairs, P - q0);                          // ... in segment 0 (row f0); the rest in segment 1 (row f0 + 1)
     int cnt = 0;                                                 // chunks issued so far: chunk c lives in buffer c & 1
     load_chunk(0, 0);
     setup_staging(f0, q0, npairs, n0);
@@ -241,8 +233,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     store_chunk(0, 0);
     __syncthreads();
 
-    constexpr bool MULTI = XSQ_WINO_MULTI != 0;
-    for (int sub = 0; sub < (MULTI ? t.nsub : 1); ++sub) {
+    {
         const int myseg = pl >= n0 ? 1 : 0;
         const int eb = (pl + 2 * myseg) * WN_SLD + 4 * kq;       // even plane: rows er, er + 1, er + 2 = positions 0, 2, 4 of the pair
         const int ob = PLANE_O + (pl + myseg) * WN_SLD + 4 * kq; // odd plane: rows or, or + 1 = positions 1, 3
@@ -255,27 +246,16 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
             dn[4] = *reinterpret_cast<const float4*>(&slab[eb + 2 * WN_SLD + 16 * s]);
         };
         clear_acc();
-        // the sub-tile behind this one (same (block, target, batch item), the next 64 pairs)
-        const int Qn = Qs + WN_PAIRS;
-        const bool next_sub = MULTI && sub + 1 < t.nsub && Qn < Fo * P;
-        int nf0 = f0, nq0 = q0 + WN_PAIRS;
-        if (nq0 >= P) { nq0 -= P; nf0 += 1; }
-        const int nnp = min(WN_PAIRS, Fo * P - Qn), nn0 = min(nnp, P - nq0);
-
         for (int df = 0; df < kf; ++df) {
             const bool more = df + 1 < kf;
-            // (the staging tables are free once the sub-tile's last slab is in LDS: the next sub-tile's are formed here, outside
-            //  the chunk loop, where few registers are live)
-            if (!more && next_sub) setup_staging(nf0, nq0, nnp, nn0);
             if (XSQ_WINO_RAW_AHEAD) read_raw(0);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 // the next chunk's weights are requested here and written into the other buffer at the end of this chunk; the next
-                // tap's (or the next sub-tile's) slab is requested in the tap's last chunk and written behind its barrier
+                // tap's slab is requested in the tap's last chunk and written behind its barrier
                 const int cur = cnt & 1;
                 if (s < 2) load_chunk(df, s + 1);
                 else if (more) { load_chunk(df + 1, 0); load_slab(df + 1); }
-                else if (next_sub) load_chunk(0, 0);
                 const float* Bc = Bs + cur * 5 * WN_BTILE;
                 if (!XSQ_WINO_RAW_AHEAD) read_raw(s);
                 Frag fr[2];
@@ -325,7 +305,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                 }
                 // other buffer: last read in the chunk before, every wave is past that chunk's barrier
                 if (s < 2) store_chunk(s + 1, cur ^ 1);
-                else if (more || next_sub) store_chunk(0, cur ^ 1);
+                else if (more) store_chunk(0, cur ^ 1);
                 cnt += 1;
                 __syncthreads();
             }
@@ -335,10 +315,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
             }
         }
 
-        // the next sub-tile's slab is requested HERE, behind the last barrier: its round trip runs beside the epilogue below (held
-        // across the last chunk as well, its 32 registers came out of the chunk loop as spills)
-        if (next_sub) load_slab(0);
-        // ---- epilogue of the sub-tile: output transform, shift + ReLU, through a per-wave LDS image (the planes are free: the
+        // ---- epilogue: output transform, shift + ReLU, through a per-wave LDS image (the planes are free: the
         // loop ended on a barrier), out as 16-byte stores.  Image row 2 p + r = output r of the wave's pair p.
         float* img = slab + wave * 32 * CS;
         const float* shift = a.pool + t.shift_off;
@@ -380,7 +357,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // image row -> output row: pair pl = 16 wave + (row >> 1) of the sub-tile, segment by n0, t = 2 q + (row & 1); rows of pairs
+        // image row -> output row: pair pl = 16 wave + (row >> 1) of the tile, segment by n0, t = 2 q + (row & 1); rows of pairs
         // that do not exist and the phantom second row of an odd To are switched out of the descriptor's range
         float* out = (TRANSPOSED ? a.act3 : a.act2) + t.out_off;
         const __amdgpu_buffer_rsrc_t ro = buf_rsrc(out, 0x40000000u);
@@ -397,12 +374,6 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
             const float4 val = *reinterpret_cast<const float4*>(img + 4 * min(slot, 32 * (CS / 4) - 1));
             buf_st4(val, ro, (ok && !((XSQ_WINO_ABL & 16) && val.x != 1.2345e-30f)) ? vo : BUF_OOB, 0);
         }
-        if (!next_sub) break;
-        // the next sub-tile: its slab (requested in the last chunk) goes into the planes once every wave has read its image
-        __syncthreads();
-        store_slab();
-        __syncthreads();
-        Qs = Qn; f0 = nf0; q0 = nq0; npairs = nnp; n0 = nn0;
     }
 }
 
