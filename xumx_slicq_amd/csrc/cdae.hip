@@ -177,7 +177,11 @@ __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int r
 }
 
 // ---- layer 1 -----------------------------------------------------------------------------
-struct CdaeL1Op {
+// CAUSAL (the realtime model's first layer, model.py:274-290) is a compile-time fact of the operator: as a run-time flag the
+// K loop carried the predicated 4-byte path of the causal layer beside the buffer path (a uniform branch per load and
+// twice the code; tools/isa_budget.py counted both).
+template <bool CAUSAL>
+struct CdaeL1OpT {
     typedef CdaeGroup Group;
     typedef RowFT RowA;
     static constexpr bool STAMPED = XSQ_GEMM_STAMP == 2;      // (diagnostic builds with XSQ_GEMM_STAMP=2: tools/gemm_phases.py)
@@ -201,8 +205,8 @@ struct CdaeL1Op {
         int b, f, t;
         split_row(m, g.Fo, g.To, b, f, t);
         r.f = f;
-        r.t = t * g.hop - ((a.causal && !a.xin8) ? g.T - 1 : 0);   // first input sample of the window
-        r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
+        r.t = t * g.hop - ((CAUSAL && !a.xin8) ? g.T - 1 : 0);   // first input sample of the window
+        if constexpr (CAUSAL) r.p = g.in + ((int64_t)b * 2 * g.F + f) * g.Ti + r.t;
         r.vo = 4u * (unsigned)((b * 2 * g.F + f) * g.Ti + r.t);    // (non-causal: r.t >= 0; the group's input is < 2^30 bytes, launch check)
         return r;
     }
@@ -231,7 +235,7 @@ struct CdaeL1Op {
         return load_at(g, r, k, (ci * g.F + df) * g.Ti, dt);
     }
     __device__ float4 load_at(const Group& g, const RowA& r, int k, int off, int dt) const {
-        if (!a.causal) {
+        if constexpr (!CAUSAL) {
             // one 16-byte buffer load (dword aligned is enough): row offset + cursor, rows past M and k past K switched
             // out of range -- no pointer sums, zero fills or exec-masked branches in the K loop
             const unsigned vo = r.vo + 4u * (unsigned)(off + dt);
@@ -255,6 +259,8 @@ struct CdaeL1Op {
         relu_shift_epilogue_xw(g, rowb, lane, a0, a16, av, NV, img);
     }
 };
+struct CdaeL1Op : CdaeL1OpT<false> { __host__ __device__ CdaeL1Op(const CdaeArgs& a_) { a = a_; } };
+struct CdaeL1CausalOp : CdaeL1OpT<true> { __host__ __device__ CdaeL1CausalOp(const CdaeArgs& a_) { a = a_; } };
 
 // ---- layer 2 -----------------------------------------------------------------------------
 struct CdaeL2Op {
@@ -1029,7 +1035,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         else hipLaunchKernelGGL((grouped_gemm_bf3_kernel<OP, MT_, 1>), dim3(tt.ntiles), dim3(256), 0, stream, OP{a}, tt.d_tiles, tt.ntiles); \
     } while (0)
     switch (layer) {
-        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); XSQ_LAUNCH(CdaeL1Op, 1, 1); } break;
+        case 1: { XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream); if (a.causal) XSQ_LAUNCH(CdaeL1CausalOp, 1, 1); else XSQ_LAUNCH(CdaeL1Op, 1, 1); } break;
         case 2: { XSQ_PROF(prof_name ? prof_name : "cdae_l2_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL2Op, 2, 0); else XSQ_LAUNCH(CdaeL2Op, 1, 1); } break;
         case 3: { XSQ_PROF(prof_name ? prof_name : "cdae_l3_gemm", stream); if (mt23 == 2) XSQ_LAUNCH(CdaeL3Op, 2, 0); else XSQ_LAUNCH(CdaeL3Op, 1, 1); } break;
         default: { XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
