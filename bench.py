@@ -819,7 +819,7 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0, precision="fp32"):
     return {"what": "BASELINE configs[4]: training.py step, CDAE fwd+bwd with the X-UMX combined loss (ComplexMSE 14 "
                     "combinations + MaskSum), differentiable Wiener-EM, AdamW; batch = 16 chunks of 2 s (S = 11), offline "
                     "model, %s; incl. the five forward sliCQTs (mix + 4 targets) of the batch"
-                    % ("fp32" if precision == "fp32" else "forward / data-gradient contractions on bf16-rounded operands (one v_mfma_f32_32x32x16_bf16 per "
+                    % ("fp32" if precision == "fp32" else "forward / data-gradient / weight-gradient contractions on bf16-rounded operands (one v_mfma_f32_32x32x16_bf16 per "
                        "product, fp32 accumulate: the arithmetic of the reference's bf16 autocast convolutions, training.py:473-476), everything else fp32"),
             "ms_per_step": round(dt * 1e3, 3), "chunks_per_s": round(batch / dt, 1), "steps_per_s": round(1.0 / dt, 2),
             "ms_per_step_pipelined": round(dtp * 1e3, 3),
@@ -830,8 +830,8 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0, precision="fp32"):
                           "(3 x %.1f GFLOP); BatchNorm, loss, Wiener-EM, sliCQTs and AdamW are not counted" % (fwd / 1e9),
             "achieved_tflops": round(flops / dt / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
             "frac": round(flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "frac_note": "of the fp32 MFMA peak (the weight gradients and, in the fp32 arm, everything run there; the bf16 arm's forward / data-gradient "
-                         "contractions run on the bf16 pipe, 16x that peak)",
+            "frac_note": "of the fp32 MFMA peak (the fp32 arm runs there; the bf16 arm's contractions run on the bf16 pipe, 16x that peak: "
+                         "its step is bound by operand delivery, BatchNorm, loss and transforms)",
             "parity": ("tests/test_training.py::test_hip_training_step_at_config_size_matches_the_oracle (this batch, fp32 and bf16x6)" if precision == "fp32"
                        else "tests/test_training.py::test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread (reference autograd under bf16 autocast)"),
             "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],

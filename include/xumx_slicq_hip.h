@@ -335,11 +335,12 @@ int64_t xsq_train_step_count(xsq_train* t, int64_t set);
 /* Arithmetic of the GEMM-shaped forward / data-gradient kernels of the step: 0 fp32 MFMA (default), 2 bf16x6 (see
  * xsq_model_set_precision), 1 = "bf16": BASELINE configs[4] as written -- the reference runs forward + loss under
  * torch.autocast(dtype=bfloat16) (training.py:66-108,473-476), i.e. its convolutions contract bf16-rounded operands.  Mode 1
- * rounds both operands of every forward and data-gradient contraction to bf16 (round to nearest even) and accumulates one
- * v_mfma_f32_32x32x16_bf16 product per pair in fp32; activations between the layers, BatchNorm, the Wiener-EM, the loss, the
- * weight gradients (fp32 operands), the master weights and AdamW stay fp32 -- fewer rounding points than autocast, which
- * also keeps BatchNorm / ReLU / sigmoid outputs in bf16 (tests/golden/training_step_bf16.npz holds the reference's own
- * fp32-vs-autocast spread; the arm is held inside it).                                                              */
+ * rounds both operands of every forward, data-gradient and weight-gradient contraction to bf16 (round to nearest even) and
+ * accumulates one v_mfma_f32_32x32x16_bf16 product per pair in fp32; activations between the layers, BatchNorm, the
+ * Wiener-EM, the loss, the master weights and AdamW stay fp32 -- fewer rounding points than autocast, which also keeps
+ * BatchNorm / ReLU / sigmoid outputs in bf16 (tests/golden/training_step_bf16.npz holds the reference's own
+ * fp32-vs-autocast spread; the arm is held inside it).  XSQ_TRAIN_WGRAD_FP32=1 keeps the weight gradients on fp32
+ * operands (an A/B arm).                                                                                             */
 int xsq_train_set_precision(xsq_train* t, int mode);
 
 /* ---- the whole call: Separator.forward (separator.py:133-232) behind ONE entry point ----------------------------

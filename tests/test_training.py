@@ -352,7 +352,7 @@ def test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread(or
     (oracle/make_golden_train_bf16.py, the reference's own autograd) holds that step on fixture A's batch next to the same
     step in fp32.  The reference's bf16 step is NOT close to its fp32 step -- loss terms 2.4e-4 apart, per-tensor gradients
     7.6 % apart in the median, ~100 % at the 90th percentile -- so the tolerances of the bf16 arm (Trainer(precision=
-    "bf16"): forward / data-gradient operands rounded to bf16, one MFMA per product, fp32 everything else) come from that
+    "bf16"): forward / data-gradient / weight-gradient operands rounded to bf16, one MFMA per product, fp32 everything else) come from that
     spread, not from a guess:
       * both loss terms within 1e-3 of the autocast reference's and of the fp32 reference's (4x the reference's own gap);
       * over all trainable tensors, the arm's relative distance to the fp32 gradients (the oracle's autograd, pinned to the

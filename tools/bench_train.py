@@ -15,7 +15,7 @@ ap.add_argument("--seq-dur", type=float, default=2.0)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--realtime", action="store_true")
-ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6"])
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x6"])
 ap.add_argument("--no-profile", action="store_true", help="no per-kernel events: the clean wall time")
 ap.add_argument("--pipelined", action="store_true", help="look at a step's loss after the next step has been issued")
 a = ap.parse_args()

@@ -978,9 +978,13 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
         hipError_t e = hipEventRecord(Tr->ev_fork[i], stream);
         return e != hipSuccess ? e : hipStreamWaitEvent(Tr->side, Tr->ev_fork[i], 0);
     };
+    // bf16 arm: the weight gradients on bf16 operands as well (XSQ_TRAIN_WGRAD_FP32=1: keep them on the fp32 pipe, an A/B arm)
+    static const bool wgrad_fp32 = getenv("XSQ_TRAIN_WGRAD_FP32") && atoi(getenv("XSQ_TRAIN_WGRAD_FP32")) != 0;
+    const bool bf16w = Mo->precision == 3 && !wgrad_fp32;
     XSQ_HIP(fork(0));
     { XSQ_PROF("train_l4_wgrad", ws_);
-      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      else hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
     CdaeArgs bw{Mo->d_blocks, Tr->d_pool_bwd, xin, g1, g2, g3, X, Y, nullptr, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
     bw.xin8 = gM; bw.act1 = g3;                                                    // g_a3 <- g_p4   (layer-1 operator)
@@ -991,7 +995,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     XSQ_HIP(fork(1));
     { XSQ_PROF("train_l3_wgrad", ws_);
-      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      else hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
     if ((rc = cdae_launch_layer(Mo, 2, bw, stream, "train_l3_dgrad_gemm"))) return rc;
@@ -1000,7 +1005,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq2), dim3(256), 0, stream, (const float4*)z2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     XSQ_HIP(fork(2));
     { XSQ_PROF("train_l2_wgrad", ws_);
-      hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      else hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
     if ((rc = cdae_launch_layer(Mo, 3, bw, stream, "train_l2_dgrad_gemm"))) return rc;
@@ -1009,7 +1015,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, grid1(nq1), dim3(256), 0, stream, (const float4*)z1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     XSQ_HIP(fork(3));
     { XSQ_PROF("train_l1_wgrad", ws_);
-      hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      else hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
     bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);
     if ((rc = cdae_launch_layer(Mo, 4, bw, stream, "train_l1_dgrad_gemm"))) return rc;   // gY is free by now

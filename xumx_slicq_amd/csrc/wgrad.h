@@ -15,15 +15,22 @@
 // k_wgrad_reduce adds the chunks of a group in order (deterministic) while scattering into the
 // canonical (state_dict) gradient layout.  4 waves: wave w owns column blocks w*NBW .. w*NBW+NBW-1
 // (32 columns each) x both 32-row blocks.
+//
+// BF16 = true (the "bf16" training arm, xsq_train_set_precision mode 1: torch.autocast runs the convolutions' weight
+// gradients on bf16 operands as well, training.py:473-476): the same staging; a lane reads its eight k of a K-step
+// (k = 8 (l / 32) + j), rounds pairs to bf16 (v_cvt_pk_bf16_f32, nearest even) and issues ONE v_mfma_f32_32x32x16_bf16
+// per (row block, column block) and K-step where the fp32 form issues eight v_mfma_f32_32x32x2_f32 -- 1/16 of the
+// matrix-pipe cycles; the loop is then bound by its operand staging.
 #pragma once
 #include "gemm_tile.h"
+#include "gemm_tile_bf6.h"
 
 namespace xsq {
 
 struct WgTile { int group, ntile, k0, k1; };
 struct WgGroupInfo { int tile_base, nch; };
 
-template <class Op>
+template <class Op, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(Op op, const WgTile* __restrict__ tiles, float* __restrict__ partial) {
     constexpr int NTL = Op::NTL, NB = NTL / 32, NBW = (NB + 3) / 4, NQ = (NTL / 4 + 15) / 16;
     const WgTile t = tiles[blockIdx.x];
@@ -70,17 +77,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(Op op, const WgTile* __restr
     for (int kb = t.k0; kb < t.k1; kb += 16) {
         const bool more = kb + 16 < t.k1;
         if (more) gload(kb + 16);
+        if constexpr (BF16) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            auto frag_a = [&](int m) {
+                float v[8];
 #pragma unroll
-        for (int kp = 0; kp < 8; ++kp) {
-            const int k = 2 * kp + lk;
-            const float a0 = As[buf][k][l32], a1 = As[buf][k][32 + l32];
+                for (int j = 0; j < 8; ++j) v[j] = As[buf][8 * lk + j][m];
+                const u32x4 w = {bf16_rne2(v[0], v[1]), bf16_rne2(v[2], v[3]), bf16_rne2(v[4], v[5]), bf16_rne2(v[6], v[7])};
+                return __builtin_bit_cast(bf16x8_t, w);
+            };
+            auto frag_b = [&](int n) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = Bs[buf][8 * lk + j][n];
+                const u32x4 w = {bf16_rne2(v[0], v[1]), bf16_rne2(v[2], v[3]), bf16_rne2(v[4], v[5]), bf16_rne2(v[6], v[7])};
+                return __builtin_bit_cast(bf16x8_t, w);
+            };
+            const bf16x8_t a0 = frag_a(l32), a1 = frag_a(32 + l32);
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
                 const int nb = wave * NBW + j;
                 if (nb < NB) {          // wave-uniform
-                    const float b = Bs[buf][k][nb * 32 + l32];
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
+                    const bf16x8_t b = frag_b(nb * 32 + l32);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                const int k = 2 * kp + lk;
+                const float a0 = As[buf][k][l32], a1 = As[buf][k][32 + l32];
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const int nb = wave * NBW + j;
+                    if (nb < NB) {          // wave-uniform
+                        const float b = Bs[buf][k][nb * 32 + l32];
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
+                    }
                 }
             }
         }
