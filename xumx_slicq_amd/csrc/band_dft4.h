@@ -91,7 +91,11 @@ __device__ unsigned long long g_d4_stamps[D4_STAMP_TILES * 8];
 #endif
 
 constexpr int D4_LD = 20, D4_MPAD = 80;     // bands up to Lg = 320 (the plan builder routes longer ones to the dense engine)
-constexpr int D4H_ROWS = 32;
+#ifndef XSQ_D4_ROWS
+#define XSQ_D4_ROWS 32          // rows of a tile: 32 (4 waves, three workgroups per CU) or 64 (8 waves, two workgroups per CU: an A/B arm)
+#endif
+constexpr int D4H_ROWS = XSQ_D4_ROWS, D4H_NT = 8 * D4H_ROWS;
+static_assert(D4H_ROWS == 32 || D4H_ROWS == 64, "tile height");
 
 // Vector issue.  On gfx950 an fp32 MFMA runs at exactly the rate of the SIMD's packed-fp32 vector ALU, and measured it does
 // not overlap with the vector instructions of the SIMD's other waves: a K-step of this kernel takes the SUM of its MFMA
@@ -106,10 +110,10 @@ constexpr int D4H_ROWS = 32;
 // NCBMAX = most 16-column blocks a band of this instantiation has.  10 (Lg <= 320): 49 KB of LDS and 80 accumulator
 // registers, three workgroups per CU -- the product configuration.  5 (Lg <= 160): 35 KB and 40 accumulator registers
 // -> FOUR workgroups per CU, an A/B arm (XSQ_D4_SPLIT=1) that measured no faster.
-template <int NCBMAX> struct D4Cfg { static constexpr int waves = NCBMAX > 5 ? 3 : 4, mpad = NCBMAX > 5 ? D4_MPAD : 40; };
+template <int NCBMAX> struct D4Cfg { static constexpr int waves = D4H_ROWS == 64 ? 4 : (NCBMAX > 5 ? 3 : 4), mpad = NCBMAX > 5 ? D4_MPAD : 40; };
 // MASKED (synthesis only): the coefficients are mask * mix, formed on the way in (Band4Args.mask).
 template <bool FWD, int NCBMAX = 10, bool MASKED = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D4Cfg<NCBMAX>::waves, D4Cfg<NCBMAX>::waves)))
+__global__ __launch_bounds__(D4H_NT) __attribute__((amdgpu_waves_per_eu(D4Cfg<NCBMAX>::waves, D4Cfg<NCBMAX>::waves)))
 void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
     static_assert(!(FWD && MASKED), "the mask product belongs to the synthesis");
     constexpr int D4H_NCB = NCBMAX, MPADL = D4Cfg<NCBMAX>::mpad;
@@ -159,9 +163,9 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     // The pool holds round_up(2m, 64) rows (zero past 2m), so every item of a requested group lies inside it.
     const __amdgpu_buffer_rsrc_t rb = buf_rsrc(a.pool + bd.d_off, 4u * (unsigned)(((K + 63) & ~63) * bd.ldd));
     const unsigned vb = 4u * (unsigned)((tid >> 2) * bd.ldd + 4 * (tid & 3));
-    const int sb64 = 4 * 64 * bd.ldd;            // 64 rows further down
+    const int sb64 = 4 * (D4H_NT / 4) * bd.ldd;  // D4H_NT / 4 rows further down
     const int nb4 = 64 * ncb;
-    constexpr int NBU = (64 * D4H_NCB + 255) / 256;     // float4 items of the matrix slab per thread (3 / 2)
+    constexpr int NBU = (64 * D4H_NCB + D4H_NT - 1) / D4H_NT;     // float4 items of the matrix slab per thread (3 / 2)
 
     float2 raw[4];         // quarter a, complex t1 (FWD: spectrum value of the quarter)
     float aux[4];          // INV: mask of quarter a
@@ -173,7 +177,7 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
     auto load_set = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < NBU; ++u)       // uniform test
-            if (256 * u < nb4) gb[u] = buf_ld4(rb, vb, u * sb64 + 4 * k0);
+            if (D4H_NT * u < nb4) gb[u] = buf_ld4(rb, vb, u * sb64 + 4 * k0);
         if (!FWD) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -239,7 +243,7 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
         float* Bw = Bs0 + buf * BBUF + b_st;
 #pragma unroll
         for (int u = 0; u < NBU; ++u)
-            if (tid + 256 * u < nb4) *reinterpret_cast<float4*>(Bw + 64 * u * D4_LD) = gb[u];
+            if (tid + D4H_NT * u < nb4) *reinterpret_cast<float4*>(Bw + (D4H_NT / 4) * u * D4_LD) = gb[u];
     };
 
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -250,7 +254,7 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
         for (int cb = 0; cb < D4H_NCB; ++cb) acc[e][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int l16 = lane & 15, kq = lane >> 4;
-    const int rh = wave & 1, rp = wave >> 1;
+    const int rh = wave & (D4H_ROWS / 16 - 1), rp = wave / (D4H_ROWS / 16);      // row block of 16, residue pair
     load_set(0);
     float w_mu = 0.f, w_sc = 1.f;                // whitening constants of this tile's band (uniform)
     if (FWD && a.xin) { w_mu = a.mean[bd.jband]; w_sc = a.scale[bd.jband]; }
@@ -258,10 +262,10 @@ void band_dft4_full_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int 
         const float2* tw = reinterpret_cast<const float2*>(a.pool + bd.tw_off);
         const float* win = a.pool + bd.win_off;
         const float2 tv = tid < 3 * mpad ? tw[tid] : make_float2(0.f, 0.f);
-        const float wv0 = tid < Lg ? win[tid] : 0.f, wv1 = tid + 256 < Lg ? win[tid + 256] : 0.f;
+        const float wv0 = tid < Lg ? win[tid] : 0.f, wv1 = (D4H_NT == 256 && tid + 256 < Lg) ? win[tid + 256] : 0.f;
         if (tid < 3 * mpad) twl[tid] = tv;
-        winl[tid] = wv0;                          // zero past Lg: the FWD staging reads up to 4 mpad - 1
-        if (tid + 256 < 4 * MPADL) winl[tid + 256] = wv1;
+        if (tid < 4 * MPADL) winl[tid] = wv0;     // zero past Lg: the FWD staging reads up to 4 mpad - 1
+        if (D4H_NT == 256 && tid + 256 < 4 * MPADL) winl[tid + 256] = wv1;
     }
     __syncthreads();             // tables complete (store_set reads the twiddles)
     store_set(0, 0);

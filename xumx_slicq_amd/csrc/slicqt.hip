@@ -333,9 +333,9 @@ static int launch_dft4(xsq_plan* P, const Band4Args& a4, int rows, int share, hi
         constexpr int N = decltype(ncbmax)::value;
         if (!t.ntiles) return;
         if constexpr (!FWD) {
-            if (masked) { hipLaunchKernelGGL((band_dft4_full_kernel<false, N, true>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles); return; }
+            if (masked) { hipLaunchKernelGGL((band_dft4_full_kernel<false, N, true>), dim3(t.ntiles), dim3(D4H_NT), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles); return; }
         }
-        hipLaunchKernelGGL((band_dft4_full_kernel<FWD, N, false>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+        hipLaunchKernelGGL((band_dft4_full_kernel<FWD, N, false>), dim3(t.ntiles), dim3(D4H_NT), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
     };
     if (!split) {
         if ((rc = get_dft4_full_tiles(P, rows, &t, share, 0))) return rc;
