@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0>
+template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0>
 __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -38,12 +38,19 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
     const i32x4 rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa >> 32) & 0xFFFF),
                       __builtin_amdgcn_readfirstlane(65536), __builtin_amdgcn_readfirstlane(0x00020000)};
     const unsigned goff = 16u * (unsigned)tid;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 65536, 0x00020000);
     f32x4 lv[NL > 0 ? NL : 1], gv[NG > 0 ? NG : 1];
     const f32x4 wv = {a, b, a, b};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 wv2 = {a, b};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(gv[i]) : "v"(goff), "s"(rs), "n"(0) : "memory");
+        // ND x buffer_load_dwordx4 ... lds (LDS-DMA: lane l's 16 bytes land at base + 16 l; no register, no ds_write)
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, lds + 8192 + 1024 * (threadIdx.x >> 6) + 256 * (i & 3) * 4, 16, (int)goff, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NL; ++i)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lv[i]) : "v"(laddr), "n"((i & 3) * 1024) : "memory");
@@ -64,8 +71,11 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(laddr), "v"(wv), "n"(16384 + (i & 3) * 1024) : "memory");
-        if (NG > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (NL > 0 || NW > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NW2; ++i)         // NW2 x ds_write_b64 (8 bytes per lane)
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(laddr), "v"(wv2), "n"(24576 + (i & 3) * 1024) : "memory");
+        if (NG > 0 || ND > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NL > 0 || NW > 0 || NW2 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (BAR) asm volatile("s_barrier" ::: "memory");
     }
     float s = 0.f;
@@ -82,13 +92,13 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
 
 static float* d_sink; static float* d_src; static int g_cus = 256;
 
-template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0>
+template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0>
 static void run(const char* what) {
     printf("%-44s NM %3d NV %3d NL %2d NW %2d NG %2d BAR %d | 32 NM + 4 NV %5d |", what, NM, NV, NL, NW, NG, BAR, 32 * NM + 4 * NV);
     for (int wgs = 1; wgs <= 4; ++wgs) {
         // dynamic LDS: floor(160 KB / wgs) minus a margin -> exactly `wgs` workgroups per CU
         const size_t lds = (size_t)(160 * 1024 / wgs) - (wgs == 1 ? 0 : 1024);
-        auto kern = k_body<NM, NV, NL, NW, NG, BAR, BUNCH>;
+        auto kern = k_body<NM, NV, NL, NW, NG, BAR, BUNCH, ND, NW2>;
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int iters = 8000;
         hipEvent_t e0, e1;
@@ -141,6 +151,10 @@ int main() {
     run<40, 55, 7, 7, 7, 1, 1>("  with 7 instead of 11 global loads");
     run<40, 55, 7, 4, 11, 1, 1>("  with 4 instead of 7 LDS writes");
     run<40, 55, 7, 4, 7, 1, 1>("  with both");
+    run<40, 55, 7, 3, 11, 1, 1, 0, 4>("  as built: 3 x ds_write_b128 + 4 x ds_write_b64");
+    run<40, 55, 7, 5, 11, 1, 1, 0, 0>("  the four residues as two ds_write_b128 (5 x b128)");
+    run<40, 55, 7, 4, 8, 1, 1, 3>("  matrix slab by LDS-DMA: 8 loads + 3 DMA, 4 LDS writes");
+    run<40, 55, 7, 2, 8, 1, 1, 3>("  ... and the four residues in two 16-byte writes");
     run<16, 55, 4, 7, 11, 1, 1>("band K-step, ncb = 2, vector behind the MFMAs");
     run<80, 55, 12, 7, 11, 1, 1>("band K-step, ncb = 10, vector behind the MFMAs");
     // Winograd chunk (16 channels, one wave): 60 MFMAs, ~110 vector, 15 B + 5 A + 5 tail reads, 4 + 3 staging writes, 7 loads, barrier
