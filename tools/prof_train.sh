@@ -15,6 +15,7 @@ with open(sys.argv[1], "w") as o:
     for r in rows:
         ms = float(r["TotalDurationNs"]) / steps / 1e6
         tot += ms
+        if r["Name"].startswith("__amd_rocclr"): continue      # one-time uploads of model / trainer construction
         name = re.sub(r"\(.*", "", r["Name"]).replace("void xsq::", "")[:90]
         line = "%-92s calls/step %5.1f  ms/step %.4f" % (name, float(r["Calls"]) / steps, ms)
         o.write(line + "\n")
