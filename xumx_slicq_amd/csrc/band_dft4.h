@@ -44,6 +44,10 @@ struct Band4Dev {
     int64_t d_off;      // float offset of Dt[n = (k, re/im)][kk = (t1, re/im)] inside the direction's pool
     int64_t tw_off;     // float offset of the twiddles w^(r t1), r = 1..3: [3][round_up(m, 8)] complex
     int64_t win_off;    // float offset of g' (FWD) / wd (INV), Lg floats in window order q
+    // band_dft4s.h (pair-contracted form): K2 = m / 2 + 1 pairs / outputs; Ct[k][n] = cos(2 pi n k / m) at c_off, rows of ldc =
+    // round_up(K2, 8) floats, round_up(K2, 16) rows; St[k][n] = -+sin(2 pi n k / m) (the direction's sign) right behind it
+    int K2, ldc;
+    int64_t c_off;
 };
 
 // One tile of the radix-4 kernel WITH its band's descriptor (72 bytes, read with scalar loads in one go).  Through a

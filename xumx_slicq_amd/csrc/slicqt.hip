@@ -24,6 +24,7 @@
 #include "prof.h"
 #include "slice_fft.h"
 #include "band_dft4.h"
+#include "band_dft4s.h"
 
 namespace xsq {
 
@@ -283,17 +284,18 @@ static int get_band_tiles(xsq_plan* P, int rows, TileTable* out) {
 // (same values, written twice).
 // cls: 0 = every band (one launch of the 10-block kernel), 1 = bands of more than 5 blocks, 2 = bands of at most 5 blocks
 // (their own instantiation: four workgroups per CU, band_dft4.h)
-static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0, int cls = 0) {
+static int get_dft4_full_tiles(xsq_plan* P, int rows, TileTable* out, int share = 0, int cls = 0, bool sym = false) {
     std::lock_guard<std::mutex> lk(P->mu);
-    auto key = std::make_tuple(3 + 16 * cls, rows, share);
+    auto key = std::make_tuple(3 + 16 * cls + (sym ? 256 : 0), rows, share);
     auto it = P->tiles.find(key);
     if (it != P->tiles.end()) { *out = it->second; return XSQ_OK; }
     std::vector<Tile4Dev> t;
     const Band4Dev* b4 = reinterpret_cast<const Band4Dev*>(P->bands4_host.data());
     const int span = share > 0 ? share : rows, copies = share > 0 ? rows / share : 1;
     for (int i = P->nbands4 - 1; i >= 0; --i) {
-        const int ncb = (2 * P->bands4_m[i] + 15) / 16;
+        int ncb = (2 * P->bands4_m[i] + 15) / 16;
         if ((cls == 1 && ncb <= 5) || (cls == 2 && ncb > 5)) continue;
+        if (sym) ncb = (P->bands4_m[i] / 2 + 1 + 15) / 16;        // band_dft4s.h: blocks of the outputs k = 0 .. m / 2
         for (int m0 = 0; m0 < span; m0 += D4H_ROWS)
             for (int k = 0; k < copies; ++k) t.push_back(Tile4Dev{m0 + k * span, ncb, b4[i]});
     }
@@ -326,9 +328,20 @@ static int d4_ranges_ok(const xsq_plan* P, int64_t rows, const char* who) {
 template <bool FWD>
 static int launch_dft4(xsq_plan* P, const Band4Args& a4, int rows, int share, hipStream_t stream) {
     static const bool split = getenv("XSQ_D4_SPLIT") && atoi(getenv("XSQ_D4_SPLIT")) == 1;
+    // the pair-contracted form (band_dft4s.h) is the default; XSQ_D4_SYM=0 runs the complex-product form (band_dft4.h)
+    static const bool sym = !(getenv("XSQ_D4_SYM") && atoi(getenv("XSQ_D4_SYM")) == 0);
     const bool masked = !FWD && a4.mask != nullptr;
     TileTable t;
     int rc;
+    if (sym) {
+        if ((rc = get_dft4_full_tiles(P, rows, &t, share, 0, true))) return rc;
+        if (!t.ntiles) return XSQ_OK;
+        if constexpr (!FWD) {
+            if (masked) { hipLaunchKernelGGL((band_dft4s_kernel<false, true>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles); return XSQ_OK; }
+        }
+        hipLaunchKernelGGL((band_dft4s_kernel<FWD, false>), dim3(t.ntiles), dim3(256), 0, stream, a4, (const Tile4Dev*)t.d_tiles, t.ntiles);
+        return XSQ_OK;
+    }
     auto launch = [&](auto ncbmax) {
         constexpr int N = decltype(ncbmax)::value;
         if (!t.ntiles) return;
@@ -604,7 +617,7 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
         // bands at least this long take the radix-4 kernel (XSQ_D4_MIN_LG: diagnostic A/B of the split point)
         int d4_min_lg = XSQ_D4_MIN_LG_DEFAULT;
         if (const char* e = getenv("XSQ_D4_MIN_LG")) d4_min_lg = atoi(e) >= 16 ? atoi(e) : d4_min_lg;
-        std::map<int, int64_t> doff, twoff;
+        std::map<int, int64_t> doff, twoff, coff;
         auto alloc2 = [&](size_t n) { size_t o = pf.size(); pf.resize(o + n, 0.f); pi.resize(o + n, 0.f); return (int64_t)o; };
         for (int j = 0; j < nbands; ++j) {
             const BandDev& b = P->bands[j];
@@ -632,6 +645,22 @@ static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg,
                     }
             }
             d.d_off = doff[m];
+            d.K2 = m / 2 + 1; d.ldc = (int)round_up(d.K2, 8);
+            if (!coff.count(m)) {       // band_dft4s.h: Ct[k][n] = cos(2 pi n k / m), St[k][n] = sin(..) with the direction's sign
+                const size_t csz = (size_t)round_up(d.K2, 16) * d.ldc;
+                const int64_t o = alloc2(2 * csz);
+                coff[m] = o;
+                for (int k = 0; k < d.K2; ++k)
+                    for (int nn = 0; nn < d.K2; ++nn) {
+                        const int r = (int)(((int64_t)k * nn) % m);
+                        const double cr = std::cos(PI2 * r / m), si = (nn == 0 || 2 * nn == m) ? 0.0 : std::sin(PI2 * r / m);
+                        pf[o + (size_t)k * d.ldc + nn] = (float)cr;
+                        pi[o + (size_t)k * d.ldc + nn] = (float)cr;
+                        pf[o + csz + (size_t)k * d.ldc + nn] = (float)(-si);     // analysis e^{+}: X[k] = P + i Q = P - i Q'
+                        pi[o + csz + (size_t)k * d.ldc + nn] = (float)si;        // synthesis e^{-}: X[k] = P - i Q
+                    }
+            }
+            d.c_off = coff[m];
             if (!twoff.count(n)) {      // twiddles w^(r t1), r = 1..3: [3][round_up(m, 8)] complex
                 const int mpad = (m + 7) & ~7;
                 const int64_t o = alloc2((size_t)3 * mpad * 2);
