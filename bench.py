@@ -123,8 +123,8 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
 _PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2Op>"], "cdae_l3_gemm": ["gemm<CdaeL3Op>"],
               "cdae_l2_slab": ["wino<CdaeL2>", "slab<CdaeL2>"], "cdae_l3_slab": ["wino<CdaeL3>", "slab<CdaeL3>"],
               "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
-              "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4<inverse>"],
-              "band_analysis_dft4": ["band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
+              "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4s<inverse>", "band_dft4<inverse>"],
+              "band_analysis_dft4": ["band_dft4s<forward>", "band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
               "slice_irfft_ola": ["k_slice_irfft"],
               "overlap_add": ["k_overlap_add"], "magnitude_whiten": ["k_magnitude_whiten"],
               "wiener_stats": ["k_wiener_stats_masked", "k_wiener_stats"], "wiener_apply": ["k_wiener_apply_masked", "k_wiener_apply"],
@@ -279,9 +279,29 @@ def issue_bound(plan, B, chunk_lengths, winograd=True):
                 # separator's path runs is ~200 instructions of prologue and the masks-only epilogue, 6 per element (sigmoid 5 +
                 # store), w / 2 elements per lane -- an estimate, the static count (8,476 over all bodies) cannot tell them apart
                 add("cdae_l4_gemm", tiles * 4, 16.0 * w + lp["mfma_cycles"] * (ks4 - 1) / 2.0, 200.0 + 6.0 * w / 2 + lp["valu"] * ks4 / 2.0)
-        # band kernels: rows = channel-slices; radix-4 bands in 32-row tiles of 4 waves, K-steps of 8 complex, 256 MFMA cycles per
-        # 16-column block and K-step; short bands on the dense engine (N = 2 Lg columns, K = 2 Lg)
+        # band kernels: rows = channel-slices; radix-4 bands in 32-row tiles of 4 waves; short bands on the dense engine
+        # (N = 2 Lg columns, K = 2 Lg).  Default (band_dft4s.h): the four m-point DFTs contracted over input PAIRS -- K-steps of
+        # 8 pairs over K2 = m / 2 + 1, 16 MFMAs (512 cycles) per 16-column block of the K2 outputs and K-step; the budget's loop
+        # and its epilogue blocks are the three-block form's, scaled to the band's blocks.  XSQ_D4_SYM=0 (band_dft4.h): K-steps of
+        # 8 complex over m, 256 MFMA cycles per 16-column block of the 2 m real outputs and K-step.
+        sym = not (os.environ.get("XSQ_D4_SYM", "1") == "0") and "band_dft4s<forward>" in K
         for name, key, rows, eblk in (("band_analysis_dft4", "band_dft4<forward>", 2 * B * S, None), ("band_synthesis_dft4", "band_dft4<inverse,masked>", 8 * B * S, 33)):
+            if sym:
+                # (the analysis binary holds two exclusive load paths -- Hermitian reflection for the two edge bands -- and the
+                # whitened-magnitude epilogue in two formats: its static count cannot tell what runs.  Its budget is the
+                # synthesis kernel's plus the window products, 16 per K-step, and the magnitudes, ~64 per epilogue block.)
+                k = K["band_dft4s<inverse,masked>"]
+                lp = k["loops"][0]
+                fwd = eblk is None
+                e = 95 + (64 if fwd else 0)                    # vector instructions of one epilogue block (of three in the binary)
+                for lg in Lg[Lg >= split]:
+                    m = int(lg) // 4
+                    k2 = m // 2 + 1
+                    ncb, ksteps = math.ceil(k2 / 16), math.ceil(k2 / 8)
+                    tiles = math.ceil(rows / 32)
+                    add(name, tiles * 4, 512.0 * ncb * ksteps,
+                        k["outside"]["valu"] + (16 if fwd else 0) - (3 - ncb) * 95 + (64 * ncb if fwd else 0) + (lp["valu"] + (16 if fwd else 0)) * (ksteps - 1))
+                continue
             k = K[key]
             lp = k["loops"][0]
             e = eblk if eblk is not None else (k["outside"]["valu"] - 300) / 10.0

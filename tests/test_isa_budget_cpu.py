@@ -57,6 +57,45 @@ def test_band_kernel_vector_instruction_budget(tmp_path):
     assert "v_pk_" not in text          # no packed-fp32 ops (Makefile NOPK; -fno-slp-vectorize stands in for it here)
 
 
+SRC_S = """#include "band_dft4s.h"
+using namespace xsq;
+template __global__ void xsq::band_dft4s_kernel<true, false>(Band4Args, const Tile4Dev*, int);
+template __global__ void xsq::band_dft4s_kernel<false, true>(Band4Args, const Tile4Dev*, int);
+template __global__ void xsq::band_dft4s_kernel<false, false>(Band4Args, const Tile4Dev*, int);
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_pair_contracted_band_kernel_budget(tmp_path):
+    """band_dft4s.h (the default band kernel: m-point DFTs contracted over input pairs): no scratch, inside three workgroups
+    per CU (168 registers, 42.1 KB of LDS), 48 MFMAs = 1,536 cycles per K-step of the three-block form, and the synthesis
+    K-step within its vector-instruction budget."""
+    src, asm = tmp_path / "d4s.hip", tmp_path / "d4s.s"
+    src.write_text(SRC_S)
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "xumx_slicq_amd", "csrc"), "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+                    "-S", "--cuda-device-only", str(src), "-o", str(asm)], check=True, capture_output=True, timeout=600)      # (the library's flags: csrc/Makefile NOPK)
+    text = asm.read_text()
+    meta = re.findall(r"\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+)\s+\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", text, flags=re.S)
+    assert len(meta) == 3, meta
+    for lds, name, scratch, vgprs in meta:
+        assert int(scratch) == 0 and int(vgprs) <= 168 and 3 * int(lds) <= 160 * 1024, (name, scratch, vgprs, lds)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_mfma.py"), str(asm)], check=True,
+                         capture_output=True, text=True, timeout=120).stdout
+    rows, cur = {}, None
+    for line in out.splitlines():
+        if line.startswith("void "):
+            cur = line
+        m = re.search(r"MFMA\s+(\d+) cycles \(\s*(\d+)\), other vector\s+(\d+)", line)
+        if m and cur:
+            rows.setdefault(cur, []).append(tuple(int(x) for x in m.groups()))
+    for sig, budget in (("<false, true>", 120), ("<false, false>", 105)):
+        loops = [v for k, v in rows.items() if "band_dft4s_kernel" + sig in k][0]
+        k_loop = min(loops, key=lambda r: r[2])
+        assert k_loop[0] == 1536 and k_loop[1] == 48 and k_loop[2] <= budget, (sig, loops)
+    assert "v_pk_" not in text
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_committed_instruction_budget_is_the_one_of_the_sources(tmp_path):
     """profiles/isa_budget.json (what bench.py's `roofline_issue` is computed from) against a fresh run of tools/isa_budget.py

@@ -30,6 +30,8 @@ WANT = {
     "gemm<CdaeL3Op>": r"grouped_gemm_kernel<xsq::CdaeL3Op, 1, 1>", "gemm<CdaeL4Op>": r"grouped_gemm_kernel<xsq::CdaeL4Op, 1, 2>",
     "band_dft4<forward>": r"band_dft4_full_kernel<true, 10, false>", "band_dft4<inverse,masked>": r"band_dft4_full_kernel<false, 10, true>",
     "band_dft4<inverse>": r"band_dft4_full_kernel<false, 10, false>",
+    "band_dft4s<forward>": r"band_dft4s_kernel<true, false>", "band_dft4s<inverse,masked>": r"band_dft4s_kernel<false, true>",
+    "band_dft4s<inverse>": r"band_dft4s_kernel<false, false>",
     "gemm<BandFwdOp>": r"grouped_gemm_kernel<xsq::BandFwdOp, 1, 0>", "gemm<BandInvOp>": r"grouped_gemm_kernel<xsq::BandInvOp, 1, 0>",
 }
 VECTOR = re.compile(r"^\s*v_")

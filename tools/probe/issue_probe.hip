@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0>
+template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0, int NG2 = 0, int NG1 = 0>
 __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
     const unsigned goff = 16u * (unsigned)tid;
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 65536, 0x00020000);
     f32x4 lv[NL > 0 ? NL : 1], gv[NG > 0 ? NG : 1];
+    typedef float f32x2g __attribute__((ext_vector_type(2)));
+    f32x2g gv2[NG2 > 0 ? NG2 : 1];
+    float gv1[NG1 > 0 ? NG1 : 1];
     const f32x4 wv = {a, b, a, b};
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 wv2 = {a, b};
@@ -47,6 +50,13 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
 #pragma unroll
         for (int i = 0; i < NG; ++i)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(gv[i]) : "v"(goff), "s"(rs), "n"(0) : "memory");
+        // NG2 x buffer_load_dwordx2, NG1 x buffer_load_dword (8 / 4 bytes per lane)
+#pragma unroll
+        for (int i = 0; i < NG2; ++i)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen offset:%3" : "=v"(gv2[i]) : "v"(goff), "s"(rs), "n"(0) : "memory");
+#pragma unroll
+        for (int i = 0; i < NG1; ++i)
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(gv1[i]) : "v"(goff), "s"(rs), "n"(0) : "memory");
         // ND x buffer_load_dwordx4 ... lds (LDS-DMA: lane l's 16 bytes land at base + 16 l; no register, no ds_write)
 #pragma unroll
         for (int i = 0; i < ND; ++i)
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
 #pragma unroll
         for (int i = 0; i < NW2; ++i)         // NW2 x ds_write_b64 (8 bytes per lane)
             asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(laddr), "v"(wv2), "n"(24576 + (i & 3) * 1024) : "memory");
-        if (NG > 0 || ND > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NG > 0 || ND > 0 || NG2 > 0 || NG1 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (NL > 0 || NW > 0 || NW2 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (BAR) asm volatile("s_barrier" ::: "memory");
     }
@@ -87,18 +97,22 @@ __global__ __launch_bounds__(256) void k_body(float* sink, const float* src, int
     for (int i = 0; i < NL; ++i) s += lv[i][0];
 #pragma unroll
     for (int i = 0; i < NG; ++i) s += gv[i][0];
+#pragma unroll
+    for (int i = 0; i < NG2; ++i) s += gv2[i][0];
+#pragma unroll
+    for (int i = 0; i < NG1; ++i) s += gv1[i];
     if (s == 1.2345e-30f) sink[tid] = s;
 }
 
 static float* d_sink; static float* d_src; static int g_cus = 256;
 
-template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0>
+template <int NM, int NV, int NL, int NW, int NG, int BAR, int BUNCH = 0, int ND = 0, int NW2 = 0, int NG2 = 0, int NG1 = 0>
 static void run(const char* what) {
     printf("%-44s NM %3d NV %3d NL %2d NW %2d NG %2d BAR %d | 32 NM + 4 NV %5d |", what, NM, NV, NL, NW, NG, BAR, 32 * NM + 4 * NV);
     for (int wgs = 1; wgs <= 4; ++wgs) {
         // dynamic LDS: floor(160 KB / wgs) minus a margin -> exactly `wgs` workgroups per CU
         const size_t lds = (size_t)(160 * 1024 / wgs) - (wgs == 1 ? 0 : 1024);
-        auto kern = k_body<NM, NV, NL, NW, NG, BAR, BUNCH, ND, NW2>;
+        auto kern = k_body<NM, NV, NL, NW, NG, BAR, BUNCH, ND, NW2, NG2, NG1>;
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int iters = 8000;
         hipEvent_t e0, e1;
@@ -161,5 +175,12 @@ int main() {
     run<60, 110, 25, 7, 7, 1, 0>("Winograd 16-channel chunk (interleaved)");
     run<60, 110, 25, 7, 7, 1, 1>("Winograd 16-channel chunk (vector behind)");
     run<60, 110, 0, 0, 0, 0, 0>("  its MFMAs + vector only");
+    // the pair-contracted band kernel (band_dft4s.h): K-step of 8 pairs = 16 ncb MFMAs, 107 vector, 13 LDS reads, 9 LDS writes, 17 loads
+    run<16, 107, 13, 9, 1, 1, 1, 0, 0, 8, 8>("pair-contracted band K-step, 1 block (8 x 8-byte + 8 x 4-byte + 1 x 16-byte loads)");
+    run<32, 107, 13, 9, 1, 1, 1, 0, 0, 8, 8>("pair-contracted band K-step, 2 blocks");
+    run<48, 107, 13, 9, 1, 1, 1, 0, 0, 8, 8>("pair-contracted band K-step, 3 blocks");
+    run<16, 107, 13, 9, 5, 1, 1, 0, 0, 4, 0>("  1 block, two pairs per thread: 4 x 16-byte + 4 x 8-byte + 1 loads");
+    run<16, 107, 13, 9, 1, 1, 1, 0, 0, 8, 0>("  1 block, without the mask loads");
+    run<16, 107, 0, 0, 0, 0, 1>("  1 block, MFMAs + vector only");
     return 0;
 }

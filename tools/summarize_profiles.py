@@ -26,6 +26,8 @@ glob.glob = newest
 def short(n):
     import re
     n = n.replace("void xsq::band_dft4_kernel<false>", "band_dft4<inverse>").replace("void xsq::band_dft4_kernel<true>", "band_dft4<forward>")    # profiles before r03e
+    n = re.sub(r"void xsq::band_dft4s_kernel<false(?:, (?:true|false))?>", "band_dft4s<inverse>", n)       # pair-contracted form (band_dft4s.h)
+    n = re.sub(r"void xsq::band_dft4s_kernel<true(?:, (?:true|false))?>", "band_dft4s<forward>", n)
     n = re.sub(r"void xsq::band_dft4_full_kernel<false(?:, \d+)?(?:, (?:true|false))?>", "band_dft4<inverse>", n)
     n = re.sub(r"void xsq::band_dft4_full_kernel<true(?:, \d+)?(?:, (?:true|false))?>", "band_dft4<forward>", n)
     n = re.sub(r"void xsq::k_slice_(i?rfft)<\d+(?:, (?:true|false))*>", r"k_slice_\1", n)
