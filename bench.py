@@ -385,6 +385,18 @@ def executed_mfma_flops(plan, B, chunk_lengths, kernel, winograd):
     """Flops the matrix pipe EXECUTES per step under `kernel` where they differ from the algorithmic count of SURVEY.md 8(d):
     layers 2 / 3 as Winograd F(2, 4) along the time taps -- 5 products per output pair, input channel (52 stored) and matrix
     column (48 of the 50 / 51 channels; the rest on the vector ALU) instead of 8 per pair, real channel and column."""
+    if kernel in ("band_synthesis_dft4", "band_analysis_dft4") and os.environ.get("XSQ_D4_SYM", "1") != "0":
+        # band_dft4s.h: the four m-point DFTs of a band contracted over input pairs -- per row and residue two real
+        # (m / 2 + 1)^2 matrices on (Re, Im) instead of one complex m x m product: 4 x 4 (m / 2 + 1)^2 x 2 flops per row
+        rows_per_slice = 8 if kernel == "band_synthesis_dft4" else 2
+        split = int(os.environ.get("XSQ_D4_MIN_LG", 24))
+        total = 0
+        for n in chunk_lengths:
+            S = plan.num_slices(max(n, plan.L // 2 + 1))
+            for lg in plan.Lg:
+                if lg >= split:
+                    total += rows_per_slice * B * S * 4 * 4 * (int(lg) // 8 + 1) ** 2 * 2
+        return total
     if kernel not in ("cdae_l2_slab", "cdae_l3_slab") or not winograd:
         return None
     from xumx_slicq_amd.weights import freq_filter

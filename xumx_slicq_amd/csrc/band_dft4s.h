@@ -32,6 +32,7 @@ constexpr int S4_KP = 8, S4_NCB = 3, S4_AROWS = 16 * D4H_ROWS, S4_BROWS = 16 * S
 template <bool FWD, bool MASKED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void band_dft4s_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntiles) {
+#pragma clang fp contract(off)          // fused multiply-adds only where written (fmaf): same bits from every instantiation
     static_assert(!(FWD && MASKED), "the mask product belongs to the synthesis");
     static_assert(D4H_ROWS == 32, "32-row tiles");
     constexpr int ABUF = S4_AROWS * S4_KP, BBUF = 2 * S4_BROWS * S4_KP;
@@ -118,6 +119,7 @@ void band_dft4s_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntil
         for (int q4 = 0; q4 < 4; ++q4) {
             float2 v = raw[q4];
             if (!FWD) {
+                // (a rounded product -- contraction is off -- as the layer-4 epilogue stores it when it materialises mask * X)
                 if (MASKED) { v.x *= mk[q4]; v.y *= mk[q4]; }
             } else {
                 const float g = winl[t1 + q4 * m_];
@@ -138,9 +140,11 @@ void band_dft4s_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntil
         const float2 yp = make_float2(d0.x - d1.y, d0.y + d1.x);      // d0 + i d1
         const float2 y1 = FWD ? yp : ym, y3 = FWD ? ym : yp;
         y[0] = make_float2(s0.x + s1.x, s0.y + s1.y);
-        y[1] = make_float2(y1.x * w1.x - y1.y * w1.y, y1.x * w1.y + y1.y * w1.x);
-        y[2] = make_float2(y2.x * w2.x - y2.y * w2.y, y2.x * w2.y + y2.y * w2.x);
-        y[3] = make_float2(y3.x * w3.x - y3.y * w3.y, y3.x * w3.y + y3.y * w3.x);
+        // (fused multiply-adds spelled out, contraction off in this kernel: the masked and the plain instantiation must round alike --
+        //  the separator's masks-only path and the decode of materialised estimates are held bitwise equal)
+        y[1] = make_float2(fmaf(y1.x, w1.x, -(y1.y * w1.y)), fmaf(y1.x, w1.y, y1.y * w1.x));
+        y[2] = make_float2(fmaf(y2.x, w2.x, -(y2.y * w2.y)), fmaf(y2.x, w2.y, y2.y * w2.x));
+        y[3] = make_float2(fmaf(y3.x, w3.x, -(y3.y * w3.y)), fmaf(y3.x, w3.y, y3.y * w3.x));
     };
     const int a_st = s_row * S4_KP + s_p;
     const int b_st = (tid >> 7) * S4_BROWS * S4_KP + b_col * S4_KP + 4 * (tid & 1);
