@@ -206,3 +206,29 @@ def test_packed_butterflies_are_a_diagnostic_build_only(fb):
             assert torch.equal(y0, y1), (n, float((y0 - y1).abs().max()))
     finally:
         eng.set_packed_fft(False)
+
+
+def test_complex_product_band_kernel_arm_agrees_with_the_default(fb, tmp_path):
+    """XSQ_D4_SYM=0 keeps the complex-product radix-4 kernel (csrc/band_dft4.h) as an A/B arm beside the default pair-contracted
+    form (csrc/band_dft4s.h, a quarter of the matrix work).  The switch is read once per process: the arm runs in a child."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base, enc, dec = fb
+    n = 60000
+    x = synth_audio(n, seed=31, nb_samples=1).cuda()
+    C = enc(x)
+    y = dec([c.clone() for c in C], n)
+    out = tmp_path / "arm.pt"
+    code = ("import torch, sys; sys.path.insert(0, %r)\n"
+            "from xumx_slicq_amd.transforms import NSGTBase, make_filterbanks\n"
+            "from xumx_slicq_amd.synth import synth_audio\n"
+            "base = NSGTBase('bark', 262, 32.9, device='cuda'); enc, dec = make_filterbanks(base)\n"
+            "x = synth_audio(%d, seed=31, nb_samples=1).cuda(); C = enc(x); y = dec([c.clone() for c in C], %d)\n"
+            "torch.save({'C': [c.cpu() for c in C], 'y': y.cpu()}, %r)\n" % (ROOT, n, n, str(out)))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, XSQ_D4_SYM="0"), timeout=600, capture_output=True)
+    arm = torch.load(out)
+    for i in range(70):
+        assert float((C[i].cpu() - arm["C"][i]).abs().max()) < 1e-4, i
+    assert float((y.cpu() - arm["y"]).abs().max()) < 5e-6
