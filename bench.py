@@ -865,7 +865,8 @@ def variant_train_step(args, sep, dev, batch=16, seq_dur=2.0, precision="fp32"):
             "frac_note": "of the fp32 MFMA peak (the fp32 arm runs there; the bf16 arm's contractions run on the bf16 pipe, 16x that peak: "
                          "its step is bound by operand delivery, BatchNorm, loss and transforms)",
             "parity": ("tests/test_training.py::test_hip_training_step_at_config_size_matches_the_oracle (this batch, fp32 and bf16x6)" if precision == "fp32"
-                       else "tests/test_training.py::test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread (reference autograd under bf16 autocast)"),
+                       else "tests/test_training.py::test_hip_training_step_bf16_arm_at_config_size (THIS batch, B = 16 x 88,200: the reference's own autograd under "
+                            "bf16 autocast, tests/golden/training_step_bf16_b16.npz) and ::test_hip_training_step_bf16_arm_sits_inside_the_reference_autocast_spread (B = 2)"),
             "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
             "dominant_kernel": {"kernel": dom, "ms_per_step": kern[dom], "share_of_step": round(kern[dom] / (dt * 1e3), 4)},
             "kernels_ms": dict(list(kern.items())[:12])}
@@ -1083,7 +1084,8 @@ def collective_block(dmx, dist, world, rank, dev, step_ms, other_ms, gather):
     if dmx.gather:
         dmx.run()
         torch.cuda.synchronize()
-        mine = int(dmx.flat.view(torch.int32).sum(dtype=torch.int64).item())
+        from xumx_slicq_amd.sharding import checksum_int32
+        mine = checksum_int32(dmx.flat)
         sums = [None] * world
         dist.all_gather_object(sums, mine)
         replicas = {"stems_checksum_int32_sum": sums[0], "identical_on_all_ranks": all(v == sums[0] for v in sums)}

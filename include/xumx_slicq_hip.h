@@ -255,6 +255,7 @@ int xsq_comm_version(void);                                                /* nc
 int xsq_comm_unique_id(void* id128);
 int xsq_comm_create(xsq_comm** out, const void* id128, int world, int rank);
 int xsq_comm_destroy(xsq_comm* comm);
+int xsq_comm_abort(xsq_comm* comm);                                        /* ncclCommAbort: do not wait for queued operations; frees the handle */
 int xsq_exchange_rows(xsq_comm* comm, const float* src, int64_t src_len, float* dst, int64_t dst_len, const int64_t* rows,
                       int nrows, int self_loop, void* stream);
 

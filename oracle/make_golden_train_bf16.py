@@ -8,6 +8,10 @@ tolerances from the fixture's OWN fp32-vs-bf16 spread: a bf16 arm is right when 
 as bf16 rounding allows, and that distance is not a number to guess.  Development container only.
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_train_bf16
+
+``--b16``: the same pair of steps on bench.py's configs[4] batch itself -- B = 16 chunks of 88,200 samples, seeds 700..703 as
+tests/test_training.py:_inputs16 -- into tests/golden/training_step_bf16_b16.npz (losses, every tensor's gradient norm in
+both arithmetics, the per-tensor fp32-vs-bf16 distance, twelve full tensors): the 2.7 ms bench number's own shape.
 """
 from __future__ import annotations
 
@@ -34,6 +38,7 @@ KEEP = ["sliced_umx.0.input_mean", "sliced_umx.0.input_scale", "sliced_umx.0.cda
 
 
 def main():
+    b16 = "--b16" in sys.argv
     torch.set_num_threads(8)
     from xumx_slicq_v2.transforms import NSGTBase, make_filterbanks, ComplexNorm
     from xumx_slicq_v2.model import Unmix
@@ -46,8 +51,11 @@ def main():
     with torch.no_grad():
         jag, _ = base.predict_input_size(1, 2, 2.0)
     sd = seeded_state_dict([(b.shape[2], b.shape[4]) for b in jag], seed=1234)
-    n = 44100
-    y_t = torch.stack([0.5 * synth_audio(n, seed=600 + j, nb_samples=2) for j in range(4)])
+    n = 88200 if b16 else 44100
+    if b16:
+        y_t = torch.stack([0.5 * synth_audio(n, seed=700 + j, nb_samples=16) for j in range(4)])
+    else:
+        y_t = torch.stack([0.5 * synth_audio(n, seed=600 + j, nb_samples=2) for j in range(4)])
     x = y_t.sum(0)
 
     def step(autocast: bool):
@@ -96,7 +104,7 @@ def main():
           (np.median(rel), np.quantile(rel, 0.9), np.quantile(rel, 0.99), rel.max()))
     print("loss difference: mse %.3e, mask %.3e (relative)" % (abs(d["bf16_mse"] - d["fp32_mse"]) / d["fp32_mse"],
                                                               abs(d["bf16_mask"] - d["fp32_mask"]) / d["fp32_mask"]))
-    path = os.path.join(OUT, "training_step_bf16.npz")
+    path = os.path.join(OUT, "training_step_bf16_b16.npz" if b16 else "training_step_bf16.npz")
     np.savez_compressed(path, **d)
     print(path, os.path.getsize(path))
 

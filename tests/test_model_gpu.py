@@ -307,6 +307,39 @@ def test_hip_graph_replay_matches_eager(seps):
 
 
 @pytest.mark.gpu
+def test_graph_replay_survives_the_plan_cache_eviction_and_follows_the_winograd_switch(seps):
+    """the native call caches one schedule + device row table per call shape, LRU-bounded at 64.
+    A captured graph holds those table pointers and a replay never passes through the cache, so 65 other shapes through the
+    eager path used to free the tables under it.  Shapes seen under stream capture are pinned.  (low): the Winograd switch
+    is part of the graph key -- a graph captured with the Winograd kernels is not replayed after set_winograd(False)."""
+    sep = seps["offline_phasemix"]
+    sep.chunk_size = 60000
+    a = synth_audio(150000, seed=43).cuda()
+    try:
+        want = sep(a).clone()
+        got0 = sep.forward_graphed(a).clone()
+        for i in range(66):                                     # 66 new call shapes: the LRU cache turns over completely
+            sep(synth_audio(20000 + 8 * i, seed=1).cuda())
+        torch.cuda.synchronize()
+        got1 = sep.forward_graphed(a).clone()
+        assert len(sep._graphs) == 1
+        assert torch.equal(want, got0) and torch.equal(want, got1)
+        # rows >= 127 positions take the Winograd kernels: a longer chunk so that the switch changes the arithmetic
+        sep.chunk_size = 700000
+        b = synth_audio(650000, seed=44).cuda()
+        w1 = sep.forward_graphed(b).clone()
+        sep.xumx_model.set_winograd(False)
+        d0 = sep(b).clone()
+        g0 = sep.forward_graphed(b).clone()
+        sep.xumx_model.set_winograd(True)
+        assert torch.equal(d0, g0) and not torch.equal(w1, g0) and float((w1 - g0).pow(2).mean().sqrt()) < 1e-6
+    finally:
+        sep.chunk_size = 2621440
+        sep.xumx_model.set_winograd(True)
+        sep.drop_graphs()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("realtime", [True, False])
 def test_fused_phasemix_decode_is_bitwise_equal(realtime):
     """Separator's mix-phase path (CDAE writes masks only, xsq_slicqt_inverse_masked forms mask * X while it

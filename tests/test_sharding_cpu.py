@@ -177,6 +177,142 @@ def test_world_size_two_gloo_matches_sequential():
     assert res == [(0, True, True), (1, True, True)]
 
 
+# ---- world = 4 and 8: the north star quotes 1 / 2 / 4 / 8 GPUs -------------------------------
+def _testset_lengths(n=50):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.testset_lengths(n)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_shard_plan_invariants_on_the_50_track_set(world):
+    """configs[3] at its stated size, plan level: the 254 (track, chunk) items of bench.py's 50 track lengths over 4 and 8
+    ranks.  Every item placed exactly once; a round holds <= stack items per rank; the exchange tables (what every rank
+    would hand xsq_exchange_rows) are a function of the plan only, cover every row of every item once with the owner the
+    plan chose, and the group cuts of csrc/exchange.hip (by ROW INDEX) pair every send with a receive of the same group."""
+    import numpy as np
+    lengths, cs = _testset_lengths(), 2_621_440
+    plan = ShardPlan(lengths, cs, world, stack=4)
+    items = chunk_items(lengths, cs)
+    assert len(items) == 254
+    seen = [p.item for rnd in plan.rounds for per_rank in rnd for p in per_rank]
+    assert sorted(seen, key=lambda i: (i.track, i.chunk)) == items
+    assert plan.imbalance() < 1.03
+    owner_of = {(p.item.track, p.item.chunk): r for rnd in plan.rounds for r, per_rank in enumerate(rnd) for p in per_rank}
+    assert all(len(per_rank) <= 4 for rnd in plan.rounds for per_rank in rnd)
+    # at least two rounds per rank: the exchange of round k runs beside the kernels of round k + 1
+    assert min(sum(1 for rnd in plan.rounds if rnd[r]) for r in range(world)) >= 2
+    # the tables as ShardedDemixer builds them (no process group needed: they depend on the plan alone)
+    track_off = [0]
+    for n in lengths:
+        track_off.append(track_off[-1] + 8 * n)
+
+    class _D:                                              # just enough of a ShardedDemixer for _exchange_table
+        pass
+    d = _D()
+    d.plan, d.world, d.track_off = plan, world, track_off
+    total_rows, total_len, covered = 0, 0, set()
+    per_group = max(1, 1024 // max(1, world - 1))          # csrc/exchange.hip: rows_per_group
+    for key in plan.exchanges():
+        tab = ShardedDemixer._exchange_table(d, *key)
+        assert tab.dtype == np.int64 and tab.shape[1] == 4 and tab.flags["C_CONTIGUOUS"]
+        assert (tab[:, 1] == tab[:, 2]).all() and (tab[:, 0] >= 0).all() and (tab[:, 0] < world).all()
+        assert (tab[:, 1] + tab[:, 3] <= track_off[-1]).all()
+        # group by group: the sends rank r queues to peer q in group g == the receives q queues from r in group g
+        for g0 in range(0, len(tab), per_group):
+            grp = tab[g0:g0 + per_group]
+            # what each rank queues, walking the group as xsq_exchange_rows does (owner: a send to every peer; else one receive)
+            sent = {r: [] for r in range(world)}           # rank -> [(peer, offset, length)] in issue order
+            recvd = {r: [] for r in range(world)}          # rank -> [(source, offset, length)]
+            for me in range(world):
+                for ow, o, do, n in grp.tolist():
+                    if ow == me:
+                        sent[me] += [(peer, o, n) for peer in range(world) if peer != me]
+                    else:
+                        recvd[me].append((ow, do, n))
+            for a in range(world):                         # point-to-point operations of a pair match IN ORDER
+                for b in range(world):
+                    if a != b:
+                        assert [(o, n) for peer, o, n in sent[a] if peer == b] == [(o, n) for src, o, n in recvd[b] if src == a]
+            assert max(len(sent[r]) + len(recvd[r]) for r in range(world)) <= 1024 + (world - 1)
+        for ow, o, _, n in tab.tolist():
+            span = (o, n)
+            assert span not in covered
+            covered.add(span)
+        total_rows += len(tab)
+        total_len += int(tab[:, 3].sum())
+    assert total_rows == 8 * 254 and total_len == 8 * sum(lengths)
+    # owners in the tables are the plan's owners
+    for key in plan.exchanges():
+        k, part = key
+        for r in range(world):
+            for p in plan.rounds[k][r]:
+                assert owner_of[(p.item.track, p.item.chunk)] == r
+    acct = plan.exchange_bytes()
+    assert acct["collectives_per_step"] == len(plan.exchanges())
+    loads = [sum(32 * i.length for i in q) for q in plan.queues]
+    assert acct["stem_bytes_in_per_rank_per_step"] == sum(loads) - min(loads)
+    assert acct["bytes_in_per_rank_per_step"] >= acct["stem_bytes_in_per_rank_per_step"] * 0.99
+
+
+def _worker_n(rank, world, port, q):
+    """world = 4 / 8: 14 tracks -> 63 items of <= 600 samples, >= 2 rounds of stack = 2 on every rank, both exchange forms,
+    buffers reused across two steps, replicas compared."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = (rank, "not run")
+    try:
+        from xumx_slicq_amd.sharding import close_row_exchanges
+        g = torch.Generator().manual_seed(7)
+        lens = [2500, 700, 1301, 64, 3100, 1800, 4790, 601, 599, 1200, 2400, 3333, 4199, 5000]
+        tracks = [torch.randn(1, 2, n, generator=g) for n in lens]
+        ref = _sequential(tracks)
+        get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+        notes = []
+        for exchange in ("sendrecv", "allgather"):
+            dmx = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange=exchange)
+            assert dmx.world == world and dmx.settle() is None
+            if min(sum(1 for rnd in dmx.plan.rounds if rnd[r]) for r in range(world)) < 2:
+                notes.append("a rank has fewer than two rounds")
+            for step in range(2):
+                dmx.flat.fill_(float("nan"))
+                got = dmx.run()
+                if not all(torch.equal(got[t], ref[t]) for t in ref):
+                    notes.append(f"{exchange} step {step}: differs from the sequential chunk loop")
+            sums = [None] * world
+            dist.all_gather_object(sums, int(dmx.flat.view(torch.int32).sum(dtype=torch.int64)))
+            if len(set(sums)) != 1:
+                notes.append(f"{exchange}: replicas differ {sums}")
+        out = demix_sharded(fake_separate, tracks, chunk_size=600)
+        if not all(torch.equal(out[t], ref[t]) for t in ref):
+            notes.append("demix_sharded differs")
+        close_row_exchanges()
+        res = (rank, "ok" if not notes else "; ".join(notes))
+    except Exception as e:                                  # noqa: BLE001
+        import traceback
+        res = (rank, f"{type(e).__name__}: {e} | {traceback.format_exc()[-400:]}")
+    finally:
+        q.put(res)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_world_size_four_and_eight_gloo_matches_sequential(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, "ok") for r in range(world)], res
+
+
 def test_single_process_without_process_group():
     tracks = [torch.arange(1500, dtype=torch.float32).view(1, 1, -1).repeat(1, 2, 1)]
     out = demix_sharded(fake_separate, tracks, chunk_size=400)
@@ -213,6 +349,23 @@ def _fault_worker(rank, world, port, q, fault):
         got = dmx.run()
         if not all(torch.equal(got[t], ref[t]) for t in ref):
             notes.append("fallback run differs")
+        # a failure at the first exchange's ENQUEUE (every rank: with gloo's blocking broadcasts a one-sided failure cannot be
+        # staged): the vote before any rank blocks sends every rank to the all-gather form, or makes every rank raise
+        os.environ["XSQ_FAULT_INJECT"] = ""
+        late = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv", fallback=True)
+        strict = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv")
+        os.environ["XSQ_FAULT_INJECT"] = "exchange:all"
+        n2 = late.settle()
+        if late.exchange != "allgather" or not n2 or "enqueue" not in n2:
+            notes.append(f"enqueue fault: exchange={late.exchange} note={n2}")
+        try:
+            strict.settle()
+            notes.append("enqueue fault without fallback: did not raise")
+        except ExchangeUnavailable:
+            pass
+        got = late.run()
+        if not all(torch.equal(got[t], ref[t]) for t in ref):
+            notes.append("run after the enqueue-fault fallback differs")
         os.environ["XSQ_FAULT_INJECT"] = ""
         ok = ShardedDemixer(FakeSeparator(), lens, get, torch.device("cpu"), stack=2, exchange="sendrecv", fallback=True)
         if ok.exchange != "sendrecv" or ok.exchange_note is not None or ok.settle() is not None:

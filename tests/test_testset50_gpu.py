@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHUNK = 2_621_440
 
 
-def _worker(rank, world, port, q, backend, wiener, exchange):
+def _worker(rank, world, port, q, backend, wiener, exchange, ntracks=50):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
@@ -42,24 +42,40 @@ def _worker(rank, world, port, q, backend, wiener, exchange):
         from xumx_slicq_amd.separator import seeded_separator
         from xumx_slicq_amd.sharding import ShardedDemixer, chunk_items, close_row_exchanges
         from xumx_slicq_amd.synth import synth_audio_device
-        lengths = bench.testset_lengths()
-        assert len(lengths) == 50 and len(chunk_items(lengths, CHUNK)) == 254
+        lengths = bench.testset_lengths(ntracks)
+        assert lengths == bench.testset_lengths()[:ntracks]
+        assert ntracks != 50 or len(chunk_items(lengths, CHUNK)) == 254
         sep = seeded_separator(realtime=False, wiener=wiener, device=dev, chunk_size=CHUNK)
         # the bench's own audio: item (track, chunk) seeded on its own, a track = its items back to back
-        tracks = [torch.cat([synth_audio_device(it.length, seed=20260101 + 64 * t + it.chunk, device=dev)
-                             for it in chunk_items([n], CHUNK)], dim=-1) for t, n in enumerate(lengths)]
-        get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+        def whole(t):
+            return torch.cat([synth_audio_device(it.length, seed=20260101 + 64 * t + it.chunk, device=dev)
+                              for it in chunk_items([lengths[t]], CHUNK)], dim=-1)
+        if world <= 2:                                           # whole tracks resident (84 MB per 240 s), items are views
+            tracks = [whole(t) for t in range(ntracks)]
+            get = lambda it: tracks[it.track][..., it.start:it.start + it.length]
+        else:                                                    # several ranks share the one device: a rank keeps its own items only
+            tracks, items = None, {}
+            def get(it):
+                key = (it.track, it.chunk)
+                if key not in items:
+                    items[key] = synth_audio_device(it.length, seed=20260101 + 64 * it.track + it.chunk, device=dev)
+                return items[key]
         dmx = ShardedDemixer(sep, lengths, get, dev, stack=4, gather=("always" if world == 1 else True), exchange=exchange)
         assert dmx.world == world and dmx.gather and dmx.exchange == exchange and dmx.settle() is None
-        assert dmx.flat.numel() == 8 * sum(lengths) > (1 << 32)
-        cross = next(t for t in range(50) if dmx.track_off[t] < (1 << 32) <= dmx.track_off[t + 1])
+        assert dmx.flat.numel() == 8 * sum(lengths) and (ntracks < 50 or dmx.flat.numel() > (1 << 32))
+        cross = next((t for t in range(ntracks) if dmx.track_off[t] < (1 << 32) <= dmx.track_off[t + 1]), -1)
+        if world > 2:                                            # every rank: >= 2 rounds, a stacked pass and tails, rows from every peer
+            per_rank = [sum(1 for rnd in dmx.plan.rounds if rnd[r]) for r in range(world)]
+            assert min(per_rank) >= 2, per_rank
+            owners = {int(o) for key in dmx.plan.exchanges() for o in (dmx._xtable[key][:, 0] if exchange == "sendrecv" else [])}
+            assert exchange != "sendrecv" or owners == set(range(world)), owners
         msgs = []
         for step in range(2 if world == 1 else 1):               # buffers and tables are reused across steps
             dmx.flat.fill_(float("nan"))                         # every element has to be written by the step
             out = dmx.run()
             torch.cuda.synchronize()
-            for t in range(50):
-                ref = sep(tracks[t])
+            for t in range(ntracks):
+                ref = sep(tracks[t] if tracks is not None else whole(t))
                 if out[t].shape != ref.shape or not torch.equal(out[t], ref):
                     msgs.append(f"step {step} track {t}{' (crosses 2^32)' if t == cross else ''} differs by "
                                 f"{float((out[t] - ref).abs().nan_to_num(nan=9e9).max()):.3e}")
@@ -68,8 +84,11 @@ def _worker(rank, world, port, q, backend, wiener, exchange):
                 if a != b:
                     msgs.append(f"step {step} track {t}: checksum {a} != {b}")
                 del ref
+                if world > 2:
+                    torch.cuda.empty_cache()                     # eight caching allocators share one device
         if world > 1:                                            # every rank must hold the same bits of everything
-            mine = int(dmx.flat.view(torch.int32).sum(dtype=torch.int64).item())
+            from xumx_slicq_amd.sharding import checksum_int32
+            mine = checksum_int32(dmx.flat)
             sums = [None] * world
             dist.all_gather_object(sums, mine)
             if len(set(sums)) != 1:
@@ -84,14 +103,14 @@ def _worker(rank, world, port, q, backend, wiener, exchange):
         dist.destroy_process_group()
 
 
-def _run(world, backend, wiener, exchange):
+def _run(world, backend, wiener, exchange, ntracks=50):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, wiener, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, wiener, exchange, ntracks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=1500) for _ in procs)
@@ -109,6 +128,40 @@ def test_testset50_one_rank_with_the_exchange_machinery_on(wiener, exchange):
 @pytest.mark.parametrize("wiener,exchange", [(False, "sendrecv"), (True, "allgather")])
 def test_testset50_two_gloo_ranks_on_one_device(wiener, exchange):
     _run(2, "gloo", wiener, exchange)
+
+
+@pytest.mark.parametrize("wiener,exchange", [(False, "sendrecv"), (True, "allgather")])
+def test_testset_eight_gloo_ranks_on_one_device(wiener, exchange):
+    """the world size the north star ends at.  Eight spawned ranks share device 0 over gloo (RCCL
+    refuses several ranks per device), the real Separator, the first 16 tracks of the set (72 work items: three rounds per
+    rank, stacked passes and tails, rows owned by every rank): bitwise against per-track Separator.forward on every rank,
+    identical replica checksums."""
+    _run(8, "gloo", wiener, exchange, ntracks=16)
+
+
+def test_testset_four_gloo_ranks_on_one_device():
+    _run(4, "gloo", False, "sendrecv", ntracks=12)
+
+
+def test_bench_gpus8_child_process_prints_one_verified_line():
+    """Item 1(c): `python bench.py --gpus 8 --workload testset50 --tracks 16` as the driver starts it, eight ranks over gloo
+    on the one device of the test box; started from a process that has not touched the GPU."""
+    env = dict(os.environ, XSQ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "testset50", "--tracks", "16",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["n_gpus"] == 8 and d["steps"] == 1
+    assert d["value"] > 0
+    assert d["verified"]["bitwise"] is True and len(d["verified"]["tracks"]) >= 3
+    c = d["collective"]
+    assert c["world"] == 8 and c["replicas"]["identical_on_all_ranks"] is True and len(c["devices"]) == 8
+    assert c["exchange"] == "sendrecv-inplace"
+    assert "single_rank_same_workload" in d["variants"]
 
 
 def test_bench_gpus2_testset50_child_process_prints_one_verified_line():

@@ -103,6 +103,7 @@ _SIGS = {
     "xsq_comm_unique_id": (C.c_int, [_vp]),
     "xsq_comm_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "xsq_comm_destroy": (C.c_int, [_vp]),
+    "xsq_comm_abort": (C.c_int, [_vp]),
     "xsq_exchange_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int, _vp]),
     "xsq_profile_enable": (C.c_int, [C.c_int]),
     "xsq_profile_reset": (C.c_int, []),

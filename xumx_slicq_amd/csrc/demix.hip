@@ -41,9 +41,9 @@ struct PassPlan {
 struct ForwardPlan {
     std::vector<PassPlan> passes;
     int64_t* d_tables = nullptr;     // one allocation behind all d_xrows / d_orows
-    int64_t* h_tables = nullptr;     // pinned host copy: uploaded with hipMemcpyAsync on the first call's stream (no host stall per new shape)
+    int64_t* h_tables = nullptr;     // pinned host copy: uploaded when the plan is made, on the demixer's own copy stream (no device-wide stall)
     size_t table_words = 0;
-    bool uploaded = false;
+    bool pinned = false;             // a HIP graph captured a call of this shape: its nodes hold d_xrows / d_orows, never evicted
     uint64_t last_use = 0;           // LRU stamp (xsq_demixer::clock)
     size_t main_bytes = 0, tail_bytes = 0;
     size_t ext_floats = 0;           // window-maximum tables of the split sets (zeroed at the start of every call)
@@ -64,6 +64,7 @@ struct xsq_demixer {
     uint64_t clock = 0;
     static constexpr size_t kMaxPlans = 64;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t up_stream = nullptr;     // row-table uploads: a non-blocking stream of its own, waited for on the host per NEW shape
 };
 
 namespace {
@@ -210,14 +211,18 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     if (it != d->plans.end()) { it->second.last_use = ++d->clock; *out = &it->second; return XSQ_OK; }
     if (d->plans.size() >= xsq_demixer::kMaxPlans) {
         // evict the least recently used shape.  Its tables may still be read by kernels in flight (any stream): wait for the
-        // device once -- this happens once per kMaxPlans NEW shapes, never in a steady loop over known shapes.
-        auto victim = d->plans.begin();
+        // device once -- this happens once per kMaxPlans NEW shapes, never in a steady loop over known shapes.  Shapes a HIP
+        // graph has captured are never victims (a replay reads the tables without coming through here: ADVICE round 5);
+        // when every cached shape is pinned the cache simply grows.
+        auto victim = d->plans.end();
         for (auto p = d->plans.begin(); p != d->plans.end(); ++p)
-            if (p->second.last_use < victim->second.last_use) victim = p;
-        XSQ_HIP(hipDeviceSynchronize());
-        (void)hipFree(victim->second.d_tables);
-        (void)hipHostFree(victim->second.h_tables);
-        d->plans.erase(victim);
+            if (!p->second.pinned && (victim == d->plans.end() || p->second.last_use < victim->second.last_use)) victim = p;
+        if (victim != d->plans.end()) {
+            XSQ_HIP(hipDeviceSynchronize());
+            (void)hipFree(victim->second.d_tables);
+            (void)hipHostFree(victim->second.h_tables);
+            d->plans.erase(victim);
+        }
     }
     const int64_t min_samples = P->L / 2 + 1;                      // separator.py:162
     const int cap = d->max_item_slices > 0 ? d->max_item_slices : default_max_item_slices(P);
@@ -274,6 +279,18 @@ static int get_forward_plan(xsq_demixer* d, const xsq_model* Mo, int nb, int64_t
     }
     fp.main_bytes += al256(fp.ext_floats * 4);
     fp.last_use = ++d->clock;
+    // The tables are on the device before the plan is visible to any caller (any thread, any stream, eager or capturing):
+    // copied on the demixer's own non-blocking stream and waited for on the host -- microseconds per NEW shape, no wait for
+    // other streams' work.  A plan cannot be made while a stream of this thread is capturing in global mode (the wait is
+    // refused): size the call first (xsq_separator_workspace), then capture.
+    hipError_t ue = hipMemcpyAsync(fp.d_tables, fp.h_tables, fp.table_words * sizeof(int64_t), hipMemcpyHostToDevice, d->up_stream);
+    if (ue == hipSuccess) ue = hipStreamSynchronize(d->up_stream);
+    if (ue != hipSuccess) {
+        (void)hipFree(fp.d_tables); (void)hipHostFree(fp.h_tables);
+        set_error("xsq_separator_forward: upload of the row tables of a new call shape -> %s (a new shape cannot be planned during "
+                  "stream capture: call xsq_separator_workspace for it first)", hipGetErrorString(ue));
+        return XSQ_ERR_HIP;
+    }
     auto ins = d->plans.emplace(key, fp);
     *out = &ins.first->second;
     return XSQ_OK;
@@ -290,6 +307,7 @@ int xsq_demixer_create(xsq_demixer** out, xsq_plan* plan) {
     for (const BlockHost& b : plan->blocks) { d->F.push_back(b.F); d->T.push_back(b.T); }
     hipError_t e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("xsq_demixer_create: hipEventCreate -> %s", hipGetErrorString(e));
         delete d;
@@ -304,6 +322,7 @@ int xsq_demixer_destroy(xsq_demixer* d) {
     for (auto& kv : d->plans) { (void)hipFree(kv.second.d_tables); (void)hipHostFree(kv.second.h_tables); }
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+    if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
     delete d;
     return XSQ_OK;
 }
@@ -393,10 +412,8 @@ static int separator_forward_impl(xsq_demixer* d, xsq_model* Mo, const float* au
         std::lock_guard<std::mutex> lk(d->mu);
         int rc = get_forward_plan(d, Mo, nb, N, cs, max_stack, wiener ? 1 : 0, &fp);
         if (rc) return rc;
-        if (!fp->uploaded) {             // first call of this shape: the row tables go up on the call's own stream, in front of its kernels
-            XSQ_HIP(hipMemcpyAsync(fp->d_tables, fp->h_tables, fp->table_words * sizeof(int64_t), hipMemcpyHostToDevice, main));
-            fp->uploaded = true;
-        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) fp->pinned = true;
     }
     bool any_tail = false;
     for (const PassPlan& p : fp->passes) any_tail = any_tail || p.tail;

@@ -31,6 +31,7 @@ struct Rccl {
     int (*GetUniqueId)(nccl_uid*) = nullptr;
     int (*CommInitRank)(nccl_comm_t*, int, nccl_uid, int) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*CommAbort)(nccl_comm_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -68,6 +69,7 @@ static int load_rccl(const char* path) {
     XSQ_SYM(GetUniqueId, "ncclGetUniqueId")
     XSQ_SYM(CommInitRank, "ncclCommInitRank")
     XSQ_SYM(CommDestroy, "ncclCommDestroy")
+    XSQ_SYM(CommAbort, "ncclCommAbort")
     XSQ_SYM(Send, "ncclSend")
     XSQ_SYM(Recv, "ncclRecv")
     XSQ_SYM(GroupStart, "ncclGroupStart")
@@ -134,6 +136,16 @@ int xsq_comm_create(xsq_comm** out, const void* id128, int world, int rank) {
 int xsq_comm_destroy(xsq_comm* c) {
     if (!c) return XSQ_OK;
     if (c->comm) g_rccl.CommDestroy(c->comm);
+    delete c;
+    return XSQ_OK;
+}
+
+// Tears the communicator down WITHOUT waiting for queued operations (ncclCommAbort): what a rank calls when the ranks have
+// voted that an exchange did not get queued everywhere -- receives whose sender never arrives would otherwise hold the
+// stream for ever.  The handle is freed.
+int xsq_comm_abort(xsq_comm* c) {
+    if (!c) return XSQ_OK;
+    if (c->comm) g_rccl.CommAbort(c->comm);
     delete c;
     return XSQ_OK;
 }

@@ -1,26 +1,35 @@
-"""Sharding of demix work across the GPUs of one node.
+"""Sharding of demix work across the GPUs of one node (BASELINE configs[3]).
 
-The reference is single-process; its chunk loop (separator.py:153-229) carries
-no state from one chunk to the next and ends in a hard ``torch.cat``
-(separator.py:231), so tracks -- and, inside a track, (track, chunk) pairs -- are
-independent work items.  Two levels, one process per GPU:
+The reference is single-process; its chunk loop (separator.py:147-158) carries no state from one
+chunk to the next and ends in a hard ``torch.cat`` (separator.py:229-231), so (track, chunk) pairs
+are independent work items.  One process per GPU; what this file holds, top down:
 
-* ``demix_tracks`` (default, what ``bench.py --gpus N`` runs): whole tracks are dealt to
-  ranks longest-first; a rank runs ``Separator.forward`` on its tracks (full chunks stacked
-  along the batch axis) and keeps their stems.  No data-path collective: at ~9 ms per 240 s
-  track an all-gather of everybody's stems (339 MB per track) would cost several times the
-  compute, and nothing downstream needs every rank to hold every track.
-* ``demix_sharded``: (track, chunk) items dealt longest-first for batches whose track lengths
-  do not balance; the exchange step is an all-gather of the finished stems (RCCL over xGMI
-  with the ``nccl`` backend), issued ``async_op=True`` per round so it overlaps the next
-  round's kernels.  Chunks are never merged into one Wiener batch across tracks' statistics
-  (the window maximum spans the batch dimension).
-* ``ShardedDemixer`` (BASELINE configs[3], what ``bench.py --gpus N`` runs for N > 1): the same
-  (track, chunk) items, but a rank runs its full-size chunks STACKED along the batch axis through
-  ``Separator.demix_into`` (the pass shape of the single-GPU headline), the kernels write the stems
-  straight into a packed per-round send buffer, one ``all_gather_into_tensor`` per round runs
-  beside the next round's kernels, and a placement step copies every item into its track's
-  ``(4, nb_samples, 2, N_t)`` tensor -- the final waveform concat of separator.py:231.
+* ``ShardedDemixer`` -- what ``bench.py --gpus N`` runs for N > 1 and ``--workload testset50``.
+  ``ShardPlan`` (identical on every rank, no communication) deals the items longest-first to the
+  ranks and cuts every rank's queue into rounds of ``stack`` items; the equal-length (full-size)
+  items of a round form ONE stacked pass through ``Separator.demix_into`` (the pass shape of the
+  single-GPU headline), the short tails of the tracks go out first on a side stream.  Every rank
+  holds the SAME flat per-track allocation (``flat``; track t = ``(4, nb, 2, N_t)`` at
+  ``track_off[t]``, int64 element offsets) and the kernels write a rank's own rows straight into
+  their final place -- that IS the waveform concat of separator.py:231.
+* The exchange (``exchange="sendrecv"``, default): one ``RowExchange.exchange`` per pass kind and
+  round on an exchange stream, beside the next pass's kernels.  The owner of a row ``ncclSend``s
+  it to every peer, every other rank ``ncclRecv``s it at the same offset (``xsq_exchange_rows``,
+  csrc/exchange.hip: grouped point-to-point over xGMI, no packing buffer, no placement pass; the
+  library's own communicator on the RCCL build torch loaded).  ``exchange="allgather"``: the
+  kernels write into this rank's slice of a per-exchange block, one in-place
+  ``all_gather_into_tensor`` per pass kind and round, one ``xsq_place_rows`` launch per exchange
+  moves the rows into ``flat``.  Which of the two runs is a COLLECTIVE decision (``RowExchange``
+  construction, ``ShardedDemixer.settle``): all ranks exchange in place, or all fall back
+  (``fallback=True``), or all raise ``ExchangeUnavailable``.
+* With the ``gloo`` backend (CPU tests; several ranks sharing the one GPU of a test box, which RCCL
+  refuses) the same rows travel host-staged: functional path only.
+* ``demix_sharded`` / ``demix_tracks``: the simple forms (one item or one whole track per rank and
+  round, ``all_gather_into_tensor`` of padded blocks).  Kept for callers without a ``Separator``
+  that has ``demix_into``; ``bench.py`` does not run them.
+
+Chunks of different tracks are never merged into one Wiener batch statistic: the window maximum is
+taken per item (``group`` argument of ``demix_into``).
 """
 from __future__ import annotations
 
@@ -201,6 +210,16 @@ def all_ranks_ok(ok: bool, group=None, dev: Optional[torch.device] = None, world
     return bool(int(t.item()))
 
 
+def checksum_int32(flat: Tensor, piece: int = 1 << 26) -> int:
+    """Exact integer checksum of a float32 tensor's BITS (sum of its words read as int32, in int64), taken in pieces: the
+    int64 widening of a whole 4.8 G-float stem allocation would be a 38 GB temporary."""
+    words = flat.reshape(-1).view(torch.int32)
+    total = 0
+    for o in range(0, words.numel(), piece):
+        total += int(words[o:o + piece].sum(dtype=torch.int64).item())
+    return total
+
+
 _ROW_EXCHANGES: Dict[tuple, "RowExchange"] = {}
 
 
@@ -299,6 +318,9 @@ class RowExchange:
         """table: numpy int64 (nrows, 4) = (owner, src offset, dst offset, length), identical on every rank.  Asynchronous
         on the current stream (RCCL); ``dst`` defaults to ``flat`` (in place)."""
         dst = flat if dst is None else dst
+        import os
+        if os.environ.get("XSQ_FAULT_INJECT", "") in ("exchange:all", f"exchange:{self.rank}"):     # tests only (see __init__)
+            raise RuntimeError("injected fault at the exchange's enqueue")
         if self.comm is not None:
             from . import _lib
             _lib.check(_lib.lib.xsq_exchange_rows(self.comm, flat.data_ptr(), flat.numel(), dst.data_ptr(), dst.numel(),
@@ -323,6 +345,14 @@ class RowExchange:
         if self.comm is not None:
             from . import _lib
             _lib.lib.xsq_comm_destroy(self.comm)
+            self.comm = None
+
+    def abort(self):
+        """ncclCommAbort: give the communicator up without waiting for what is queued on it (``ShardedDemixer.settle``)."""
+        self.closed = True
+        if self.comm is not None:
+            from . import _lib
+            _lib.lib.xsq_comm_abort(self.comm)
             self.comm = None
 
     def __del__(self):
@@ -481,25 +511,44 @@ class ShardedDemixer:
                 self._place[key] = self._place_table(*key)
 
     def settle(self) -> Optional[str]:
-        """One warm-up step whose OUTCOME the ranks agree on: a rank whose first in-place exchange raised (a refused table,
-        an RCCL enqueue error) reports it through an all-reduce (MIN) instead of leaving its peers in another mode.  With
-        ``fallback`` every rank then rebuilds the all-gather form together; without it every rank raises.  Returns
-        ``exchange_note`` (None = the chosen exchange ran).  (What this cannot catch: a rank that dies INSIDE a grouped
-        exchange its peers have already queued -- their kernels wait on the device, not on the host.)"""
+        """One warm-up step whose OUTCOME the ranks agree on.  The vote comes BEFORE any rank blocks: ``run()`` only queues
+        work, so each rank knows on the host whether its sends / receives were accepted (a refused table, an RCCL enqueue
+        error raise out of ``xsq_exchange_rows``), and an all-reduce (MIN) of that flag -- on a side stream with the
+        ``nccl`` backend, so it does not queue behind the exchange it is voting about -- decides.  All ranks queued it:
+        synchronize and vote once more on the outcome.  Somebody did not: peers may hold receives whose sender never
+        arrives, so every rank ABORTS the communicator (``xsq_comm_abort``) instead of waiting, then all fall back to the
+        all-gather form together (``fallback``) or all raise ``ExchangeUnavailable``.  Returns ``exchange_note`` (None =
+        the chosen exchange ran).  (Not recoverable: a rank that dies outright -- that is the process group's timeout.)"""
         if not (self.gather and self.exchange == "sendrecv"):
             return self.exchange_note
-        err = None
+        grp = self.group if self._live else None
+        err, stage = None, "enqueue"
         try:
             self.run()
-            if self.dev.type == "cuda":
-                torch.cuda.synchronize(self.dev)
         except Exception as e:                                 # noqa: BLE001 -- reported through the collective decision
             err = e
-        if all_ranks_ok(err is None, self.group if self._live else None, self.dev, self.world):
-            return self.exchange_note
+        if self.dev.type == "cuda":
+            if getattr(self, "_vote_stream", None) is None:
+                self._vote_stream = torch.cuda.Stream(device=self.dev)
+            with torch.cuda.stream(self._vote_stream):
+                queued = all_ranks_ok(err is None, grp, self.dev, self.world)
+        else:
+            queued = all_ranks_ok(err is None, grp, self.dev, self.world)
+        if queued:
+            stage = "completion"
+            try:
+                if self.dev.type == "cuda":
+                    torch.cuda.synchronize(self.dev)
+            except Exception as e:                             # noqa: BLE001
+                err = e
+            if all_ranks_ok(err is None, grp, self.dev, self.world):
+                return self.exchange_note
+        if self._rowx is not None:
+            self._rowx.abort()
         if not self.fallback:
-            raise ExchangeUnavailable(f"the first in-place exchange failed on at least one rank (this rank: {err!r})")
-        self.exchange_note = "first sendrecv-inplace exchange failed on at least one rank (this rank: %r); every rank fell back to allgather+place" % (err,)
+            raise ExchangeUnavailable(f"the first in-place exchange failed at {stage} on at least one rank (this rank: {err!r})")
+        self.exchange_note = ("first sendrecv-inplace exchange failed at %s on at least one rank (this rank: %r); every rank "
+                              "aborted the communicator and fell back to allgather+place" % (stage, err))
         self.exchange = "allgather"
         self._setup_exchange()
         return self.exchange_note
