@@ -48,6 +48,9 @@ typedef struct xsq_model xsq_model;
 /* ---- library ---------------------------------------------------------------- */
 int xsq_abi_version(void);
 const char* xsq_last_error(void);
+/* How this library was built: "arch=<offload arch>; flags=<the Makefile's EXTRA and NOPK>; date=<__DATE__ __TIME__>" -- a
+ * diagnostic build (ablation / stamp macros) says so here, and bench.py copies the string into its JSON line. */
+const char* xsq_build_info(void);
 
 /* ---- sliCQT plan ---------------------------------------------------------------
  * Replaces the plan objects built by NSGT_sliced.__init__ (nsgt/slicq.py:70-151):

@@ -132,7 +132,8 @@ def blockwise_wiener(X: torch.Tensor, Ymag: torch.Tensor,
 
 
 def unmix(sd: Dict[str, torch.Tensor], X_list: List[torch.Tensor],
-          causal: bool, wiener: bool, training: bool = False, minima=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+          causal: bool, wiener: bool, training: bool = False, minima=None,
+          masks: List[torch.Tensor] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """model.py:69-82 (Unmix.forward, return_masks=True).
 
     ``causal`` selects _CausalConv2d for layer 1 (the reference's
@@ -142,10 +143,10 @@ def unmix(sd: Dict[str, torch.Tensor], X_list: List[torch.Tensor],
     BASELINE config 2 is offline conv stack + phasemix, reachable there by
     flipping ``.realtime`` on the built blocks.
     """
-    Ys, masks = [], []
-    for b, X in enumerate(X_list):
+    given, (Ys, masks) = masks, ([], [])       # ``masks``: reuse the CDAE output of an earlier call on the same X (the
+    for b, X in enumerate(X_list):           # other post-filter on the same masks: oracle/separator.py separate_both)
         mag = abs_of_real_complex(X)
-        m = cdae_masks(sd, b, mag, causal, training, minima)
+        m = given[b] if given is not None else cdae_masks(sd, b, mag, causal, training, minima)
         Ymag = m * mag
         Ys.append(blockwise_wiener(X, Ymag) if wiener else phasemix_sep(X, Ymag))
         masks.append(m)

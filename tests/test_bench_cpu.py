@@ -96,3 +96,42 @@ def test_issue_bound_of_the_bench_track():
         assert 0.80 < d[k][0] < 0.95          # ms: the direct kernels measured 1.00 ms = ~0.9 of this bound
     assert abs(bench.executed_mfma_flops(plan, 1, items, "cdae_l3_slab", True) / 1e9 - 72.9) < 0.5     # against 112.3 GFLOP algorithmic
     assert bench.executed_mfma_flops(plan, 1, items, "cdae_l1_gemm", True) is None
+
+
+def test_roofline_issue_covers_the_whole_step():
+    """every kernel of the step carries a vector-issue bound -- the MFMA kernels from the static
+    instruction budget, the slice FFTs from the dynamic SQ_INSTS_VALU of the committed PMC pass -- and the table says what
+    share of the step's kernel time it covers (>= 95 %)."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_bench.json")) if "testset" not in f and "gpus" not in f and "wiener" not in f)
+    d = json.load(open(files[-1]))
+    prof = {k: (v["ms_per_step"], v["launches_per_step"]) for k, v in d["kernels"].items()}
+    plan = build_plan()
+    items = [2621440] * 4 + [10584000 - 4 * 2621440]
+    table = bench.roofline_issue_table(bench.issue_bound(plan, 1, items, winograd=True), prof, 1)
+    cov = table[-1]
+    assert "coverage" in cov and cov["coverage"] >= 0.95, cov
+    rows = {r["kernel"]: r for r in table[:-1]}
+    for k in ("slice_rfft", "slice_irfft_ola"):
+        assert rows[k]["source"].startswith("pmc") and 0.4 < rows[k]["frac_of_issue_bound"] < 1.0
+        assert abs(rows[k]["t_issue_bound_ms"] - rows[k]["frac_of_issue_bound"] * rows[k]["ms_per_step"]) < 1e-3
+    for k in ("cdae_l2_slab", "cdae_l1_gemm", "band_synthesis_dft4"):
+        assert rows[k]["source"] == "isa" and 0.3 < rows[k]["frac_of_issue_bound"] < 1.0
+
+
+def test_provenance_records_what_selected_the_kernels(monkeypatch):
+    """`env` / `library` / `nondefault` of the JSON line: a stray XSQ_* switch or a diagnostic library must show up."""
+    for k in [k for k in os.environ if k.startswith("XSQ_")]:
+        monkeypatch.delenv(k)
+    p = bench.provenance()
+    assert p["env"] == {"xsq": {}, "selecting_kernels_or_paths": []} and p["nondefault"] is False
+    assert p["library"]["abi"] == 2 and p["library"]["default_path"] and "arch=gfx950" in p["library"]["build"]
+    assert "no-packed-fp32-ops" in p["library"]["build"]
+    monkeypatch.setenv("XSQ_DIST_BACKEND", "gloo")                 # transport only: recorded, not flagged
+    p = bench.provenance()
+    assert p["env"]["xsq"] == {"XSQ_DIST_BACKEND": "gloo"} and p["nondefault"] is False
+    monkeypatch.setenv("XSQ_D4_SYM", "0")                          # selects another band kernel: flagged
+    p = bench.provenance()
+    assert p["env"]["selecting_kernels_or_paths"] == ["XSQ_D4_SYM"] and p["nondefault"] is True

@@ -166,6 +166,18 @@ def test_inference_separate_and_cli(tmp_path, seps):
         y, rate = A.load_audio(str(tmp_path / "out" / "clip" / f"{t}.wav"))
         assert rate == 44100 and y.shape == (2, 30000)
         assert float((y - est2[t][0].cpu()).abs().max()) < 1e-6
+    # the pipelined loop (default: decode | H2D | demix | GPU interleave | D2H | encode overlapped across tracks, pinned
+    # buffers reused) writes the same files as the reference's one-track-at-a-time loop (--serial), for tracks of different
+    # lengths in any order
+    for i, n in enumerate((52000, 30000, 70001, 30000, 9031)):
+        A.save_wav_float(str(tmp_path / "in" / f"t{i}.wav"), synth_audio(n, seed=300 + i)[0], 44100)
+    inference_main(["--input-dir", str(tmp_path / "in"), "--output-dir", str(tmp_path / "piped")])
+    inference_main(["--input-dir", str(tmp_path / "in"), "--output-dir", str(tmp_path / "serial"), "--serial"])
+    for w in sorted((tmp_path / "in").glob("*.wav")):
+        for t in ("bass", "vocals", "other", "drums"):
+            a = (tmp_path / "piped" / w.stem / f"{t}.wav").read_bytes()
+            b = (tmp_path / "serial" / w.stem / f"{t}.wav").read_bytes()
+            assert a == b and len(a) > 44, (w.name, t)
 
 
 @pytest.mark.parametrize("name", ["offline_phasemix", "offline_wiener"])
@@ -611,19 +623,24 @@ def test_graph_cache_follows_parameter_and_postfilter_changes(seeded_sd):
     assert c._handles == {} and sep.xumx_model._handles
 
 
-_FULL_SIZE_ORACLE = {}       # wiener -> the oracle's stems of the bench track (~2 minutes of host CPU each, shared by the modes)
+_FULL_SIZE_ORACLE = {}       # wiener -> the oracle's stems of the bench track, shared by the four parametrisations
 
 
 def _full_size_oracle(oracle_plan, seeded_sd, x, wiener):
+    """Both post-filters from one oracle pass (oracle/separator.py separate_both: ~2 minutes of host CPU), computed by the
+    background job tests/conftest.py started at collection (oracle/precompute.py fullsize) or inline."""
     import os
-    from oracle import separator as osep
-    if wiener not in _FULL_SIZE_ORACLE:
-        old = torch.get_num_threads()
-        torch.set_num_threads(max(old, min(32, os.cpu_count() or 1)))
-        try:
-            _FULL_SIZE_ORACLE[wiener] = osep.separate(oracle_plan, seeded_sd, x, causal=False, wiener=wiener)
-        finally:
-            torch.set_num_threads(old)
+    from conftest import precomputed
+    from oracle import precompute
+    if not _FULL_SIZE_ORACLE:
+        def inline():
+            old = torch.get_num_threads()
+            torch.set_num_threads(max(old, min(32, os.cpu_count() or 1)))
+            try:
+                return precompute.fullsize(oracle_plan, seeded_sd)
+            finally:
+                torch.set_num_threads(old)
+        _FULL_SIZE_ORACLE.update(precomputed("fullsize", inline))
     return _FULL_SIZE_ORACLE[wiener]
 
 
@@ -636,7 +653,9 @@ def test_full_size_track_matches_the_oracle(seps, oracle_plan, seeded_sd, name, 
     literal chunk loop (phase.py:43-59 at 85,264 frames, norbert/__init__.py:257).  ~1-2 minutes of host CPU
     per configuration (once per post-filter).  Bar: 1e-4 RMS / 1e-3 max-abs (BASELINE.json).  The bf16x6 contraction
     mode (bench.py's fp32-grade variant) is held to the same oracle at the same size."""
+    from oracle import precompute
     n = 10_584_000
+    assert (n, 20260101) == (precompute.FULL_N, precompute.FULL_SEED)
     sep = seps[name]
     sep.chunk_size = 2621440
     x = synth_audio(n, seed=20260101)

@@ -150,7 +150,7 @@ def test_bench_gpus8_child_process_prints_one_verified_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "testset50", "--tracks", "16",
                         "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
                        timeout=1500, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, "\n".join([ln for ln in r.stderr.splitlines() if "Error" in ln][:6]) + "\n...\n" + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
@@ -172,7 +172,7 @@ def test_bench_gpus2_testset50_child_process_prints_one_verified_line():
     env = dict(os.environ, XSQ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "testset50", "--steps", "1",
                         "--warmup", "1", "--no-variants"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, "\n".join([ln for ln in r.stderr.splitlines() if "Error" in ln][:6]) + "\n...\n" + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])

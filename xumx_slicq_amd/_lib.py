@@ -42,6 +42,7 @@ _i64p = C.POINTER(C.c_int64)
 _SIGS = {
     "xsq_abi_version": (C.c_int, []),
     "xsq_last_error": (C.c_char_p, []),
+    "xsq_build_info": (C.c_char_p, []),
     "xsq_plan_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "xsq_plan_destroy": (C.c_int, [_vp]),
     "xsq_plan_num_blocks": (C.c_int, [_vp]),
@@ -119,6 +120,18 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 EXPORTED = tuple(_SIGS)
+
+
+def build_info() -> dict:
+    """What is loaded: path, ABI version, the library's own build string (xsq_build_info)."""
+    return {"path": LIB_PATH, "default_path": LIB_PATH == os.path.join(_HERE, "libxumx_slicq_hip.so"),
+            "abi": int(lib.xsq_abi_version()), "build": (lib.xsq_build_info() or b"").decode("utf-8", "replace")}
+
+
+def xsq_environment() -> dict:
+    """Every XSQ_* variable set in this process: most of them select kernels, fusions or diagnostic paths (csrc getenv,
+    separator.py / model.py / transforms.py switches).  bench.py records them and flags a line measured with any."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("XSQ_")}
 
 
 def last_error() -> str:

@@ -97,6 +97,21 @@ def save_wav_float(path: str, audio: torch.Tensor, rate: int) -> None:
         f.write(struct.pack("<4sI", b"data", len(data)) + data)
 
 
+def save_wav_float_interleaved(path: str, frames: torch.Tensor, rate: int) -> None:
+    """(samples, channels) float32 ALREADY in the payload's order (the pipelined CLI interleaves on the GPU): header +
+    one write of the tensor's memory, no host-side transpose or copy."""
+    a = frames.detach()
+    assert a.device.type == "cpu" and a.dtype == torch.float32 and a.dim() == 2 and a.is_contiguous()
+    n, channels = a.shape
+    nbytes = n * channels * 4
+    fmt = struct.pack("<HHIIHH", 3, channels, int(rate), int(rate) * channels * 4, channels * 4, 32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sI4s", b"RIFF", 4 + 8 + len(fmt) + 8 + nbytes, b"WAVE"))
+        f.write(struct.pack("<4sI", b"fmt ", len(fmt)) + fmt)
+        f.write(struct.pack("<4sI", b"data", nbytes))
+        f.write(memoryview(a.numpy()).cast("B"))
+
+
 def preprocess_audio(audio: torch.Tensor, rate: Optional[float] = None,
                      model_rate: Optional[float] = None) -> torch.Tensor:
     """data.py:98-156: any of (T,), (C,T), (T,C), (B,C,T) -> (nb_samples, 2, T).

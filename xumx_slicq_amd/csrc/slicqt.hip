@@ -452,6 +452,14 @@ using namespace xsq;
 extern "C" {
 
 int xsq_abi_version(void) { return XSQ_ABI_VERSION; }
+
+#ifndef XSQ_BUILD_ARCH
+#define XSQ_BUILD_ARCH "unknown"
+#endif
+#ifndef XSQ_BUILD_FLAGS
+#define XSQ_BUILD_FLAGS ""
+#endif
+const char* xsq_build_info(void) { return "arch=" XSQ_BUILD_ARCH "; flags=" XSQ_BUILD_FLAGS "; date=" __DATE__ " " __TIME__; }
 const char* xsq_last_error(void) { return g_err; }
 
 static int plan_build(xsq_plan* P, int L, int tr, int nbands, const int32_t* Lg, const int32_t* c,
