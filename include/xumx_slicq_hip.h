@@ -180,11 +180,15 @@ int xsq_model_destroy(xsq_model* model);
  *      product, one fp32 rounding -- measured as close to the torch-cpu reference as mode 0
  *      (1.1e-7 RMS), 6/16 of the matrix-pipe time.                                              */
 int xsq_model_set_precision(xsq_model* model, int mode);
-/* fp32 inference, layers 2 / 3 (the 4-tap time convolutions of model.py:140-170), rows of >= 127 time positions: 1 (default) =
- * Winograd F(2, 4) along the time taps (csrc/cdae_wino.h: five MFMA products per output pair and channel pair instead of
- * eight; input transform with integer coefficients in registers, weights transformed on the host in fp64; ~2e-7 RMS of a
- * layer's output against fp64 where the direct fp32 sum has ~7e-8), 0 = the direct slab kernels (csrc/cdae_slab.h).  The
- * split-bf16 modes and shorter rows always take the direct kernels.                                                   */
+/* Fast-convolution forms of the fp32 inference layers, a bit mask (default 3 = both):
+ *   1  layers 2 / 3 (the 4-tap time convolutions of model.py:140-170), rows of >= 127 time positions: Winograd F(2, 4) along
+ *      the time taps (csrc/cdae_wino.h: five MFMA products per output pair and channel pair instead of eight; input transform
+ *      with integer coefficients in registers, weights transformed on the host in fp64; ~2e-7 RMS of a layer's output against
+ *      fp64 where the direct fp32 sum has ~7e-8).  Without the bit: the direct slab kernels (csrc/cdae_slab.h).
+ *   2  layer 1 (model.py:130-139, non-causal): F(2, 2) along the hop (csrc/cdae_l1f.h: the strided (kf, W) convolution is a
+ *      two-tap convolution in units of the hop -- three half-window products per output pair instead of four, W0 + W1 summed
+ *      on the host in fp64).  Without the bit: the implicit GEMM (CdaeL1Op).
+ * The split-bf16 modes, the causal first layer and (bit 1) shorter rows always take the direct kernels.                  */
 int xsq_model_set_winograd(xsq_model* model, int on);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)

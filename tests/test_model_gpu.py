@@ -45,6 +45,38 @@ def test_cdae_masks_match_golden(seps):
             assert abs(float(a.sum()) - sums[i][0]) < 1e-5 * masks[i].numel() + 1e-3, (tag, i)
 
 
+@pytest.mark.parametrize("n,nb", [(9031, 1), (70000, 3), (650_000, 2)])
+def test_layer1_f22_along_the_hop_matches_the_implicit_gemm(seps, n, nb):
+    """Layer 1 as F(2, 2) along the hop (csrc/cdae_l1f.h, bit 2 of xsq_model_set_winograd; model.py:130-139) against the
+    implicit GEMM (CdaeL1Op) on every one of the 70 x 4 masks: S = 3 (three pairs per row: a 64-pair tile covers many
+    (b, f1) rows, most of its pairs do not exist), S = 9 with a batch of three, and S = 74.  T1 = 2 S - 1 is odd: the last
+    pair of every row has a phantom second output that would land on the NEXT row's first one.  Blocks with hop % 4 == 2
+    exercise the padded K order, blocks with 3 and 5 frequency taps the segment cursor.  Only layer 1 differs between the
+    arms (layers 2 / 3 stay on the same kernels): masks within 2e-6, and not bitwise equal (it IS another kernel)."""
+    sep = seps["offline_phasemix"]
+    m = sep.xumx_model
+    x = synth_audio(n, seed=88, nb_samples=nb).cuda()
+    X = sep.nsgt(x)
+    try:
+        m.set_winograd(1)
+        _, direct = m(X, return_masks=True)
+        direct = [d.clone() for d in direct]
+        m.set_winograd(3)
+        _, fast = m(X, return_masks=True)
+        fast = [f.clone() for f in fast]
+        _, again = m(X, return_masks=True)
+    finally:
+        m.set_winograd(True)
+    worst, differs = 0.0, False
+    for i in range(70):
+        assert torch.equal(fast[i], again[i]), i
+        assert bool(torch.isfinite(fast[i]).all())
+        worst = max(worst, float((fast[i] - direct[i]).abs().max()))
+        differs = differs or not torch.equal(fast[i], direct[i])
+    print(f"layer-1 F(2, 2) vs implicit GEMM, n = {n}, batch {nb}: max mask difference {worst:.2e}")
+    assert differs and worst < 2e-6, worst
+
+
 def test_phasemix_is_mask_times_mix(seps):
     n = 50000
     x = synth_audio(n, seed=11).cuda()

@@ -584,6 +584,7 @@ struct CdaeL4Op {
 }  // namespace xsq
 #include "cdae_slab.h"
 #include "cdae_wino.h"
+#include "cdae_l1f.h"
 namespace xsq {
 
 // ------------------------------------------------------------------------------------------
@@ -735,6 +736,42 @@ static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
     return XSQ_OK;
 }
 
+// tiles of the layer-1 F(2, 2) kernel (cdae_l1f.h): 64 consecutive output PAIRS of one batch item in the flattened (f1, pair)
+// space; the four targets of a patch adjacent (they read the same whitened magnitudes: the re-reads hit the XCD's L2)
+static int get_l1f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(1 + 160, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = 2 * S - 1, P = (T1 + 1) / 2;
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].nch1 > Mo->blocks[y].nch1; });
+    std::vector<L1fTileDev> t;
+    for (int b : order) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        L1fTileDev e;
+        e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.nchunks = d.nch1; e.P = P;
+        e.in_off = (int64_t)Bn * 2 * S * d.cum;
+        const int perb = d.F1 * P;
+        for (int bi = 0; bi < Bn; ++bi)
+            for (int Q = 0; Q < perb; Q += LF_PAIRS)
+                for (int tgt = 0; tgt < NT; ++tgt) {
+                    e.Q0 = Q; e.b = bi;
+                    e.out_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
+                    e.shift_off = d.s1[tgt]; e.u_off = d.u1[tgt];
+                    t.push_back(e);
+                }
+    }
+    TileTable tt;                    // (d_tiles holds L1fTileDev entries for this key: cast at the launch site)
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc((void**)&tt.d_tiles, t.size() * sizeof(L1fTileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(L1fTileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace xsq
@@ -817,6 +854,27 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                 pool[d.s1[t] + co] = (float)((double)bb[co] - (double)rm[co] * s);
                 for (int k = 0; k < K1; ++k)       // k = (ci*kf + df)*W + dt, the weight's own order
                     pool[d.w1[t] + (size_t)co * d.ld1 + k] = (float)((double)w[(size_t)co * K1 + k] * s);
+            }
+            // ---- F(2, 2) along the hop (cdae_l1f.h): per chunk of 16 k the three tiles W0 | W0 + W1 | W1 of the FOLDED fp32
+            //      weights above; k order = (segment (ci, df), d < hop) with every segment padded to whole quads (zero weights)
+            {
+                d.nch1 = l1f_chunks(kf, hop);
+                const int64_t u = (int64_t)upool.size();
+                upool.resize(upool.size() + (size_t)d.nch1 * LF_U16, 0.f);
+                d.u1[t] = u;
+                const int hq = (hop + 3) / 4;
+                for (int s = 0; s < d.nch1; ++s)
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const int e4 = 4 * s + kk / 4, seg = e4 / hq, dd = 4 * (e4 % hq) + kk % 4;
+                        if (seg >= 2 * kf || dd >= hop) continue;
+                        for (int co = 0; co < H1; ++co) {
+                            const double w0 = pool[d.w1[t] + (size_t)co * d.ld1 + (size_t)seg * W + dd];
+                            const double w1v = pool[d.w1[t] + (size_t)co * d.ld1 + (size_t)seg * W + hop + dd];
+                            upool[u + l1f_u_off(s, 0, co, kk)] = (float)w0;
+                            upool[u + l1f_u_off(s, 1, co, kk)] = (float)(w0 + w1v);
+                            upool[u + l1f_u_off(s, 2, co, kk)] = (float)w1v;
+                        }
+                    }
             }
             // ---- L2: Conv2d weight (51,50,kf,4); BN(51);  k = (df*4 + dt)*52 + c1
             w = p; p += (size_t)H2 * H1 * kf * 4;
@@ -921,8 +979,8 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
 }
 
 int xsq_model_set_winograd(xsq_model* Mo, int on) {
-    XSQ_REQUIRE(Mo, "xsq_model_set_winograd: null model");
-    Mo->winograd = on ? 1 : 0;
+    XSQ_REQUIRE(Mo && on >= 0 && on <= 3, "xsq_model_set_winograd: null model or mask %d (1 = layers 2 / 3 Winograd F(2, 4), 2 = layer 1 F(2, 2))", on);
+    Mo->winograd = on;
     return XSQ_OK;
 }
 
@@ -991,7 +1049,7 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "offsets of a block's activations; split the batch", a.Bn, a.S);
         // fp32: Winograd F(2, 4) along the four time taps (cdae_wino.h) -- 5 instead of 8 MFMA products per output pair;
         // rows of >= 64 pairs, i.e. To >= 127.  xsq_model_set_winograd(0) / XSQ_CDAE_VARIANT=2048: the direct slab kernels.
-        if (!bf3 && !bf6 && a.upool && Mo->winograd && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
+        if (!bf3 && !bf6 && a.upool && (Mo->winograd & 1) && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
             // XSQ_WINO_MIN_KF (A/B): blocks with fewer frequency taps stay on the direct kernel (their tiles are short: a
             // prologue per 64 pairs and tap), the Winograd kernel takes the rest
             static const int min_kf = getenv("XSQ_WINO_MIN_KF") ? atoi(getenv("XSQ_WINO_MIN_KF")) : 0;
@@ -1019,6 +1077,15 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         else { if (bf3) XSQ_SLAB(true, 1); else if (bf6) XSQ_SLAB(true, 2); else if (exw && late) XSQ_SLAB_LATE(true); else if (exw) XSQ_SLAB(true, 3); else XSQ_SLAB(true, 0); }
 #undef XSQ_SLAB_LATE
 #undef XSQ_SLAB
+        return XSQ_OK;
+    }
+    if (layer == 1 && !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && !a.causal && a.upool && (Mo->winograd & 2)) {
+        // fp32 inference, non-causal: F(2, 2) along the hop (cdae_l1f.h) -- three half-window products per output pair
+        // instead of four.  xsq_model_set_winograd without bit 2: the implicit GEMM below.
+        int rcf = get_l1f_tiles(Mo, a.Bn, a.S, &tt);
+        if (rcf) return rcf;
+        XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream);
+        hipLaunchKernelGGL(cdae_l1f_kernel, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L1fTileDev*)tt.d_tiles, tt.ntiles);
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity

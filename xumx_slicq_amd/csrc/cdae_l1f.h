@@ -1,0 +1,250 @@
+// Layer 1 of the CDAE (fp32, non-causal) as F(2, 2) along the HOP.
+//
+// Layer 1 is Conv2d(2 -> 50, (kf, W), stride (1, hop = W / 2)) over the whitened magnitudes (/root/reference/xumx_slicq_v2/
+// model.py:130-139): output u of a (b, f) row contracts the window x[u hop .. u hop + W) of every (channel, frequency tap).  In
+// units of the hop that is a TWO-tap convolution: with X[u] = the u-th half window (2 kf hop values) and the weights cut
+// the same way (W0 = columns dt < hop, W1 = columns dt >= hop)
+//     y[u] = W0 X[u] + W1 X[u + 1].
+// The implicit GEMM (CdaeL1Op, gemm_tile.h) runs four half-length products per output pair.  F(2, 2) -- the same saving as
+// cdae_wino.h takes from layers 2 / 3 -- needs three:
+//     m1 = W0 (X[u] - X[u + 1]),   m2 = (W0 + W1) X[u + 1],   m3 = W1 (X[u + 2] - X[u + 1])
+//     y[u] = m1 + m2,              y[u + 1] = m2 + m3
+// with W0 + W1 summed on the host in fp64 from the BN-folded fp32 weights (xsq_model::d_upool).  Three quarters of the MFMA
+// cycles of a kernel whose issue port they fill to three quarters.
+//
+// As a GEMM: rows = output PAIRS, three accumulator sets of (pairs x 50 columns), K = the 2 kf hop values of a half window.
+// Tile = 64 consecutive pairs of one batch item in the flattened (f1, pair) space, 256 threads = 4 waves x 16 pairs.
+//  * A operand: NOT staged.  In the MFMA's own layout a lane (pair q, k-quad kq) needs, per chunk of 16 k, the four
+//    consecutive values 4 kq .. 4 kq + 3 of its pair's three half windows -- three 16-byte buffer loads at byte offsets
+//    0, 4 hop, 8 hop from ONE per-lane address (X[u + 1] IS X[u] displaced by a hop: the input row is contiguous in time).
+//    Two subtractions per value make the three operands in registers; each transformed value feeds exactly one lane, so an
+//    LDS round trip would buy nothing (cdae_wino.h transforms in registers for the same reason).  Requested one chunk ahead.
+//  * K order: (segment = (channel, frequency tap), d < hop) with every segment padded to a multiple of 4 values, so a
+//    lane's four values never straddle two segments; the pad values are whatever follows in the row (finite whitened
+//    magnitudes of the next half window) against ZERO weights.  Chunks of 16: 2 kf ceil(hop / 4) quads, padded to 4 quads.
+//  * B operand: the three weight tiles of a chunk ([component][column < 50][16 k], 9.6 KB) stream through two LDS buffers
+//    exactly as the Winograd kernel's do (requested at the start of a chunk, written at its end, one barrier per chunk), row
+//    stride 24 words (cdae_wino.h explains the bank pattern); columns 48 / 49 on the vector ALU through one LDS word and
+//    v_fmac_f32_dpp row_newbcast.
+//  * per chunk and wave: 36 v_mfma_f32_16x16x4_f32 (1,152 cycles) where the implicit GEMM issues 1,536 for the same outputs.
+//  * epilogue: output sums, shift + ReLU, through a per-wave LDS image (the weight buffers are free), 16-byte stores.
+//   LDS 28.8 KB + 256 B.
+#pragma once
+#include "cdae_api.h"
+#include "gemm_tile.h"
+
+#ifndef XSQ_L1F_WAVES_PER_EU
+#define XSQ_L1F_WAVES_PER_EU 3
+#endif
+
+namespace xsq {
+
+constexpr int LF_PAIRS = 64;                              // output pairs per tile (4 waves x 16)
+constexpr int LF_COLS = 50;                               // H1 output channels: 48 on the matrix pipe + 2 on the vector ALU
+constexpr int LF_BLD = 24;                                // weight tile row: 16 k | 8 pad words (6 slots, cdae_wino.h)
+constexpr int LF_BTILE = LF_COLS * LF_BLD;                // words per component tile in LDS (row = component * 50 + column)
+constexpr int LF_U16 = 3 * LF_COLS * 16;                  // words of a chunk in global memory: [component][col][16 k] = 600 float4
+
+// chunks of 16 k of a block: 2 kf segments of ceil(hop / 4) quads
+__host__ __device__ constexpr int l1f_chunks(int kf, int hop) { return (2 * kf * ((hop + 3) / 4) + 3) / 4; }
+// word offset of (chunk s, component j, column col, k kk) inside a (block, target)'s transformed layer-1 weights
+__host__ __device__ constexpr int l1f_u_off(int s, int j, int col, int kk) { return s * LF_U16 + (j * LF_COLS + col) * 16 + kk; }
+
+struct L1fTileDev {                // 64 bytes: one scalar load
+    int Q0, kf, F, F1;             // first pair of the tile (f1 * P + p inside batch item b); taps; input / output rows
+    int64_t in_off, out_off;       // the block's whitened magnitudes inside xin / the (block, target)'s act1, in floats
+    int64_t shift_off, u_off;      // shift vector inside the pool / transformed weights inside the Winograd pool
+    int b, hop, nchunks, P;        // batch item, hop, chunks of 16 k, pairs per (b, f1) row = (T1 + 1) / 2
+};
+static_assert(sizeof(L1fTileDev) == 64, "L1fTileDev is meant to be one 64-byte scalar load");
+
+__global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(CdaeArgs a, const L1fTileDev* __restrict__ tiles, int ntiles) {
+#pragma clang fp contract(off)
+    constexpr int NV = H1 - 48;                                  // real channels past 47
+    __shared__ __attribute__((aligned(16))) float Bs[2 * 3 * LF_BTILE];
+    __shared__ unsigned obase[LF_PAIRS];                         // byte offset of a pair's first output row | 1 when its second output exists
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 15, kq = lane >> 4;
+    const L1fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.shift_off), "s"(t.u_off),
+                 "s"(t.b), "s"(t.hop), "s"(t.nchunks), "s"(t.P));
+    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, b = t.b, hop = t.hop, nchunks = t.nchunks;
+    const int Ti = a.S * 2 * hop, T1 = a.T1;
+    const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.xin + t.in_off, 4u * (unsigned)(a.Bn * 2 * F * Ti));     // (< 2^30 bytes: cdae_launch_layer)
+
+    // ---- this lane's pair: row base of its first half window; output offsets for the epilogue
+    const int pl = wave * 16 + q;
+    const int Q = t.Q0 + pl;
+    const bool pair_ok = Q < F1 * P;
+    const int f1 = Q / P, p = Q - f1 * P;
+    const unsigned vo_row = pair_ok ? 4u * (unsigned)((b * 2 * F + f1) * Ti + 2 * p * hop) : BUF_OOB;
+    if (kq == 0) obase[pl] = pair_ok ? (4u * (unsigned)(((b * F1 + f1) * T1 + 2 * p) * CS) | (2 * p + 1 < T1 ? 1u : 0u)) : 0xffffffffu;
+
+    // ---- K cursor of this lane: quad e4 = kq + 4 s of the padded K order -> (segment, quad inside the segment).  seg_off =
+    // floats from the row base to the segment's row: segment (c, df) is input row (c F + f1 + df)
+    const int hq = (hop + 3) >> 2;
+    int dq = kq, c_df = 0, c_c = 0, seg_off = 0;
+    auto norm = [&]() {
+        while (dq >= hq) {
+            dq -= hq; seg_off += Ti;
+            if (++c_df == kf) { c_df = 0; ++c_c; seg_off += (F - kf) * Ti; }
+        }
+    };
+    norm();
+    float4 xa[2][3];
+    auto load_a = [&](int set) {
+        const unsigned vo = c_c < 2 ? vo_row + 4u * (unsigned)(seg_off + 4 * dq) : BUF_OOB;
+        xa[set][0] = buf_ld4(rin, vo, 0);
+        xa[set][1] = buf_ld4(rin, vo, 4 * hop);
+        xa[set][2] = buf_ld4(rin, vo, 8 * hop);
+        dq += 4;
+        norm();
+    };
+
+    // ---- weight stream: chunk s = three component tiles of 50 columns -> the LDS buffer of its parity.  600 float4: thread
+    // tid takes float4 tid + 256 r; the spare threads of r = 2 load past the descriptor (zeros) and write into pad words
+    const __amdgpu_buffer_rsrc_t ru = buf_rsrc(a.upool + t.u_off, 4u * (unsigned)(nchunks * LF_U16));
+    const int b_lds0 = (tid >> 2) * LF_BLD + 4 * (tid & 3);      // float4 x -> LDS row x >> 2, k quad x & 3
+    constexpr int LAST = LF_U16 / 4 - 512;                       // float4s of the third round (88)
+    float4 gb[3];
+    auto load_chunk = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) gb[r] = buf_ld4(ru, (r < 2 || tid < LAST) ? 16u * (unsigned)(tid + 256 * r) : BUF_OOB, 4 * s * LF_U16);
+    };
+    auto store_chunk = [&](int buf) {
+        float* Bw = Bs + buf * 3 * LF_BTILE;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            *reinterpret_cast<float4*>(&Bw[(r < 2 || tid < LAST) ? b_lds0 + 64 * r * LF_BLD : (tid & 127) * LF_BLD + 20]) = gb[r];
+    };
+
+    const int bf = q * LF_BLD + 4 * kq;                          // weight tile: column q of a 16-column block, k-quad kq
+    const int bv = 48 * LF_BLD + 4 * kq + (q & 3);               // vector columns: one word per lane (cdae_wino.h)
+
+    f32x4 acc[3][3];
+    float accv[3][NV];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) acc[j][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NV; ++cc) accv[j][cc] = 0.f;
+    }
+
+    struct Frag { float4 w[3]; float u[NV]; };
+    auto read_frag = [&](Frag& f, const float* Bt) {
+        f.w[0] = *reinterpret_cast<const float4*>(&Bt[bf]);
+        f.w[1] = *reinterpret_cast<const float4*>(&Bt[bf + 16 * LF_BLD]);
+        f.w[2] = *reinterpret_cast<const float4*>(&Bt[bf + 32 * LF_BLD]);
+#pragma unroll
+        for (int cc = 0; cc < NV; ++cc) f.u[cc] = Bt[bv + cc * LF_BLD];
+    };
+
+    // one chunk: operands of register set SET against LDS buffer BUF; `next`: the chunk after it exists (uniform)
+    auto chunk = [&](auto set_c, auto buf_c, int s, bool next) {
+        constexpr int SET = decltype(set_c)::value, BUF = decltype(buf_c)::value;
+        if (next) { load_chunk(s + 1); load_a(SET ^ 1); }
+        const float* Bc = Bs + BUF * 3 * LF_BTILE;
+        Frag fr[2];
+        read_frag(fr[0], Bc);
+        const float4 x0 = xa[SET][0], x1 = xa[SET][1], x2 = xa[SET][2];
+        const float d[3][4] = {{x0.x - x1.x, x0.y - x1.y, x0.z - x1.z, x0.w - x1.w}, {x1.x, x1.y, x1.z, x1.w},
+                               {x2.x - x1.x, x2.y - x1.y, x2.z - x1.z, x2.w - x1.w}};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const Frag& f = fr[j & 1];
+            if (j < 2) read_frag(fr[(j + 1) & 1], Bc + (j + 1) * LF_BTILE);
+            const float wa[4] = {f.w[0].x, f.w[0].y, f.w[0].z, f.w[0].w}, wb[4] = {f.w[1].x, f.w[1].y, f.w[1].z, f.w[1].w};
+            const float wc[4] = {f.w[2].x, f.w[2].y, f.w[2].z, f.w[2].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wa[i], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wb[i], acc[j][1], 0, 0, 0);
+                acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wc[i], acc[j][2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cc = 0; cc < NV; ++cc)
+                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                    : "+v"(accv[j][cc])
+                    : "v"(f.u[cc]), "v"(d[j][0]), "v"(d[j][1]), "v"(d[j][2]), "v"(d[j][3]));
+        }
+        if (next) store_chunk(BUF ^ 1);          // the other buffer: last read in the chunk before, every wave is past that chunk's barrier
+        __syncthreads();
+    };
+
+    // ---- prologue: chunk 0's weights in LDS buffer 0, its operands in register set 0
+    load_chunk(0);
+    load_a(0);
+    store_chunk(0);
+    __syncthreads();
+    {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        int s = 0;
+        for (int pr = 0; pr < nchunks / 2; ++pr, s += 2) {
+            chunk(I0{}, I0{}, s, true);
+            chunk(I1{}, I1{}, s + 1, s + 2 < nchunks);
+        }
+        if (nchunks & 1) chunk(I0{}, I0{}, s, false);
+    }
+
+    // ---- epilogue: y[u] = m1 + m2, y[u + 1] = m2 + m3, shift + ReLU, through a per-wave LDS image (the loop ended on a
+    // barrier: the weight buffers are free), out as 16-byte stores.  Image row 2 p' + r = output r of the wave's pair p'.
+    float* img = Bs + wave * 32 * CS;
+    const float* shift = a.pool + t.shift_off;
+    {
+        const int rq = lane >> 4;
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+            const int col = 16 * cb + q;
+            const float sh = shift[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m1 = acc[0][cb][r], m2 = acc[1][cb][r], m3 = acc[2][cb][r];
+                img[(2 * (4 * rq + r)) * CS + col] = fmaxf((m1 + m2) + sh, 0.f);
+                img[(2 * (4 * rq + r) + 1) * CS + col] = fmaxf((m2 + m3) + sh, 0.f);
+            }
+        }
+        float y0v[4] = {0.f, 0.f, 0.f, 0.f}, y1v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < NV; ++cc) {
+            float m[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                // the four k-quads' partial sums meet here (fixed order)
+                float x = accv[j][cc];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                m[j] = x;
+            }
+            y0v[cc] = m[0] + m[1];
+            y1v[cc] = m[1] + m[2];
+        }
+        if (kq == 0) {
+            const float4 sh = *reinterpret_cast<const float4*>(shift + 48);
+            *reinterpret_cast<float4*>(img + (2 * q) * CS + 48) =
+                make_float4(fmaxf(y0v[0] + sh.x, 0.f), fmaxf(y0v[1] + sh.y, 0.f), fmaxf(y0v[2] + sh.z, 0.f), fmaxf(y0v[3] + sh.w, 0.f));
+            *reinterpret_cast<float4*>(img + (2 * q + 1) * CS + 48) =
+                make_float4(fmaxf(y1v[0] + sh.x, 0.f), fmaxf(y1v[1] + sh.y, 0.f), fmaxf(y1v[2] + sh.z, 0.f), fmaxf(y1v[3] + sh.w, 0.f));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // image row -> output row: pair 16 wave + (row >> 1) of the tile; a pair that does not exist and the phantom second output
+    // of a row's last pair (T1 is odd: it would land on the NEXT row's first output) are switched out of the descriptor's range
+    const __amdgpu_buffer_rsrc_t ro = buf_rsrc(a.act1 + t.out_off, 0x40000000u);
+#pragma unroll
+    for (int it = 0; it < (32 * (CS / 4) + 63) / 64; ++it) {
+        const int slot = lane + 64 * it;
+        const int row = slot / (CS / 4), c4 = slot - row * (CS / 4);
+        const unsigned ob = obase[wave * 16 + min(row >> 1, 15)];
+        const bool ok = slot < 32 * (CS / 4) && ob != 0xffffffffu && (!(row & 1) || (ob & 1u));
+        const unsigned vo = (ob & ~1u) + 4u * (unsigned)((row & 1) * CS + 4 * c4);
+        const float4 val = *reinterpret_cast<const float4*>(img + 4 * min(slot, 32 * (CS / 4) - 1));
+        buf_st4(val, ro, ok ? vo : BUF_OOB, 0);
+    }
+}
+
+}  // namespace xsq
