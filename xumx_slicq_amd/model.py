@@ -1,11 +1,3 @@
-    def set_winograd(self, on):
-        """Fast-convolution forms of the fp32 inference layers.  True (default) = all of them, False = the direct kernels, an int =
-        a bit mask: 1 = layers 2 / 3 of long rows as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), 2 = layer 1 as
-        F(2, 2) along the hop (csrc/cdae_l1f.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
-        self.winograd = (3 if on else 0) if isinstance(on, bool) else int(on)
-        for _ver, h in self._handles.values():
-            _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
-
 """Drop-in mirror of /root/reference/xumx_slicq_v2/model.py (Unmix,
 _SlicedUnmixCDAE, _CausalConv2d) on top of the HIP library.
 
@@ -295,10 +287,11 @@ class Unmix(nn.Module):
             with torch.cuda.device(idx):       # the split-weight pool is allocated / converted on the model's device
                 _lib.check(_lib.lib.xsq_model_set_precision(h, _PRECISIONS[precision]), "xsq_model_set_precision")
 
-    def set_winograd(self, on: bool):
-        """fp32 layers 2 / 3 of long rows: True (default) = Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), False =
-        the direct slab kernels (csrc/cdae_slab.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
-        self.winograd = 1 if on else 0
+    def set_winograd(self, on):
+        """Fast-convolution forms of the fp32 inference layers.  True (default) = all of them, False = the direct kernels, an int =
+        a bit mask: 1 = layers 2 / 3 of long rows as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), 2 = layer 1 as
+        F(2, 2) along the hop (csrc/cdae_l1f.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
+        self.winograd = (3 if on else 0) if isinstance(on, bool) else int(on)
         for _ver, h in self._handles.values():
             _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
 
