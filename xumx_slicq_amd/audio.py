@@ -83,6 +83,37 @@ def load_audio(path: str, start: float = 0.0, dur: Optional[float] = None,
     return torch.from_numpy(a.reshape(-1, channels).T.copy()), rate
 
 
+def load_audio_into(path: str, take) -> Tuple[torch.Tensor, int]:
+    """``load_audio`` + the channel rules of ``preprocess_audio`` for the pipelined CLI: the file's samples are converted
+    STRAIGHT into a caller-supplied (pinned) float32 buffer as (2, samples) -- one strided pass per channel, no interleaved
+    float copy, no transpose copy, no second copy into the staging buffer.  ``take(numel)`` returns a 1-D float32 tensor of at
+    least that many elements.  Returns ((2, samples) view of it, rate).  Same values as load_audio -> preprocess_audio."""
+    fmt, off, size = _read_chunks(path)
+    tag, channels, rate, align, bits = _parse_fmt(fmt)
+    n = size // align
+    with open(path, "rb") as f:
+        f.seek(off)
+        raw = f.read(n * align)
+    if (tag == 1 and bits == 24) or channels > 2:      # 24-bit PCM, or the reference's shape rules for > 2 channels: the general decoder
+        sig, rate = load_audio(path)
+        out = take(2 * n)[:2 * n].view(2, n)
+        out.copy_(preprocess_audio(sig)[0])
+        return out, rate
+    dt, scale, bias = {(3, 32): (torch.float32, None, 0.0), (3, 64): (torch.float64, None, 0.0), (1, 8): (torch.uint8, 1.0 / 128.0, -128.0),
+                       (1, 16): (torch.int16, 1.0 / 32768.0, 0.0), (1, 32): (torch.int32, 1.0 / 2147483648.0, 0.0)}[(tag, bits)]
+    out = take(2 * n)[:2 * n].view(2, n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # (the bytes object is read-only; nothing writes through the view)
+        frames = torch.frombuffer(raw, dtype=dt).view(n, channels)
+    # one converting, de-interleaving copy per file (a strided read, a contiguous write), then the scale in place
+    out.copy_(frames[:, :2].T if channels >= 2 else frames.T.expand(2, n))
+    if bias:
+        out.add_(bias)
+    if scale is not None:
+        out.mul_(scale)
+    return out, rate
+
+
 def save_wav_float(path: str, audio: torch.Tensor, rate: int) -> None:
     """(channels, samples) -> IEEE float32 wav (torchaudio.save(..., encoding="PCM_F"), inference.py:135-142)."""
     a = audio.detach().to("cpu", torch.float32).numpy()

@@ -36,6 +36,15 @@
 #ifndef XSQ_L1F_WAVES_PER_EU
 #define XSQ_L1F_WAVES_PER_EU 3
 #endif
+#ifndef XSQ_L1F_AHEAD
+#define XSQ_L1F_AHEAD 1     // chunks by which the operand loads run ahead of their MFMAs (2: a third register set, 12 more registers)
+#endif
+#ifndef XSQ_L1F_PRIO
+#define XSQ_L1F_PRIO 0      // 1: s_setprio 1 around a chunk's MFMAs
+#endif
+#ifndef XSQ_L1F_ABL
+#define XSQ_L1F_ABL 0       // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no operand loads, 16 no epilogue stores, 32 no MFMAs
+#endif
 
 namespace xsq {
 
@@ -92,12 +101,15 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         }
     };
     norm();
-    float4 xa[2][3];
+    float4 xa[XSQ_L1F_AHEAD + 1][3];
     auto load_a = [&](int set) {
         const unsigned vo = c_c < 2 ? vo_row + 4u * (unsigned)(seg_off + 4 * dq) : BUF_OOB;
+        if (XSQ_L1F_ABL & 8) { xa[set][0] = make_float4(1.f, 2.f, 3.f, (float)vo); xa[set][1] = make_float4(2.f, 3.f, 1.f, 4.f); xa[set][2] = make_float4(3.f, 1.f, 2.f, 4.f); }
+        else {
         xa[set][0] = buf_ld4(rin, vo, 0);
         xa[set][1] = buf_ld4(rin, vo, 4 * hop);
         xa[set][2] = buf_ld4(rin, vo, 8 * hop);
+        }
         dq += 4;
         norm();
     };
@@ -109,10 +121,12 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
     constexpr int LAST = LF_U16 / 4 - 512;                       // float4s of the third round (88)
     float4 gb[3];
     auto load_chunk = [&](int s) {
+        if (XSQ_L1F_ABL & 4) return;
 #pragma unroll
         for (int r = 0; r < 3; ++r) gb[r] = buf_ld4(ru, (r < 2 || tid < LAST) ? 16u * (unsigned)(tid + 256 * r) : BUF_OOB, 4 * s * LF_U16);
     };
     auto store_chunk = [&](int buf) {
+        if (XSQ_L1F_ABL & 4) return;
         float* Bw = Bs + buf * 3 * LF_BTILE;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -141,16 +155,22 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         for (int cc = 0; cc < NV; ++cc) f.u[cc] = Bt[bv + cc * LF_BLD];
     };
 
-    // one chunk: operands of register set SET against LDS buffer BUF; `next`: the chunk after it exists (uniform)
-    auto chunk = [&](auto set_c, auto buf_c, int s, bool next) {
-        constexpr int SET = decltype(set_c)::value, BUF = decltype(buf_c)::value;
-        if (next) { load_chunk(s + 1); load_a(SET ^ 1); }
-        const float* Bc = Bs + BUF * 3 * LF_BTILE;
+    // one chunk: operands of register set SET against the LDS buffer of the chunk's parity; the loads of chunk s + AHEAD and the
+    // weights of chunk s + 1 are requested first (uniform conditions)
+    int cnt = 0;
+    auto chunk = [&](auto set_c, int s) {
+        constexpr int SET = decltype(set_c)::value, NS = XSQ_L1F_AHEAD + 1;
+        const bool next = s + 1 < nchunks;
+        if (next) load_chunk(s + 1);
+        if (s + XSQ_L1F_AHEAD < nchunks) load_a((SET + XSQ_L1F_AHEAD) % NS);
+        const int cur = cnt & 1;
+        const float* Bc = Bs + cur * 3 * LF_BTILE;
         Frag fr[2];
         read_frag(fr[0], Bc);
         const float4 x0 = xa[SET][0], x1 = xa[SET][1], x2 = xa[SET][2];
         const float d[3][4] = {{x0.x - x1.x, x0.y - x1.y, x0.z - x1.z, x0.w - x1.w}, {x1.x, x1.y, x1.z, x1.w},
                                {x2.x - x1.x, x2.y - x1.y, x2.z - x1.z, x2.w - x1.w}};
+        if (XSQ_L1F_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const Frag& f = fr[j & 1];
@@ -159,37 +179,47 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
             const float wc[4] = {f.w[2].x, f.w[2].y, f.w[2].z, f.w[2].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (XSQ_L1F_ABL & 32) { acc[j][0][i] += d[j][i] * wa[i]; acc[j][1][i] += d[j][i] * wb[i]; acc[j][2][i] += d[j][i] * wc[i]; continue; }
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wa[i], acc[j][0], 0, 0, 0);
                 acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wb[i], acc[j][1], 0, 0, 0);
                 acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wc[i], acc[j][2], 0, 0, 0);
             }
 #pragma unroll
-            for (int cc = 0; cc < NV; ++cc)
+            for (int cc = 0; cc < NV; ++cc) {
+                if (XSQ_L1F_ABL & 2) { accv[j][cc] += d[j][0] + f.u[cc]; continue; }
                 asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
                     "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
                     "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
                     "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf"
                     : "+v"(accv[j][cc])
                     : "v"(f.u[cc]), "v"(d[j][0]), "v"(d[j][1]), "v"(d[j][2]), "v"(d[j][3]));
+            }
         }
-        if (next) store_chunk(BUF ^ 1);          // the other buffer: last read in the chunk before, every wave is past that chunk's barrier
+        if (XSQ_L1F_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (next) store_chunk(cur ^ 1);          // the other buffer: last read in the chunk before, every wave is past that chunk's barrier
+        cnt += 1;
         __syncthreads();
     };
 
-    // ---- prologue: chunk 0's weights in LDS buffer 0, its operands in register set 0
+    // ---- prologue: chunk 0's weights in LDS buffer 0, the operands of the first AHEAD chunks in their register sets
     load_chunk(0);
     load_a(0);
+    if (XSQ_L1F_AHEAD == 2 && nchunks > 1) load_a(1);
     store_chunk(0);
     __syncthreads();
     {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
         int s = 0;
-        for (int pr = 0; pr < nchunks / 2; ++pr, s += 2) {
-            chunk(I0{}, I0{}, s, true);
-            chunk(I1{}, I1{}, s + 1, s + 2 < nchunks);
+        if constexpr (XSQ_L1F_AHEAD == 1) {
+            for (int pr = 0; pr < nchunks / 2; ++pr, s += 2) { chunk(I0{}, s); chunk(I1{}, s + 1); }
+            if (nchunks & 1) chunk(I0{}, s);
+        } else {
+            for (int tr = 0; tr < nchunks / 3; ++tr, s += 3) { chunk(I0{}, s); chunk(I1{}, s + 1); chunk(I2{}, s + 2); }
+            if (nchunks - s >= 1) chunk(I0{}, s);
+            if (nchunks - s >= 2) chunk(I1{}, s + 1);
         }
-        if (nchunks & 1) chunk(I0{}, I0{}, s, false);
     }
 
     // ---- epilogue: y[u] = m1 + m2, y[u + 1] = m2 + m3, shift + ReLU, through a per-wave LDS image (the loop ended on a
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         const bool ok = slot < 32 * (CS / 4) && ob != 0xffffffffu && (!(row & 1) || (ob & 1u));
         const unsigned vo = (ob & ~1u) + 4u * (unsigned)((row & 1) * CS + 4 * c4);
         const float4 val = *reinterpret_cast<const float4*>(img + 4 * min(slot, 32 * (CS / 4) - 1));
-        buf_st4(val, ro, ok ? vo : BUF_OOB, 0);
+        buf_st4(val, ro, (ok && !((XSQ_L1F_ABL & 16) && val.x != 1.2345e-30f)) ? vo : BUF_OOB, 0);
     }
 }
 

@@ -57,7 +57,7 @@ class _PinnedPool:
         self._free.put(buf)
 
 
-def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 2, writers: int = 4, depth: int = 3, quiet=False):
+def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 3, writers: int = 4, depth: int = 3, quiet=False):
     """The CLI's loop (inference.py:118-146) as a pipeline over the tracks: decode -> pinned host buffer (reader threads) |
     H2D on a copy stream | ``separator(audio)`` | channel interleave on the GPU (the wav payload layout, so the host never
     transposes 339 MB per track) | D2H into a pinned buffer on a second copy stream | header + payload written by writer
@@ -76,13 +76,15 @@ def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 2, w
     wq: "queue.Queue" = queue.Queue()
 
     def read(path):
-        info = xaudio.load_info(str(path))
-        buf = pool_in.take(info["samples"] * max(2, info["channels"]), depth + readers)
-        sig, rate = xaudio.load_audio(str(path))                     # (channels, samples) float32
-        sig = xaudio.preprocess_audio(sig, rate, separator.sample_rate)[0]      # (2, N)
-        view = buf[:sig.numel()].view(sig.shape)
-        view.copy_(sig)
-        return path, view, buf, rate
+        keep = []
+
+        def take(numel):
+            keep.append(pool_in.take(numel, depth + readers))
+            return keep[0]
+        view, rate = xaudio.load_audio_into(str(path), take)        # (2, N) float32 in the pinned buffer, decoded in one pass
+        if float(rate) != float(separator.sample_rate):
+            raise ValueError(f"{path}: {rate} Hz, the model runs at {float(separator.sample_rate)} Hz: resample first")
+        return path, view, keep[0], rate
 
     def writer():
         while True:
