@@ -213,7 +213,7 @@ def pmc_issue(kernel, tag=None):
 SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4     # 256 CUs x 4 SIMDs; the clock the fp32 MFMA peak of MI355X_MICROARCH.md is quoted at
 
 
-def issue_bound(plan, B, chunk_lengths, winograd=True):
+def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True):
     """Per-kernel ISSUE BOUND of the fp32 MFMA kernels for one pass over the given chunks, in ms: on gfx950 an fp32 MFMA and the
     other vector instructions of a SIMD's waves take turns on one issue port (DESIGN.md "Vector issue": a loop's time is the SUM
     of its MFMA cycles and ~4 cycles per other vector instruction), so no schedule of the kernel AS COMPILED can beat
@@ -252,8 +252,21 @@ def issue_bound(plan, B, chunk_lengths, winograd=True):
         for (_, F, T) in plan.blocks:
             kf = freq_filter(F)
             F1, F2 = F - kf + 1, F - 2 * kf + 2
-            # layer 1: one 52-column tile per 128 rows and target; K = 2 kf T padded to 16
-            engine("cdae_l1_gemm", "gemm<CdaeL1Op>", B * F1 * T1, 4, math.ceil(2 * kf * T / 16))
+            if l1f and "cdae_l1f" in K:
+                # layer 1 as F(2, 2) along the hop (csrc/cdae_l1f.h): tiles of 64 output pairs (4 waves x 16) per target, chunks of
+                # 16 k of the padded half-window order; the assembly's loop holds TWO chunks (72 MFMAs), an odd last chunk and
+                # the prologue / epilogue are its out-of-loop part
+                k = K["cdae_l1f"]
+                lp = k["loops"][0]
+                hop = T // 2
+                nch = (2 * kf * ((hop + 3) // 4) + 3) // 4
+                tiles = 4 * B * math.ceil(F1 * ((T1 + 1) // 2) / 64)
+                tail_v = lp["valu"] / 2.0
+                add("cdae_l1_gemm", tiles * 4, lp["mfma_cycles"] * (nch // 2) + (k["outside"]["mfma_cycles"] if nch & 1 else 0),
+                    lp["valu"] * (nch // 2) + (k["outside"]["valu"] - (0 if nch & 1 else tail_v)))
+            else:
+                # layer 1: one 52-column tile per 128 rows and target; K = 2 kf T padded to 16
+                engine("cdae_l1_gemm", "gemm<CdaeL1Op>", B * F1 * T1, 4, math.ceil(2 * kf * T / 16))
             # layers 2 / 3
             for name, To, Fo, key_w, key_s, key_g in (("cdae_l2", T2, F2, "cdae_wino<L2>", "cdae_slab<L2>", "gemm<CdaeL2Op>"),
                                                     ("cdae_l3", T1, F1, "cdae_wino<L3>", "cdae_slab<L3>", "gemm<CdaeL3Op>")):
@@ -710,7 +723,10 @@ def bench_track(args, sep, dev, world, rank, dist):
     roofline = dominant_roofline(dom, prof, work, args.steps, dt, args.precision, args.wiener) if dom else None
     hbm, mfma = roofline_tables(work, prof_all, nwarm, args.wiener)
     wino = bool(getattr(sep.xumx_model, "winograd", 1)) and not (int(os.environ.get("XSQ_CDAE_VARIANT", "0")) & 2048) and args.precision == "fp32"
-    issue = roofline_issue_table(issue_bound(plan, 1, my_items, winograd=wino) if args.precision == "fp32" else None, prof_all, nwarm, args.wiener)
+    wmask = int(getattr(sep.xumx_model, "winograd", 7))
+    wino = bool(wmask & 1) and wino
+    issue = roofline_issue_table(issue_bound(plan, 1, my_items, winograd=wino, l1f=bool(wmask & 2)) if args.precision == "fp32" else None,
+                                 prof_all, nwarm, args.wiener)
     if roofline and issue:
         for row in issue:
             if row.get("kernel") == roofline["kernel"]:

@@ -25,6 +25,7 @@ PASSES = {"32x32x2": 16, "16x16x4": 8, "32x32x1": 16, "16x16x1": 8, "4x4x1": 2,
 # kernels of the fp32 inference path (event name of bench.py -> demangled-name filter)
 WANT = {
     "cdae_wino<L2>": r"cdae_wino_kernel<false>", "cdae_wino<L3>": r"cdae_wino_kernel<true>",
+    "cdae_l1f": r"cdae_l1f_kernel",
     "cdae_slab<L2>": r"cdae_slab_kernel<false, 3, true>", "cdae_slab<L3>": r"cdae_slab_kernel<true, 3, true>",
     "gemm<CdaeL1Op>": r"grouped_gemm_kernel<xsq::CdaeL1Op, 1, 1>", "gemm<CdaeL2Op>": r"grouped_gemm_kernel<xsq::CdaeL2Op, 1, 1>",
     "gemm<CdaeL3Op>": r"grouped_gemm_kernel<xsq::CdaeL3Op, 1, 1>", "gemm<CdaeL4Op>": r"grouped_gemm_kernel<xsq::CdaeL4Op, 1, 2>",

@@ -585,6 +585,7 @@ struct CdaeL4Op {
 #include "cdae_slab.h"
 #include "cdae_wino.h"
 #include "cdae_l1f.h"
+#include "cdae_l4f.h"
 namespace xsq {
 
 // ------------------------------------------------------------------------------------------
@@ -772,6 +773,48 @@ static int get_l1f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
     return XSQ_OK;
 }
 
+// tiles of the layer-4 F(2, 2) kernel (cdae_l4f.h): 64 consecutive output PAIRS of one batch item in the flattened (f, pair)
+// space x one column tile of <= 64 columns; one (block, target) after the other (the targets share nothing; the column tiles
+// of a row block share its operand rows, neighbouring row blocks share rows through the frequency taps)
+static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(4 + 160, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = 2 * S - 1, P = S;
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].kf > Mo->blocks[y].kf; });
+    std::vector<L4fTileDev> t;
+    for (int b : order) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        const int W = d.T, cols = l4f_cols(W);
+        const int64_t FST = (int64_t)d.F * S * d.T;
+        L4fTileDev e;
+        e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.P = P;
+        const int perb = d.F * P;
+        for (int tgt = 0; tgt < NT; ++tgt) {
+            e.in_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
+            e.out_off = (int64_t)Bn * 8 * S * d.cum + (int64_t)tgt * Bn * 2 * FST;
+            e.bias_off = d.b4[tgt];
+            for (int bi = 0; bi < Bn; ++bi)
+                for (int Q = 0; Q < perb; Q += L4_PAIRS)
+                    for (int n0 = 0; n0 < cols; n0 += 64) {
+                        e.Q0 = Q; e.b = bi; e.n0 = n0;
+                        e.u_off = d.u4[tgt] + (int64_t)3 * CS * n0;
+                        t.push_back(e);
+                    }
+        }
+    }
+    TileTable tt;                    // (d_tiles holds L4fTileDev entries for this key: cast at the launch site)
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc((void**)&tt.d_tiles, t.size() * sizeof(L4fTileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(L4fTileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace xsq
@@ -937,6 +980,25 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                             for (int dt = 0; dt < hop; ++dt)
                                 pool[d.w4[t] + (size_t)(c * hop + dt) * d.ld4 + (df * 2 + (1 - tap)) * CS + ci] =
                                     w[(((size_t)ci * 2 + c) * kf + df) * W + dt + tap * hop];
+            // ---- F(2, 2) along the hop (cdae_l4f.h): per frequency tap and column tile the three tiles Wb | Wa + Wb | Wa
+            //      ([component][column][52 k]; Wa = kernel columns dt < hop, Wb = columns dt + hop), summed in fp64
+            {
+                const int64_t u = (int64_t)upool.size();
+                const int tapf = l4f_tap_floats(W), cols = l4f_cols(W);
+                upool.resize(upool.size() + (size_t)kf * tapf, 0.f);
+                d.u4[t] = u;
+                for (int df = 0; df < kf; ++df)
+                    for (int n0 = 0; n0 < cols; n0 += 64)
+                        for (int n = n0; n < std::min(cols, n0 + 64) && n < W; ++n)
+                            for (int ci = 0; ci < H1; ++ci) {
+                                const double wa = pool[d.w4[t] + (size_t)n * d.ld4 + (df * 2 + 1) * CS + ci];
+                                const double wb = pool[d.w4[t] + (size_t)n * d.ld4 + (df * 2 + 0) * CS + ci];
+                                const size_t o = (size_t)u + (size_t)df * tapf;
+                                upool[o + l4f_u_off(W, n0, 0, n, ci)] = (float)wb;
+                                upool[o + l4f_u_off(W, n0, 1, n, ci)] = (float)(wa + wb);
+                                upool[o + l4f_u_off(W, n0, 2, n, ci)] = (float)wa;
+                            }
+            }
         }
         Mo->blocks.push_back(d);
     }
@@ -979,7 +1041,7 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
 }
 
 int xsq_model_set_winograd(xsq_model* Mo, int on) {
-    XSQ_REQUIRE(Mo && on >= 0 && on <= 3, "xsq_model_set_winograd: null model or mask %d (1 = layers 2 / 3 Winograd F(2, 4), 2 = layer 1 F(2, 2))", on);
+    XSQ_REQUIRE(Mo && on >= 0 && on <= 7, "xsq_model_set_winograd: null model or mask %d (1 = layers 2 / 3 Winograd F(2, 4), 2 / 4 = layer 1 / 4 F(2, 2))", on);
     Mo->winograd = on;
     return XSQ_OK;
 }
@@ -1086,6 +1148,16 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         if (rcf) return rcf;
         XSQ_PROF(prof_name ? prof_name : "cdae_l1_gemm", stream);
         hipLaunchKernelGGL(cdae_l1f_kernel, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L1fTileDev*)tt.d_tiles, tt.ntiles);
+        return XSQ_OK;
+    }
+    bool l4f_fits = true;            // cdae_l4f.h runs several frequency taps only on column tiles of <= 32 columns
+    for (const CdaeBlockDev& d : Mo->blocks) l4f_fits = l4f_fits && (d.kf == 1 || d.T <= 32);
+    if (layer == 4 && l4f_fits && !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && !a.causal && !a.Y && a.masks && a.upool && (Mo->winograd & 4)) {
+        // fp32 inference, masks only (the separator's path), non-causal: F(2, 2) along the hop (cdae_l4f.h)
+        int rcf = get_l4f_tiles(Mo, a.Bn, a.S, &tt);
+        if (rcf) return rcf;
+        XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
+        hipLaunchKernelGGL(cdae_l4f_kernel, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity

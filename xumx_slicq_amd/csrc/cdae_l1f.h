@@ -36,12 +36,6 @@
 #ifndef XSQ_L1F_WAVES_PER_EU
 #define XSQ_L1F_WAVES_PER_EU 3
 #endif
-#ifndef XSQ_L1F_AHEAD
-#define XSQ_L1F_AHEAD 1     // chunks by which the operand loads run ahead of their MFMAs (2: a third register set, 12 more registers)
-#endif
-#ifndef XSQ_L1F_PRIO
-#define XSQ_L1F_PRIO 0      // 1: s_setprio 1 around a chunk's MFMAs
-#endif
 #ifndef XSQ_L1F_ABL
 #define XSQ_L1F_ABL 0       // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no operand loads, 16 no epilogue stores, 32 no MFMAs
 #endif
@@ -101,7 +95,7 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         }
     };
     norm();
-    float4 xa[XSQ_L1F_AHEAD + 1][3];
+    float4 xa[2][3];
     auto load_a = [&](int set) {
         const unsigned vo = c_c < 2 ? vo_row + 4u * (unsigned)(seg_off + 4 * dq) : BUF_OOB;
         if (XSQ_L1F_ABL & 8) { xa[set][0] = make_float4(1.f, 2.f, 3.f, (float)vo); xa[set][1] = make_float4(2.f, 3.f, 1.f, 4.f); xa[set][2] = make_float4(3.f, 1.f, 2.f, 4.f); }
@@ -155,14 +149,14 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         for (int cc = 0; cc < NV; ++cc) f.u[cc] = Bt[bv + cc * LF_BLD];
     };
 
-    // one chunk: operands of register set SET against the LDS buffer of the chunk's parity; the loads of chunk s + AHEAD and the
-    // weights of chunk s + 1 are requested first (uniform conditions)
+    // one chunk: operands of register set SET against the LDS buffer of the chunk's parity; the operands and the weights of chunk
+    // s + 1 are requested first (uniform condition).  (Measured, profiles/r11_ab_runs.txt: operands TWO chunks ahead -- a third
+    // register set, 135 registers, three waves per SIMD instead of four -- 5 % slower; s_setprio around the MFMAs: nothing.)
     int cnt = 0;
     auto chunk = [&](auto set_c, int s) {
-        constexpr int SET = decltype(set_c)::value, NS = XSQ_L1F_AHEAD + 1;
+        constexpr int SET = decltype(set_c)::value;
         const bool next = s + 1 < nchunks;
-        if (next) load_chunk(s + 1);
-        if (s + XSQ_L1F_AHEAD < nchunks) load_a((SET + XSQ_L1F_AHEAD) % NS);
+        if (next) { load_chunk(s + 1); load_a(SET ^ 1); }
         const int cur = cnt & 1;
         const float* Bc = Bs + cur * 3 * LF_BTILE;
         Frag fr[2];
@@ -170,7 +164,6 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         const float4 x0 = xa[SET][0], x1 = xa[SET][1], x2 = xa[SET][2];
         const float d[3][4] = {{x0.x - x1.x, x0.y - x1.y, x0.z - x1.z, x0.w - x1.w}, {x1.x, x1.y, x1.z, x1.w},
                                {x2.x - x1.x, x2.y - x1.y, x2.z - x1.z, x2.w - x1.w}};
-        if (XSQ_L1F_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const Frag& f = fr[j & 1];
@@ -195,31 +188,22 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
                     : "v"(f.u[cc]), "v"(d[j][0]), "v"(d[j][1]), "v"(d[j][2]), "v"(d[j][3]));
             }
         }
-        if (XSQ_L1F_PRIO) __builtin_amdgcn_s_setprio(0);
         if (next) store_chunk(cur ^ 1);          // the other buffer: last read in the chunk before, every wave is past that chunk's barrier
         cnt += 1;
         __syncthreads();
     };
 
-    // ---- prologue: chunk 0's weights in LDS buffer 0, the operands of the first AHEAD chunks in their register sets
+    // ---- prologue: chunk 0's weights in LDS buffer 0, its operands in register set 0
     load_chunk(0);
     load_a(0);
-    if (XSQ_L1F_AHEAD == 2 && nchunks > 1) load_a(1);
     store_chunk(0);
     __syncthreads();
     {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
         int s = 0;
-        if constexpr (XSQ_L1F_AHEAD == 1) {
-            for (int pr = 0; pr < nchunks / 2; ++pr, s += 2) { chunk(I0{}, s); chunk(I1{}, s + 1); }
-            if (nchunks & 1) chunk(I0{}, s);
-        } else {
-            for (int tr = 0; tr < nchunks / 3; ++tr, s += 3) { chunk(I0{}, s); chunk(I1{}, s + 1); chunk(I2{}, s + 2); }
-            if (nchunks - s >= 1) chunk(I0{}, s);
-            if (nchunks - s >= 2) chunk(I1{}, s + 1);
-        }
+        for (int pr = 0; pr < nchunks / 2; ++pr, s += 2) { chunk(I0{}, s); chunk(I1{}, s + 1); }
+        if (nchunks & 1) chunk(I0{}, s);
     }
 
     // ---- epilogue: y[u] = m1 + m2, y[u + 1] = m2 + m3, shift + ReLU, through a per-wave LDS image (the loop ended on a

@@ -272,7 +272,7 @@ class Unmix(nn.Module):
                 1 if causal.pop() else 0, params.ctypes.data, params.size), "xsq_model_create")
             # inside the device guard: bf16 modes allocate and launch on the CURRENT device
             _lib.check(_lib.lib.xsq_model_set_precision(out, _PRECISIONS[self.precision]), "xsq_model_set_precision")
-            _lib.check(_lib.lib.xsq_model_set_winograd(out, int(getattr(self, "winograd", 3))), "xsq_model_set_winograd")
+            _lib.check(_lib.lib.xsq_model_set_winograd(out, int(getattr(self, "winograd", 7))), "xsq_model_set_winograd")
         self._handles[idx] = (ver, out)
         return out
 
@@ -289,9 +289,9 @@ class Unmix(nn.Module):
 
     def set_winograd(self, on):
         """Fast-convolution forms of the fp32 inference layers.  True (default) = all of them, False = the direct kernels, an int =
-        a bit mask: 1 = layers 2 / 3 of long rows as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), 2 = layer 1 as
-        F(2, 2) along the hop (csrc/cdae_l1f.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
-        self.winograd = (3 if on else 0) if isinstance(on, bool) else int(on)
+        a bit mask: 1 = layers 2 / 3 of long rows as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), 2 / 4 = layer 1 /
+        layer 4 as F(2, 2) along the hop (csrc/cdae_l1f.h, csrc/cdae_l4f.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
+        self.winograd = (7 if on else 0) if isinstance(on, bool) else int(on)
         for _ver, h in self._handles.values():
             _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
 

@@ -84,7 +84,7 @@ class Separator(nn.Module):
                 bool(getattr(self, "fuse_whiten", os.environ.get("XSQ_FUSE_WHITEN", "1") != "0")),
                 bool(getattr(m, "wiener_masked", os.environ.get("XSQ_WIENER_MASKED", "1") != "0")), self._packed_fft(),
                 bool(getattr(self, "native", os.environ.get("XSQ_NATIVE_FORWARD", "1") != "0")), int(getattr(self, "max_item_slices", 0)),
-                int(getattr(m, "winograd", 3)))
+                int(getattr(m, "winograd", 7)))
 
     def drop_graphs(self):
         """Forget every captured forward (they hold raw pointers into the model handle and the workspaces)."""
