@@ -213,7 +213,7 @@ def pmc_issue(kernel, tag=None):
 SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4     # 256 CUs x 4 SIMDs; the clock the fp32 MFMA peak of MI355X_MICROARCH.md is quoted at
 
 
-def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True):
+def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True, l4f=True):
     """Per-kernel ISSUE BOUND of the fp32 MFMA kernels for one pass over the given chunks, in ms: on gfx950 an fp32 MFMA and the
     other vector instructions of a SIMD's waves take turns on one issue port (DESIGN.md "Vector issue": a loop's time is the SUM
     of its MFMA cycles and ~4 cycles per other vector instruction), so no schedule of the kernel AS COMPILED can beat
@@ -260,7 +260,7 @@ def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True):
                 lp = k["loops"][0]
                 hop = T // 2
                 nch = (2 * kf * ((hop + 3) // 4) + 3) // 4
-                tiles = 4 * B * math.ceil(F1 * ((T1 + 1) // 2) / 64)
+                tiles = 4 * math.ceil(B * F1 * ((T1 + 1) // 2) / 64)
                 tail_v = lp["valu"] / 2.0
                 add("cdae_l1_gemm", tiles * 4, lp["mfma_cycles"] * (nch // 2) + (k["outside"]["mfma_cycles"] if nch & 1 else 0),
                     lp["valu"] * (nch // 2) + (k["outside"]["valu"] - (0 if nch & 1 else tail_v)))
@@ -280,6 +280,19 @@ def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True):
                     add(name + "_slab", tiles * 8, k["outside"]["mfma_cycles"] + kf * k["loops"][0]["mfma_cycles"], k["outside"]["valu"] + kf * k["loops"][0]["valu"])
                 else:
                     engine(name + "_gemm", key_g, B * Fo * To, 4, kf * 13)
+            if l4f and "cdae_l4f<4>" in K:
+                # layer 4 as F(2, 2) along the hop (csrc/cdae_l4f.h): tiles of 64 output pairs x one column tile of 16 NCB <= 64
+                # columns; the four width classes are budgeted from probe kernels of their own (tools/isa_budget.py); the
+                # compiler peels the first frequency tap: out-of-loop = prologue + first tap + epilogue, loop = one more tap
+                cols = 16 * math.ceil(T / 16)
+                for n0 in range(0, cols, 64):
+                    ncb = min(4, (cols - n0) // 16)
+                    k = K["cdae_l4f<%d>" % ncb]
+                    tap_m = 39 * ncb * 32.0
+                    tap_v = k["loops"][0]["valu"] if k["loops"] else 0.0
+                    tiles = 4 * math.ceil(B * F * S / 64)
+                    add("cdae_l4_gemm", tiles * 4, tap_m * kf, k["outside"]["valu"] + tap_v * (kf - 1))
+                continue
             # layer 4: N = T columns in tiles of 64 with a last tile of 16 / 32 / 48 / 64; K = kf * 104 padded to 16
             k4 = K["gemm<CdaeL4Op>"]
             loops = {lp["mfma_cycles"] // 32: lp for lp in k4["loops"]}           # columns of the class -> its loop (512 cycles = 16 columns, ...)
@@ -725,7 +738,7 @@ def bench_track(args, sep, dev, world, rank, dist):
     wino = bool(getattr(sep.xumx_model, "winograd", 1)) and not (int(os.environ.get("XSQ_CDAE_VARIANT", "0")) & 2048) and args.precision == "fp32"
     wmask = int(getattr(sep.xumx_model, "winograd", 7))
     wino = bool(wmask & 1) and wino
-    issue = roofline_issue_table(issue_bound(plan, 1, my_items, winograd=wino, l1f=bool(wmask & 2)) if args.precision == "fp32" else None,
+    issue = roofline_issue_table(issue_bound(plan, 1, my_items, winograd=wino, l1f=bool(wmask & 2), l4f=bool(wmask & 4) and os.environ.get("XSQ_WIENER_MASKED", "1") != "0") if args.precision == "fp32" else None,
                                  prof_all, nwarm, args.wiener)
     if roofline and issue:
         for row in issue:

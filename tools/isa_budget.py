@@ -93,6 +93,52 @@ def parse(path):
     return funcs
 
 
+L4F_PROBE = r"""
+// tools/isa_budget.py: the four column-width bodies of cdae_l4f_kernel as kernels of their own (the product kernel holds all
+// four behind a uniform switch: a static count over it cannot tell which one runs)
+#include "cdae_l4f.h"
+namespace xsq {
+template <int NCB>
+__global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void l4f_body_probe(CdaeArgs a, const L4fTileDev* __restrict__ tiles, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float Bs[L4_BROWS * L4_BLD];
+    __shared__ unsigned obase[L4_PAIRS];
+    const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
+                 "s"(t.hop), "s"(t.n0), "s"(t.P));
+    cdae_l4f_body<NCB>(a, t, Bs, obase);
+}
+template __global__ void l4f_body_probe<1>(CdaeArgs, const L4fTileDev*, int);
+template __global__ void l4f_body_probe<2>(CdaeArgs, const L4fTileDev*, int);
+template __global__ void l4f_body_probe<3>(CdaeArgs, const L4fTileDev*, int);
+template __global__ void l4f_body_probe<4>(CdaeArgs, const L4fTileDev*, int);
+}
+"""
+
+
+def l4f_bodies():
+    """{"cdae_l4f<NCB>": budget} from a probe translation unit (see L4F_PROBE)."""
+    src = os.path.join(CSRC, "_isa_budget_l4f_probe.hip")
+    open(src, "w").write(L4F_PROBE)
+    try:
+        compile_asm("_isa_budget_l4f_probe.hip", "/tmp/isa_budget_l4f.s")
+    finally:
+        os.remove(src)
+    funcs = parse("/tmp/isa_budget_l4f.s")
+    names = subprocess.run(["c++filt"], input="\n".join(funcs), capture_output=True, text=True).stdout.split("\n")
+    out = {}
+    for mangled, dem in zip(funcs, names):
+        m = re.search(r"l4f_body_probe<(\d)>", dem)
+        if not m:
+            continue
+        d = funcs[mangled]
+        loops = [v for v in d["loops"].values() if v["nmfma"]]
+        extra = sum(v["valu"] for v in d["loops"].values() if not v["nmfma"])
+        out["cdae_l4f<%s>" % m.group(1)] = {"symbol": "cdae_l4f_body<%s> (probe kernel of tools/isa_budget.py)" % m.group(1),
+                                            "outside": dict(d["outside"], valu=d["outside"]["valu"] + extra),
+                                            "loops": sorted(loops, key=lambda v: v["mfma_cycles"])}
+    return out
+
+
 def main():
     out = {"what": "MFMA cycles and other vector instructions (4 issue cycles each) per loop trip and outside the MFMA loops, per wave; "
                    "tools/isa_budget.py from the gfx950 assembly of csrc/cdae.hip and csrc/slicqt.hip", "kernels": {}}
@@ -110,7 +156,8 @@ def main():
                     extra = sum(v["valu"] for v in d["loops"].values() if not v["nmfma"])
                     outside = dict(d["outside"], valu=d["outside"]["valu"] + extra)
                     out["kernels"][key] = {"symbol": dem.split("(")[0], "outside": outside, "loops": sorted(loops, key=lambda v: v["mfma_cycles"])}
-    missing = [k for k in WANT if k not in out["kernels"]]
+    out["kernels"].update(l4f_bodies())
+    missing = [k for k in list(WANT) + ["cdae_l4f<%d>" % i for i in (1, 2, 3, 4)] if k not in out["kernels"]]
     if missing:
         sys.exit("isa_budget: kernels not found in the assembly: %s" % missing)
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "isa_budget.json")

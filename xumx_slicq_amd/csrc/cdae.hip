@@ -754,15 +754,15 @@ static int get_l1f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
         L1fTileDev e;
         e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.nchunks = d.nch1; e.P = P;
         e.in_off = (int64_t)Bn * 2 * S * d.cum;
-        const int perb = d.F1 * P;
-        for (int bi = 0; bi < Bn; ++bi)
-            for (int Q = 0; Q < perb; Q += LF_PAIRS)
-                for (int tgt = 0; tgt < NT; ++tgt) {
-                    e.Q0 = Q; e.b = bi;
-                    e.out_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
-                    e.shift_off = d.s1[tgt]; e.u_off = d.u1[tgt];
-                    t.push_back(e);
-                }
+        const int total = Bn * d.F1 * P;                   // tiles run across batch items: (b, f1, pair) flattened
+        e.pad0 = 0;
+        for (int Q = 0; Q < total; Q += LF_PAIRS)
+            for (int tgt = 0; tgt < NT; ++tgt) {
+                e.Q0 = Q;
+                e.out_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
+                e.shift_off = d.s1[tgt]; e.u_off = d.u1[tgt];
+                t.push_back(e);
+            }
     }
     TileTable tt;                    // (d_tiles holds L1fTileDev entries for this key: cast at the launch site)
     tt.ntiles = (int)t.size();
@@ -792,18 +792,18 @@ static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
         const int64_t FST = (int64_t)d.F * S * d.T;
         L4fTileDev e;
         e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.P = P;
-        const int perb = d.F * P;
+        const int total = Bn * d.F * P;                    // tiles run across batch items: (b, f, pair) flattened
+        e.pad0 = 0;
         for (int tgt = 0; tgt < NT; ++tgt) {
             e.in_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
             e.out_off = (int64_t)Bn * 8 * S * d.cum + (int64_t)tgt * Bn * 2 * FST;
             e.bias_off = d.b4[tgt];
-            for (int bi = 0; bi < Bn; ++bi)
-                for (int Q = 0; Q < perb; Q += L4_PAIRS)
-                    for (int n0 = 0; n0 < cols; n0 += 64) {
-                        e.Q0 = Q; e.b = bi; e.n0 = n0;
-                        e.u_off = d.u4[tgt] + (int64_t)3 * CS * n0;
-                        t.push_back(e);
-                    }
+            for (int Q = 0; Q < total; Q += L4_PAIRS)
+                for (int n0 = 0; n0 < cols; n0 += 64) {
+                    e.Q0 = Q; e.n0 = n0;
+                    e.u_off = d.u4[tgt] + (int64_t)3 * CS * n0;
+                    t.push_back(e);
+                }
         }
     }
     TileTable tt;                    // (d_tiles holds L4fTileDev entries for this key: cast at the launch site)

@@ -13,7 +13,7 @@
 // cycles of a kernel whose issue port they fill to three quarters.
 //
 // As a GEMM: rows = output PAIRS, three accumulator sets of (pairs x 50 columns), K = the 2 kf hop values of a half window.
-// Tile = 64 consecutive pairs of one batch item in the flattened (f1, pair) space, 256 threads = 4 waves x 16 pairs.
+// Tile = 64 consecutive pairs of the flattened (b, f1, pair) space, 256 threads = 4 waves x 16 pairs.
 //  * A operand: NOT staged.  In the MFMA's own layout a lane (pair q, k-quad kq) needs, per chunk of 16 k, the four
 //    consecutive values 4 kq .. 4 kq + 3 of its pair's three half windows -- three 16-byte buffer loads at byte offsets
 //    0, 4 hop, 8 hop from ONE per-lane address (X[u + 1] IS X[u] displaced by a hop: the input row is contiguous in time).
@@ -54,10 +54,10 @@ __host__ __device__ constexpr int l1f_chunks(int kf, int hop) { return (2 * kf *
 __host__ __device__ constexpr int l1f_u_off(int s, int j, int col, int kk) { return s * LF_U16 + (j * LF_COLS + col) * 16 + kk; }
 
 struct L1fTileDev {                // 64 bytes: one scalar load
-    int Q0, kf, F, F1;             // first pair of the tile (f1 * P + p inside batch item b); taps; input / output rows
+    int Q0, kf, F, F1;             // first pair of the tile in the flattened (b, f1, pair) space; taps; input / output rows
     int64_t in_off, out_off;       // the block's whitened magnitudes inside xin / the (block, target)'s act1, in floats
     int64_t shift_off, u_off;      // shift vector inside the pool / transformed weights inside the Winograd pool
-    int b, hop, nchunks, P;        // batch item, hop, chunks of 16 k, pairs per (b, f1) row = (T1 + 1) / 2
+    int pad0, hop, nchunks, P;     // -, hop, chunks of 16 k, pairs per (b, f1) row = (T1 + 1) / 2
 };
 static_assert(sizeof(L1fTileDev) == 64, "L1fTileDev is meant to be one 64-byte scalar load");
 
@@ -71,15 +71,16 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
     const int q = lane & 15, kq = lane >> 4;
     const L1fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.shift_off), "s"(t.u_off),
-                 "s"(t.b), "s"(t.hop), "s"(t.nchunks), "s"(t.P));
-    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, b = t.b, hop = t.hop, nchunks = t.nchunks;
+                 "s"(t.hop), "s"(t.nchunks), "s"(t.P));
+    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, hop = t.hop, nchunks = t.nchunks;
     const int Ti = a.S * 2 * hop, T1 = a.T1;
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.xin + t.in_off, 4u * (unsigned)(a.Bn * 2 * F * Ti));     // (< 2^30 bytes: cdae_launch_layer)
 
     // ---- this lane's pair: row base of its first half window; output offsets for the epilogue
     const int pl = wave * 16 + q;
-    const int Q = t.Q0 + pl;
-    const bool pair_ok = Q < F1 * P;
+    const int Qg = t.Q0 + pl;                                    // pair of the flattened (b, f1, pair) space: tiles run across batch items
+    const bool pair_ok = Qg < a.Bn * F1 * P;
+    const int b = Qg / (F1 * P), Q = Qg - b * (F1 * P);
     const int f1 = Q / P, p = Q - f1 * P;
     const unsigned vo_row = pair_ok ? 4u * (unsigned)((b * 2 * F + f1) * Ti + 2 * p * hop) : BUF_OOB;
     if (kq == 0) obase[pl] = pair_ok ? (4u * (unsigned)(((b * F1 + f1) * T1 + 2 * p) * CS) | (2 * p + 1 < T1 ? 1u : 0u)) : 0xffffffffu;

@@ -12,7 +12,7 @@
 // with Wa + Wb summed on the host in fp64 (xsq_model::d_upool), and its K is exact: 52 channels as three chunks of 16 and
 // one MFMA of the four tail channels per product and column block, where the GEMM pads 104 to 112.
 //
-// Tile = 64 consecutive output pairs of one batch item in the flattened (f, pair) space x one column tile of 16 NCB <= 64
+// Tile = 64 consecutive output pairs of the flattened (b, f, pair) space x one column tile of 16 NCB <= 64
 // columns; 256 threads = 4 waves x 16 pairs.  To = 2 S is even: every pair has both outputs.
 //  * B operand: the column tile's three weight tiles of ONE frequency tap ([component][column][52 k], 13 KB per 16 columns)
 //    go into LDS whole, once per tap -- for the 67 of 70 blocks with one tap the K loop has NO barrier and no stream.
@@ -50,10 +50,10 @@ __host__ __device__ constexpr int l4f_u_off(int W, int n0, int j, int n, int ci)
 }
 
 struct L4fTileDev {                // 64 bytes: one scalar load
-    int Q0, kf, F, F1;             // first pair of the tile (f * P + p inside batch item b); taps; output / input rows
+    int Q0, kf, F, F1;             // first pair of the tile in the flattened (b, f, pair) space; taps; output / input rows
     int64_t in_off, out_off;       // the (block, target)'s act3 / masks, in floats
     int64_t bias_off, u_off;       // output bias (2) inside the pool / the column tile's weights of tap 0 inside the Winograd pool
-    int b, hop, n0, P;             // batch item, hop, first column of the tile, pairs per (b, f) row = S
+    int pad0, hop, n0, P;          // -, hop, first column of the tile, pairs per (b, f) row = S
 };
 static_assert(sizeof(L4fTileDev) == 64, "L4fTileDev is meant to be one 64-byte scalar load");
 
@@ -62,15 +62,16 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
 #pragma clang fp contract(off)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, kq = lane >> 4;
-    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, b = t.b, hop = t.hop, n0 = t.n0;
+    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, hop = t.hop, n0 = t.n0;
     const int T1 = a.T1, W = 2 * hop;
     const int ST = a.S * W;                                      // floats of one (b, c, f) output row
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.act3 + t.in_off, 4u * (unsigned)(a.Bn * F1 * T1 * CS));   // (< 2^30 bytes: cdae_launch_layer)
 
     // ---- this lane's pair
     const int pl = wave * 16 + q;
-    const int Q = t.Q0 + pl;
-    const bool pair_ok = Q < F * P;
+    const int Qg = t.Q0 + pl;                                    // pair of the flattened (b, f, pair) space: tiles run across batch items
+    const bool pair_ok = Qg < a.Bn * F * P;
+    const int b = Qg / (F * P), Q = Qg - b * (F * P);
     const int f = Q / P, p = Q - f * P;
     if (kq == 0) obase[pl] = pair_ok ? 4u * (unsigned)((b * 2 * F + f) * ST + 2 * p * hop) : 0xffffffffu;
     // positions 2 p - 1 (exists for p > 0), 2 p, 2 p + 1 (exists below T1 = 2 S - 1: not for the row's last pair)
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void cdae_l4f_kernel(Cda
     __shared__ unsigned obase[L4_PAIRS];                         // byte offset of a pair's first output (channel 0, dt 0) inside the target's masks
     const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
-                 "s"(t.b), "s"(t.hop), "s"(t.n0), "s"(t.P));
+                 "s"(t.hop), "s"(t.n0), "s"(t.P));
     const int rem = l4f_cols(2 * t.hop) - t.n0;                  // (workgroup-uniform)
     if (rem >= 64) cdae_l4f_body<4>(a, t, Bs, obase);
     else if (rem == 48) cdae_l4f_body<3>(a, t, Bs, obase);
