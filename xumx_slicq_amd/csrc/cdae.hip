@@ -793,17 +793,23 @@ static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
         L4fTileDev e;
         e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.P = P;
         const int total = Bn * d.F * P;                    // tiles run across batch items: (b, f, pair) flattened
-        e.pad0 = 0;
+        const int rtiles = (total + L4_PAIRS - 1) / L4_PAIRS;
+        // one tap: a workgroup keeps its column tile's weights in LDS for a run of consecutive row tiles (cdae_l4f.h); runs of
+        // equal length, at most l4f_run row tiles
+        static const int l4f_run = getenv("XSQ_L4F_RUN") ? std::max(1, atoi(getenv("XSQ_L4F_RUN"))) : 6;
+        const int nruns = d.kf == 1 ? (rtiles + l4f_run - 1) / l4f_run : rtiles;
         for (int tgt = 0; tgt < NT; ++tgt) {
             e.in_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
             e.out_off = (int64_t)Bn * 8 * S * d.cum + (int64_t)tgt * Bn * 2 * FST;
             e.bias_off = d.b4[tgt];
-            for (int Q = 0; Q < total; Q += L4_PAIRS)
+            for (int r = 0; r < nruns; ++r) {
+                const int t0 = (int)((int64_t)rtiles * r / nruns), t1 = (int)((int64_t)rtiles * (r + 1) / nruns);
                 for (int n0 = 0; n0 < cols; n0 += 64) {
-                    e.Q0 = Q; e.n0 = n0;
+                    e.Q0 = t0 * L4_PAIRS; e.run = t1 - t0; e.n0 = n0;
                     e.u_off = d.u4[tgt] + (int64_t)3 * CS * n0;
                     t.push_back(e);
                 }
+            }
         }
     }
     TileTable tt;                    // (d_tiles holds L4fTileDev entries for this key: cast at the launch site)
