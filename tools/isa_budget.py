@@ -102,9 +102,9 @@ template <int NCB>
 __global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void l4f_body_probe(CdaeArgs a, const L4fTileDev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float Bs[L4_BROWS * L4_BLD];
     const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
-                 "s"(t.run), "s"(t.hop), "s"(t.n0), "s"(t.P));
-    cdae_l4f_body<NCB>(a, t, Bs);
+    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.run), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
+                 "s"(t.hop), "s"(t.n0), "s"(t.P), "s"(t.x_off));
+    cdae_l4f_body<NCB, false>(a, t, Bs);
 }
 template __global__ void l4f_body_probe<1>(CdaeArgs, const L4fTileDev*, int);
 template __global__ void l4f_body_probe<2>(CdaeArgs, const L4fTileDev*, int);

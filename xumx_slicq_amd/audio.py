@@ -99,18 +99,20 @@ def load_audio_into(path: str, take) -> Tuple[torch.Tensor, int]:
         out = take(2 * n)[:2 * n].view(2, n)
         out.copy_(preprocess_audio(sig)[0])
         return out, rate
-    dt, scale, bias = {(3, 32): (torch.float32, None, 0.0), (3, 64): (torch.float64, None, 0.0), (1, 8): (torch.uint8, 1.0 / 128.0, -128.0),
-                       (1, 16): (torch.int16, 1.0 / 32768.0, 0.0), (1, 32): (torch.int32, 1.0 / 2147483648.0, 0.0)}[(tag, bits)]
+    dt, scale, bias = {(3, 32): ("<f4", None, 0.0), (3, 64): ("<f8", None, 0.0), (1, 8): (np.uint8, 1.0 / 128.0, -128.0),
+                       (1, 16): ("<i2", 1.0 / 32768.0, 0.0), (1, 32): ("<i4", 1.0 / 2147483648.0, 0.0)}[(tag, bits)]
     out = take(2 * n)[:2 * n].view(2, n)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")     # (the bytes object is read-only; nothing writes through the view)
-        frames = torch.frombuffer(raw, dtype=dt).view(n, channels)
-    # one converting, de-interleaving copy per file (a strided read, a contiguous write), then the scale in place
-    out.copy_(frames[:, :2].T if channels >= 2 else frames.T.expand(2, n))
+    dst = out.numpy()
+    frames = np.frombuffer(raw, dtype=dt).reshape(n, channels)
+    # one converting, de-interleaving pass per channel (a strided read, a contiguous float32 write), then the scale in place --
+    # in numpy: single-threaded inside the reader thread that called (a torch copy_ fans out over every core of the host and
+    # measured 2.4x SLOWER on the 100-core GPU box than here)
+    for c in range(2):
+        dst[c] = frames[:, min(c, channels - 1)]             # mono is duplicated
     if bias:
-        out.add_(bias)
+        np.add(dst, np.float32(bias), out=dst)
     if scale is not None:
-        out.mul_(scale)
+        np.multiply(dst, np.float32(scale), out=dst)
     return out, rate
 
 

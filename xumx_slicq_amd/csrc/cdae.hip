@@ -791,7 +791,7 @@ static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
         const int W = d.T, cols = l4f_cols(W);
         const int64_t FST = (int64_t)d.F * S * d.T;
         L4fTileDev e;
-        e.kf = d.kf; e.F = d.F; e.F1 = d.F1; e.hop = d.hop; e.P = P;
+        e.kf = d.kf; e.F = d.F; e.hop = d.hop; e.P = P; e.x_off = (int)((int64_t)Bn * 2 * S * d.cum);
         const int total = Bn * d.F * P;                    // tiles run across batch items: (b, f, pair) flattened
         const int rtiles = (total + L4_PAIRS - 1) / L4_PAIRS;
         // one tap: a workgroup keeps its column tile's weights in LDS for a run of consecutive row tiles (cdae_l4f.h); runs of
@@ -1158,12 +1158,17 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
     }
     bool l4f_fits = true;            // cdae_l4f.h runs several frequency taps only on column tiles of <= 32 columns
     for (const CdaeBlockDev& d : Mo->blocks) l4f_fits = l4f_fits && (d.kf == 1 || d.T <= 32);
-    if (layer == 4 && l4f_fits && !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && !a.causal && !a.Y && a.masks && a.upool && (Mo->winograd & 4)) {
-        // fp32 inference, masks only (the separator's path), non-causal: F(2, 2) along the hop (cdae_l4f.h)
+    if (layer == 4 && l4f_fits && !bf3 && !bf6 && !a.raw && !a.xin8 && !a.gx8 && !a.causal && (a.Y || a.masks) && a.upool && (Mo->winograd & 4)) {
+        // fp32 inference, non-causal: F(2, 2) along the hop (cdae_l4f.h) -- masks only (the separator's path) or with the
+        // estimates materialised (the module API): one kernel, the same masks bit for bit
+        for (const CdaeBlockDev& d : Mo->blocks)
+            XSQ_REQUIRE((int64_t)8 * 2 * a.Bn * d.F * a.S * d.T < ((int64_t)1 << 31) && (int64_t)a.Bn * 2 * a.S * d.cum < ((int64_t)1 << 31),
+                        "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block's coefficients; split the batch", a.Bn, a.S);
         int rcf = get_l4f_tiles(Mo, a.Bn, a.S, &tt);
         if (rcf) return rcf;
         XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
-        hipLaunchKernelGGL(cdae_l4f_kernel, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
+        if (a.Y) hipLaunchKernelGGL(cdae_l4f_kernel<true>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
+        else hipLaunchKernelGGL(cdae_l4f_kernel<false>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity

@@ -53,19 +53,20 @@ __host__ __device__ constexpr int l4f_u_off(int W, int n0, int j, int n, int ci)
 }
 
 struct L4fTileDev {                // 64 bytes: one scalar load
-    int Q0, kf, F, F1;             // first pair of the tile in the flattened (b, f, pair) space; taps; output / input rows
-    int64_t in_off, out_off;       // the (block, target)'s act3 / masks, in floats
+    int Q0, kf, F, run;            // first pair of the run in the flattened (b, f, pair) space; taps; output rows; row tiles of 64 pairs this
+                                   // workgroup runs (1 with several taps)
+    int64_t in_off, out_off;       // the (block, target)'s act3, in floats / its masks, in floats (= its estimates inside Y, in float2)
     int64_t bias_off, u_off;       // output bias (2) inside the pool / the column tile's weights of tap 0 inside the Winograd pool
-    int run, hop, n0, P;           // row tiles of 64 pairs this workgroup runs (1 with several taps), hop, first column of the tile, pairs per (b, f) row = S
+    int hop, n0, P, x_off;         // hop, first column of the tile, pairs per (b, f) row = S, the block's mix coefficients inside X in float2
 };
 static_assert(sizeof(L4fTileDev) == 64, "L4fTileDev is meant to be one 64-byte scalar load");
 
-template <int NCB>
+template <int NCB, bool WITH_Y>
 __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDev& t, float* const Bs) {
 #pragma clang fp contract(off)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, kq = lane >> 4;
-    const int kf = t.kf, F = t.F, F1 = t.F1, P = t.P, hop = t.hop, n0 = t.n0, run = t.run;
+    const int kf = t.kf, F = t.F, F1 = t.F - t.kf + 1, P = t.P, hop = t.hop, n0 = t.n0, run = t.run;
     const int T1 = a.T1, W = 2 * hop;
     const int ST = a.S * W;                                      // floats of one (b, c, f) output row
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(a.act3 + t.in_off, 4u * (unsigned)(a.Bn * F1 * T1 * CS));   // (< 2^30 bytes: cdae_launch_layer)
@@ -184,10 +185,32 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     // boundary n = hop falls between quads); two 8-byte stores per quad otherwise (hop % 4 == 2: the boundary halves a quad).
     const float* bias = a.pool + t.bias_off;
     const float bias0 = bias[0], bias1 = bias[1];
-    const __amdgpu_buffer_rsrc_t rm = buf_rsrc(a.masks + t.out_off, 0x40000000u);
+    const __amdgpu_buffer_rsrc_t rm = buf_rsrc(a.masks ? a.masks + t.out_off : a.pool, a.masks ? 0x40000000u : 0u);
+    // WITH_Y (the module API, Unmix.forward: the estimates are materialised): Y = mask * X, a rounded product per component as
+    // CdaeL4Op stores it and as the masked decoder forms it -- the masks-only call and this one stay bitwise interchangeable
+    const __amdgpu_buffer_rsrc_t rx = buf_rsrc(WITH_Y ? reinterpret_cast<const float2*>(a.X) + t.x_off : nullptr, WITH_Y ? 0x80000000u : 0u);
+    const __amdgpu_buffer_rsrc_t ry = buf_rsrc(WITH_Y ? reinterpret_cast<float2*>(a.Y) + t.out_off : nullptr, WITH_Y ? 0x80000000u : 0u);
     const bool quads = (hop & 3) == 0;                           // (uniform)
+    auto emit = [&](int om, bool ok, const float* y0, const float* y1, auto cnt_c) {      // cnt values of u and of u + 1 at element offset om
+        constexpr int CNT = decltype(cnt_c)::value;
+        if (!WITH_Y || a.masks) {
+            const unsigned vo = ok ? 4u * (unsigned)om : BUF_OOB;
+            if constexpr (CNT == 4) { buf_st4(make_float4(y0[0], y0[1], y0[2], y0[3]), rm, vo, 0); buf_st4(make_float4(y1[0], y1[1], y1[2], y1[3]), rm, vo, 4 * hop); }
+            else { buf_st2(make_float2(y0[0], y0[1]), rm, vo, 0); buf_st2(make_float2(y1[0], y1[1]), rm, vo, 4 * hop); }
+        }
+        if constexpr (WITH_Y) {
+            const unsigned vx = ok ? 8u * (unsigned)om : 0xfffffff0u;         // (the mix and the estimates are 8 bytes per element: ranges up to 2^31)
+#pragma unroll
+            for (int hf = 0; hf < CNT / 2; ++hf) {
+                const float4 xa = buf_ld4(rx, vx, 16 * hf), xb = buf_ld4(rx, vx, 8 * hop + 16 * hf);
+                const float a0 = y0[2 * hf], a1 = y0[2 * hf + 1], b0 = y1[2 * hf], b1 = y1[2 * hf + 1];
+                buf_st4(make_float4(a0 * xa.x, a0 * xa.y, a1 * xa.z, a1 * xa.w), ry, vx, 16 * hf);
+                buf_st4(make_float4(b0 * xb.x, b0 * xb.y, b1 * xb.z, b1 * xb.w), ry, vx, 8 * hop + 16 * hf);
+            }
+        }
+    };
     auto epilogue = [&](const Pair& pr) {
-        const unsigned ob = pr.ok ? 4u * (unsigned)((pr.b * 2 * F + pr.f) * ST + 2 * pr.p * hop) : BUF_OOB;
+        const int ob = (pr.b * 2 * F + pr.f) * ST + 2 * pr.p * hop;          // element offset of (channel 0, dt 0) of the pair's first output
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int n = n0 + 16 * cb + 4 * kq;                 // first column of the quad
@@ -199,20 +222,16 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
                 y0[r] = __builtin_amdgcn_rcpf(1.f + __expf(-((m1 + m2) + bs)));
                 y1[r] = __builtin_amdgcn_rcpf(1.f + __expf(-((m2 + m3) + bs)));
             }
-            const bool live = !((XSQ_L4F_ABL & 16) && y0[0] != 1.2345e-30f);
+            const bool live = pr.ok && !((XSQ_L4F_ABL & 16) && y0[0] != 1.2345e-30f);
             if (quads) {
                 const int c = n >= hop ? 1 : 0;
-                const unsigned vo = (n < W && live) ? ob + 4u * (unsigned)(c * F * ST + n - c * hop) : BUF_OOB;
-                buf_st4(make_float4(y0[0], y0[1], y0[2], y0[3]), rm, vo, 0);
-                buf_st4(make_float4(y1[0], y1[1], y1[2], y1[3]), rm, vo, 4 * hop);
+                emit(ob + c * F * ST + n - c * hop, live && n < W, y0, y1, std::integral_constant<int, 4>{});
             } else {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int nh = n + 2 * hf;
                     const int c = nh >= hop ? 1 : 0;
-                    const unsigned vo = (nh < W && live) ? ob + 4u * (unsigned)(c * F * ST + nh - c * hop) : BUF_OOB;
-                    buf_st2(make_float2(y0[2 * hf], y0[2 * hf + 1]), rm, vo, 0);
-                    buf_st2(make_float2(y1[2 * hf], y1[2 * hf + 1]), rm, vo, 4 * hop);
+                    emit(ob + c * F * ST + nh - c * hop, live && nh < W, y0 + 2 * hf, y1 + 2 * hf, std::integral_constant<int, 2>{});
                 }
             }
         }
@@ -264,16 +283,17 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     }
 }
 
+template <bool WITH_Y>
 __global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void cdae_l4f_kernel(CdaeArgs a, const L4fTileDev* __restrict__ tiles, int ntiles) {
     __shared__ __attribute__((aligned(16))) float Bs[L4_BROWS * L4_BLD];
     const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
-    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.F1), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
-                 "s"(t.run), "s"(t.hop), "s"(t.n0), "s"(t.P));
+    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.run), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
+                 "s"(t.hop), "s"(t.n0), "s"(t.P), "s"(t.x_off));
     const int rem = l4f_cols(2 * t.hop) - t.n0;                  // (workgroup-uniform)
-    if (rem >= 64) cdae_l4f_body<4>(a, t, Bs);
-    else if (rem == 48) cdae_l4f_body<3>(a, t, Bs);
-    else if (rem == 32) cdae_l4f_body<2>(a, t, Bs);
-    else cdae_l4f_body<1>(a, t, Bs);
+    if (rem >= 64) cdae_l4f_body<4, WITH_Y>(a, t, Bs);
+    else if (rem == 48) cdae_l4f_body<3, WITH_Y>(a, t, Bs);
+    else if (rem == 32) cdae_l4f_body<2, WITH_Y>(a, t, Bs);
+    else cdae_l4f_body<1, WITH_Y>(a, t, Bs);
 }
 
 }  // namespace xsq

@@ -50,13 +50,39 @@ class _CausalConv2d(Conv2d):
         super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=0, bias=bias)
 
 
+class _no_parameter_init:
+    """Context: Conv / BatchNorm modules constructed inside leave their parameters as allocated and ZERO them instead of drawing
+    the Kaiming / unit initialisation (``reset_parameters`` is what costs: a third of Unmix() for weights a checkpoint replaces
+    a moment later).  Not re-entrant; construction is single-threaded."""
+
+    def __enter__(self):
+        from torch.nn.modules.batchnorm import _NormBase
+        from torch.nn.modules.conv import _ConvNd
+        self._saved = (_ConvNd.reset_parameters, _NormBase.reset_parameters)
+
+        def zero(mod):
+            with torch.no_grad():
+                for t in list(mod._parameters.values()) + list(mod._buffers.values()):
+                    if t is not None:
+                        t.zero_()
+        _ConvNd.reset_parameters = zero
+        _NormBase.reset_parameters = zero
+        return self
+
+    def __exit__(self, *exc):
+        from torch.nn.modules.batchnorm import _NormBase
+        from torch.nn.modules.conv import _ConvNd
+        _ConvNd.reset_parameters, _NormBase.reset_parameters = self._saved
+        return False
+
+
 class _SlicedUnmixCDAE(nn.Module):
     """model.py:86-211: the four target CDAEs of one time-frequency block."""
 
     def __init__(self, slicq_sample_input, hidden_size_1: int = 50, hidden_size_2: int = 51,
                  freq_filter_small: int = 1, freq_filter_medium: int = 3, freq_filter_large: int = 5,
                  freq_thresh_small: int = 10, freq_thresh_medium: int = 20, time_filter_2: int = 4,
-                 realtime: bool = False, input_mean=None, input_scale=None):
+                 realtime: bool = False, input_mean=None, input_scale=None, weights_follow: bool = False):
         super().__init__()
         if (hidden_size_1, hidden_size_2, time_filter_2) != (50, 51, 4) or \
                 (freq_filter_small, freq_filter_medium, freq_filter_large,
@@ -69,18 +95,27 @@ class _SlicedUnmixCDAE(nn.Module):
         kf = freq_filter(nb_f_bins)
         window, hop = nb_t_bins, nb_t_bins // 2
         first = _CausalConv2d if realtime else Conv2d
-        layers = [
-            first(nb_channels, hidden_size_1, (kf, window), stride=(1, hop), bias=False),
-            BatchNorm2d(hidden_size_1), ReLU(),
-            Conv2d(hidden_size_1, hidden_size_2, (kf, time_filter_2), bias=False),
-            BatchNorm2d(hidden_size_2), ReLU(),
-            ConvTranspose2d(hidden_size_2, hidden_size_1, (kf, time_filter_2), bias=False),
-            BatchNorm2d(hidden_size_1), ReLU(),
-            ConvTranspose2d(hidden_size_1, nb_channels, (kf, window), stride=(1, hop), bias=True),
-            Sigmoid(),
-        ]
-        cdae = Sequential(*layers)
-        self.cdaes = nn.ModuleList([cdae] + [copy.deepcopy(cdae) for _ in range(3)])
+
+        def stack(make):
+            return Sequential(
+                make(first, nb_channels, hidden_size_1, (kf, window), stride=(1, hop), bias=False),
+                make(BatchNorm2d, hidden_size_1), ReLU(),
+                make(Conv2d, hidden_size_1, hidden_size_2, (kf, time_filter_2), bias=False),
+                make(BatchNorm2d, hidden_size_2), ReLU(),
+                make(ConvTranspose2d, hidden_size_2, hidden_size_1, (kf, time_filter_2), bias=False),
+                make(BatchNorm2d, hidden_size_1), ReLU(),
+                make(ConvTranspose2d, hidden_size_1, nb_channels, (kf, window), stride=(1, hop), bias=True),
+                Sigmoid())
+        if weights_follow:
+            # a checkpoint is loaded right after construction (build_models(state=...)): no Kaiming initialisation of 15 M
+            # weights that are about to be overwritten and no deep copies (0.7 of the 0.9 s of Unmix() -- what a user of
+            # Separator.load waits for, tools/cold_start.py); parameters and BatchNorm statistics start as ZEROS, strict
+            # loading guarantees that every one of them is replaced
+            with _no_parameter_init():
+                self.cdaes = nn.ModuleList([stack(lambda cls, *a, **k: cls(*a, **k)) for _ in range(4)])
+        else:
+            cdae = stack(lambda cls, *a, **k: cls(*a, **k))
+            self.cdaes = nn.ModuleList([cdae] + [copy.deepcopy(cdae) for _ in range(3)])
         self.mask = True
         self.realtime = realtime          # read per call: True -> mix-phase, False -> Wiener-EM (model.py:264)
         self.causal = realtime            # fixed at construction (model.py:125-128)
@@ -177,7 +212,7 @@ class Unmix(nn.Module):
     """model.py:29-82."""
 
     def __init__(self, jagged_slicq_sample_input, realtime: bool = False, lstm: bool = False,
-                 input_means=None, input_scales=None):
+                 input_means=None, input_scales=None, weights_follow: bool = False):
         super().__init__()
         if lstm:
             raise ValueError("the LSTM variant is not on the accelerated path (SURVEY.md 2, row 4b)")
@@ -187,7 +222,7 @@ class Unmix(nn.Module):
             self.sliced_umx.append(_SlicedUnmixCDAE(
                 C_block, realtime=realtime,
                 input_mean=input_means[i] if input_means else None,
-                input_scale=input_scales[i] if input_scales else None))
+                input_scale=input_scales[i] if input_scales else None, weights_follow=weights_follow))
             shapes.append((C_block.shape[2], C_block.shape[4]))
         self.table = BlockTable(shapes)
         self._F = np.asarray([s[0] for s in shapes], dtype=np.int32)
@@ -214,11 +249,25 @@ class Unmix(nn.Module):
     def _version(self) -> int:
         return getattr(self, "_stamp", 0)
 
-    def load_state_dict(self, *args, **kwargs):
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """nn.Module.load_state_dict; a strict load of a well-formed checkpoint (same keys, same shapes) takes a direct
+        path -- one ``copy_`` per tensor instead of a walk over 3,500 modules (0.1 s of Separator.load); anything else goes
+        through the module walk and fails (or reports) exactly as torch does."""
         self.refresh()
-        return super().load_state_dict(*args, **kwargs)
+        if strict and not assign:
+            own = self.__dict__.get("_own_tensors")
+            if own is None:
+                own = self.__dict__["_own_tensors"] = {**dict(self.named_parameters()), **dict(self.named_buffers())}
+            if len(own) == len(state_dict) and all(k in own and own[k].shape == v.shape for k, v in state_dict.items()):
+                with torch.no_grad():
+                    for k, v in state_dict.items():
+                        own[k].copy_(v)
+                from torch.nn.modules.module import _IncompatibleKeys
+                return _IncompatibleKeys([], [])
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_own_tensors", None)            # (.to(device) may replace parameter objects)
         self.refresh()
         return super()._apply(fn, *args, **kwargs)
 
@@ -245,9 +294,12 @@ class Unmix(nn.Module):
     def packed_parameters(self) -> np.ndarray:
         """fp32 tensors of the state_dict in key order, num_batches_tracked left out
         (the host buffer xsq_model_create expects)."""
-        parts = [v.detach().to("cpu", torch.float32).reshape(-1)
-                 for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")]
-        return torch.cat(parts).numpy()
+        # (state_dict order = registration order: parameters, then buffers, per module; built without the state_dict's
+        #  OrderedDict + hooks and without 5,740 .to() calls when everything already is fp32 on one device: 0.46 -> 0.05 s)
+        parts = [v.detach().reshape(-1) for k, v in self.state_dict(keep_vars=True).items() if not k.endswith("num_batches_tracked")]
+        if all(p.dtype == torch.float32 for p in parts) and len({p.device for p in parts}) == 1:
+            return torch.cat(parts).cpu().numpy()
+        return torch.cat([p.to("cpu", torch.float32) for p in parts]).numpy()
 
     def _model(self, device: torch.device):
         if device.type != "cuda":

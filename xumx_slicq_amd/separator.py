@@ -458,7 +458,7 @@ def build_models(fscale: str = "bark", fbins: int = 262, fmin: float = 32.9, sam
     jagged_slicq, _ = nsgt_base.predict_input_size(1, 2, seq_dur)
     cnorm = ComplexNorm()
     nsgt, insgt = make_filterbanks(nsgt_base, sample_rate)
-    xumx_model = Unmix(cnorm(jagged_slicq), realtime=realtime)
+    xumx_model = Unmix(cnorm(jagged_slicq), realtime=realtime, weights_follow=state is not None and strict)
     if state is not None:
         # the reference loads with strict=False and silently drops mismatches (quirk A7); be strict
         xumx_model.load_state_dict(state, strict=strict)
