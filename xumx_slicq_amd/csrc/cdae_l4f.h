@@ -33,6 +33,10 @@
 #ifndef XSQ_L4F_WAVES_PER_EU
 #define XSQ_L4F_WAVES_PER_EU 3
 #endif
+#ifndef XSQ_L4F_SCHED
+#define XSQ_L4F_SCHED 0     // what may cross the scheduling barrier behind a group of MFMAs: nothing (measured: 0.535 ms; everything but LDS
+                            // operations, 0x7e: 0.551; no barrier at all, 0x3ff: 0.550 -- profiles/r11_ab_runs.txt r11p)
+#endif
 #ifndef XSQ_L4F_ABL
 #define XSQ_L4F_ABL 0       // diagnostic builds (wrong results, timings only): 4 no weight tiles, 8 no operand loads, 16 no epilogue stores
 #endif
@@ -112,28 +116,38 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     // ---- operands of (pair, tap): input row f - df, positions 2 p - 1 (exists for p > 0), 2 p, 2 p + 1 (exists below T1 =
     // 2 S - 1: not for the row's last pair), channels 16 s + 4 kq .. (s < 3) and 48 + kq
     struct Ops { float4 x[3][3]; float xt[3]; };
-    auto load_a = [&](Ops& o, const Pair& pr, int df) {
+    struct Addr { unsigned v0, v1, v2; };                        // byte offsets of the three positions' channel quad 4 kq (BUF_OOB: reads as zero)
+    auto addr_of = [&](const Pair& pr, int df) {
         const int fi = pr.f - df;
         const bool row_ok = pr.ok && (unsigned)fi < (unsigned)F1;
         const unsigned base = 4u * (unsigned)(((pr.b * F1 + fi) * T1 + 2 * pr.p - 1) * CS + 4 * kq);
-        const unsigned v0 = (row_ok && pr.p > 0) ? base : BUF_OOB, v1 = row_ok ? base + 4u * CS : BUF_OOB,
-                       v2 = (row_ok && 2 * pr.p + 1 < T1) ? base + 8u * CS : BUF_OOB;
+        Addr ad;
+        ad.v0 = (row_ok && pr.p > 0) ? base : BUF_OOB;
+        ad.v1 = row_ok ? base + 4u * CS : BUF_OOB;
+        ad.v2 = (row_ok && 2 * pr.p + 1 < T1) ? base + 8u * CS : BUF_OOB;
+        return ad;
+    };
+    // chunk s < 3: channels 16 s + 4 kq ..; s == 3: channel 48 + kq, the lane's own word of the tail quad (the offsets carry 4 kq
+    // channels = 16 kq bytes: 192 + 4 kq from the row = offset + 192 - 12 kq)
+    auto load_chunk_a = [&](Ops& o, const Addr& ad, int s) {
         if (XSQ_L4F_ABL & 8) {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) { o.x[0][s] = make_float4(1.f, 2.f, 3.f, (float)v0); o.x[1][s] = make_float4(2.f, 3.f, 1.f, (float)v1); o.x[2][s] = make_float4(3.f, 1.f, 2.f, (float)v2); }
-            o.xt[0] = 1.f; o.xt[1] = 2.f; o.xt[2] = 3.f;
+            if (s < 3) { o.x[0][s] = make_float4(1.f, 2.f, 3.f, (float)ad.v0); o.x[1][s] = make_float4(2.f, 3.f, 1.f, (float)ad.v1); o.x[2][s] = make_float4(3.f, 1.f, 2.f, (float)ad.v2); }
+            else { o.xt[0] = 1.f; o.xt[1] = 2.f; o.xt[2] = 3.f; }
             return;
         }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            o.x[0][s] = buf_ld4(rin, v0, 64 * s);
-            o.x[1][s] = buf_ld4(rin, v1, 64 * s);
-            o.x[2][s] = buf_ld4(rin, v2, 64 * s);
+        if (s < 3) {
+            o.x[0][s] = buf_ld4(rin, ad.v0, 64 * s);
+            o.x[1][s] = buf_ld4(rin, ad.v1, 64 * s);
+            o.x[2][s] = buf_ld4(rin, ad.v2, 64 * s);
+        } else {
+            o.xt[0] = buf_ld1(rin, ad.v0 - 12u * (unsigned)kq, 192);
+            o.xt[1] = buf_ld1(rin, ad.v1 - 12u * (unsigned)kq, 192);
+            o.xt[2] = buf_ld1(rin, ad.v2 - 12u * (unsigned)kq, 192);
         }
-        // channel 48 + kq: the lane's own word of the tail quad (base carries 4 kq channels = 16 kq bytes: 192 + 4 kq from the row = base + 192 - 12 kq)
-        o.xt[0] = buf_ld1(rin, v0 - 12u * (unsigned)kq, 192);
-        o.xt[1] = buf_ld1(rin, v1 - 12u * (unsigned)kq, 192);
-        o.xt[2] = buf_ld1(rin, v2 - 12u * (unsigned)kq, 192);
+    };
+    auto load_a = [&](Ops& o, const Addr& ad) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) load_chunk_a(o, ad, s);
     };
 
     f32x4 acc[3][NCB];
@@ -144,31 +158,48 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
             for (int cb = 0; cb < NCB; ++cb) acc[j][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     const int bf = q * L4_BLD + 4 * kq;                          // weight tile: column q of a 16-column block, k-quad kq
-    // one tap of one row tile against the weight tiles in LDS
-    auto contract = [&](const Ops& o) {
+    // one tap of one row tile against the weight tiles in LDS: nine groups (chunk s, component j) of 4 NCB MFMAs and the tail
+    // group.  The fragments of group g + 1 are read while group g computes, and a scheduling barrier closes every group: left
+    // alone the compiler hoists the fragment reads of ALL groups to the top (36 NCB registers: 205 spilled registers in the
+    // 64-column body, measured by tools/isa_budget.py's probe kernels).
+    // `refill`: chunk s of the NEXT operand set (`nx`: the next row tile of the run, or the next tap) is requested into the
+    // registers of chunk s as soon as that chunk has been transformed -- one operand set in registers instead of two (a second
+    // set in flight cost 39 registers: 58 spilled in the 64-column body); the request is a whole row tile ahead of its use.
+    auto contract = [&](Ops& o, const Addr& nx, bool refill) {
+        float4 w[2][NCB];
+        auto read_w = [&](int g, float4 (&dst)[NCB]) {
+            const int s = g / 3, j = g - 3 * s;
+            const float* Bj = Bs + j * 64 * L4_BLD + bf + 16 * s;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const float4 x0 = o.x[0][s], x1 = o.x[1][s], x2 = o.x[2][s];
-            const float d[3][4] = {{x0.x - x1.x, x0.y - x1.y, x0.z - x1.z, x0.w - x1.w}, {x1.x, x1.y, x1.z, x1.w},
-                                   {x2.x - x1.x, x2.y - x1.y, x2.z - x1.z, x2.w - x1.w}};
+            for (int cb = 0; cb < NCB; ++cb) dst[cb] = *reinterpret_cast<const float4*>(&Bj[cb * 16 * L4_BLD]);
+        };
+        read_w(0, w[0]);
+        float d[3][4];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float* Bj = Bs + j * 64 * L4_BLD + bf + 16 * s;
-                float4 w[NCB];
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) w[cb] = *reinterpret_cast<const float4*>(&Bj[cb * 16 * L4_BLD]);
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    // (the WEIGHTS are the MFMA's row operand: accumulator register r of a lane is column 4 kq + r of the block for the
-                    //  lane's OWN pair q -- four consecutive outputs of one row: 16-byte stores, no exchange of output offsets)
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].x, d[j][0], acc[j][cb], 0, 0, 0);
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].y, d[j][1], acc[j][cb], 0, 0, 0);
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].z, d[j][2], acc[j][cb], 0, 0, 0);
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].w, d[j][3], acc[j][cb], 0, 0, 0);
-                }
+        for (int g = 0; g < 9; ++g) {
+            const int s = g / 3, j = g - 3 * s;
+            if (j == 0) {
+                const float4 x0 = o.x[0][s], x1 = o.x[1][s], x2 = o.x[2][s];
+                d[0][0] = x0.x - x1.x; d[0][1] = x0.y - x1.y; d[0][2] = x0.z - x1.z; d[0][3] = x0.w - x1.w;
+                d[1][0] = x1.x; d[1][1] = x1.y; d[1][2] = x1.z; d[1][3] = x1.w;
+                d[2][0] = x2.x - x1.x; d[2][1] = x2.y - x1.y; d[2][2] = x2.z - x1.z; d[2][3] = x2.w - x1.w;
             }
+            if (j == 0 && refill) load_chunk_a(o, nx, s);
+            if (g < 8) read_w(g + 1, w[(g + 1) & 1]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                // (the WEIGHTS are the MFMA's row operand: accumulator register r of a lane is column 4 kq + r of the block for the
+                //  lane's OWN pair q -- four consecutive outputs of one row: 16-byte stores, no exchange of output offsets)
+                const float4 wv = w[g & 1][cb];
+                acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, d[j][0], acc[j][cb], 0, 0, 0);
+                acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, d[j][1], acc[j][cb], 0, 0, 0);
+                acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, d[j][2], acc[j][cb], 0, 0, 0);
+                acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, d[j][3], acc[j][cb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(XSQ_L4F_SCHED);
         }
         const float dt[3] = {o.xt[0] - o.xt[1], o.xt[1], o.xt[2] - o.xt[1]};
+        if (refill) load_chunk_a(o, nx, 3);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float* Bj = Bs + j * 64 * L4_BLD + bf - 4 * kq + 48 + kq;      // channel 48 + kq of column q
@@ -178,11 +209,8 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[j][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[cb], dt[j], acc[j][cb], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(XSQ_L4F_SCHED);
     };
-    // out[u] = m1 + m2, out[u + 1] = m2 + m3, + bias[c], sigmoid (the formula of CdaeL4Op).  Accumulator register r of this lane is
-    // column n0 + 16 cb + 4 kq + r of the lane's own pair: the four values of a quad are consecutive in the output row -- one
-    // 16-byte store each for u and u + 1 when the hop is a multiple of 4 (every address is then 16-byte aligned and the channel
-    // boundary n = hop falls between quads); two 8-byte stores per quad otherwise (hop % 4 == 2: the boundary halves a quad).
     const float* bias = a.pool + t.bias_off;
     const float bias0 = bias[0], bias1 = bias[1];
     const __amdgpu_buffer_rsrc_t rm = buf_rsrc(a.masks ? a.masks + t.out_off : a.pool, a.masks ? 0x40000000u : 0u);
@@ -191,22 +219,41 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     const __amdgpu_buffer_rsrc_t rx = buf_rsrc(WITH_Y ? reinterpret_cast<const float2*>(a.X) + t.x_off : nullptr, WITH_Y ? 0x80000000u : 0u);
     const __amdgpu_buffer_rsrc_t ry = buf_rsrc(WITH_Y ? reinterpret_cast<float2*>(a.Y) + t.out_off : nullptr, WITH_Y ? 0x80000000u : 0u);
     const bool quads = (hop & 3) == 0;                           // (uniform)
-    auto emit = [&](int om, bool ok, const float* y0, const float* y1, auto cnt_c) {      // cnt values of u and of u + 1 at element offset om
-        constexpr int CNT = decltype(cnt_c)::value;
+    // the values of u (y0) and of u + 1 (y1) at element offset om.  The hop's displacement of u + 1 is ADDED TO THE LANE OFFSET,
+    // not passed as the buffer instruction's scalar offset: a 16-byte buffer store whose scalar offset sits in an SGPR lost its
+    // FIRST data dword to the vector instruction behind it -- 16 lanes of a wave stored the integer a following v_add had just
+    // put into that register (the next row tile's pair index) instead of mask * X, in 1-3 of 30 runs, only in the run-of-tiles
+    // form (profiles/r11_ab_runs.txt, r11o).  The ISA manual's store-data hazard (a wait state between a > 64-bit store and a
+    // write of its data registers) is documented -- and handled by the compiler -- only for stores WITHOUT an SGPR offset;
+    // with the offset in the lane operand the compiler places that wait state.
+    auto emit4 = [&](int om, bool ok, float4 y0, float4 y1) {
         if (!WITH_Y || a.masks) {
             const unsigned vo = ok ? 4u * (unsigned)om : BUF_OOB;
-            if constexpr (CNT == 4) { buf_st4(make_float4(y0[0], y0[1], y0[2], y0[3]), rm, vo, 0); buf_st4(make_float4(y1[0], y1[1], y1[2], y1[3]), rm, vo, 4 * hop); }
-            else { buf_st2(make_float2(y0[0], y0[1]), rm, vo, 0); buf_st2(make_float2(y1[0], y1[1]), rm, vo, 4 * hop); }
+            buf_st4(y0, rm, vo, 0);
+            buf_st4(y1, rm, vo + 4u * (unsigned)hop, 0);
         }
         if constexpr (WITH_Y) {
-            const unsigned vx = ok ? 8u * (unsigned)om : 0xfffffff0u;         // (the mix and the estimates are 8 bytes per element: ranges up to 2^31)
-#pragma unroll
-            for (int hf = 0; hf < CNT / 2; ++hf) {
-                const float4 xa = buf_ld4(rx, vx, 16 * hf), xb = buf_ld4(rx, vx, 8 * hop + 16 * hf);
-                const float a0 = y0[2 * hf], a1 = y0[2 * hf + 1], b0 = y1[2 * hf], b1 = y1[2 * hf + 1];
-                buf_st4(make_float4(a0 * xa.x, a0 * xa.y, a1 * xa.z, a1 * xa.w), ry, vx, 16 * hf);
-                buf_st4(make_float4(b0 * xb.x, b0 * xb.y, b1 * xb.z, b1 * xb.w), ry, vx, 8 * hop + 16 * hf);
-            }
+            // (the mix and the estimates are 8 bytes per element: ranges of up to 2^31 bytes -- the launch checks it -- and BUF_OOB =
+            //  2^31 as the switched-off offset: the sums below must not wrap past 2^32 back into the range)
+            const unsigned vx = ok ? 8u * (unsigned)om : BUF_OOB, vx1 = vx + 8u * (unsigned)hop;
+            const float4 xa0 = buf_ld4(rx, vx, 0), xa1 = buf_ld4(rx, vx, 16), xb0 = buf_ld4(rx, vx1, 0), xb1 = buf_ld4(rx, vx1, 16);
+            buf_st4(make_float4(y0.x * xa0.x, y0.x * xa0.y, y0.y * xa0.z, y0.y * xa0.w), ry, vx, 0);
+            buf_st4(make_float4(y0.z * xa1.x, y0.z * xa1.y, y0.w * xa1.z, y0.w * xa1.w), ry, vx, 16);
+            buf_st4(make_float4(y1.x * xb0.x, y1.x * xb0.y, y1.y * xb0.z, y1.y * xb0.w), ry, vx1, 0);
+            buf_st4(make_float4(y1.z * xb1.x, y1.z * xb1.y, y1.w * xb1.z, y1.w * xb1.w), ry, vx1, 16);
+        }
+    };
+    auto emit2 = [&](int om, bool ok, float2 y0, float2 y1) {
+        if (!WITH_Y || a.masks) {
+            const unsigned vo = ok ? 4u * (unsigned)om : BUF_OOB;
+            buf_st2(y0, rm, vo, 0);
+            buf_st2(y1, rm, vo + 4u * (unsigned)hop, 0);
+        }
+        if constexpr (WITH_Y) {
+            const unsigned vx = ok ? 8u * (unsigned)om : BUF_OOB, vx1 = vx + 8u * (unsigned)hop;
+            const float4 xa0 = buf_ld4(rx, vx, 0), xb0 = buf_ld4(rx, vx1, 0);
+            buf_st4(make_float4(y0.x * xa0.x, y0.x * xa0.y, y0.y * xa0.z, y0.y * xa0.w), ry, vx, 0);
+            buf_st4(make_float4(y1.x * xb0.x, y1.x * xb0.y, y1.y * xb0.z, y1.y * xb0.w), ry, vx1, 0);
         }
     };
     auto epilogue = [&](const Pair& pr) {
@@ -225,40 +272,36 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
             const bool live = pr.ok && !((XSQ_L4F_ABL & 16) && y0[0] != 1.2345e-30f);
             if (quads) {
                 const int c = n >= hop ? 1 : 0;
-                emit(ob + c * F * ST + n - c * hop, live && n < W, y0, y1, std::integral_constant<int, 4>{});
+                emit4(ob + c * F * ST + n - c * hop, live && n < W, make_float4(y0[0], y0[1], y0[2], y0[3]), make_float4(y1[0], y1[1], y1[2], y1[3]));
             } else {
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int nh = n + 2 * hf;
-                    const int c = nh >= hop ? 1 : 0;
-                    emit(ob + c * F * ST + nh - c * hop, live && nh < W, y0 + 2 * hf, y1 + 2 * hf, std::integral_constant<int, 2>{});
-                }
+                const int c0 = n >= hop ? 1 : 0, c1 = n + 2 >= hop ? 1 : 0;
+                emit2(ob + c0 * F * ST + n - c0 * hop, live && n < W, make_float2(y0[0], y0[1]), make_float2(y1[0], y1[1]));
+                emit2(ob + c1 * F * ST + n + 2 - c1 * hop, live && n + 2 < W, make_float2(y0[2], y0[3]), make_float2(y1[2], y1[3]));
             }
         }
     };
 
     if (kf == 1) {
         // ONE frequency tap (67 of the 70 Bark-262 blocks): the column tile's weights go into LDS once and STAY for the run of
-        // `run` consecutive row tiles this workgroup owns; the next row tile's operands are requested before the current one
-        // computes -- no barrier and no weight traffic inside the run.  (One row tile per workgroup, the first form, spent half
+        // `run` consecutive row tiles this workgroup owns; the next row tile's operands are requested chunk by chunk into the
+        // registers the current one has just transformed -- no barrier and no weight traffic inside the run.  (One row tile per workgroup, the first form, spent half
         // its time in the prologue: without the weight loads -27 %, without the operand loads -21 %, without both -50 %,
         // profiles/r11_ab_runs.txt r11j.)
-        Ops o[2];
-        Pair pr[2];
+        Ops o;
+        Pair pr = pair_of(0);
         load_b(0);
-        pr[0] = pair_of(0);
-        load_a(o[0], pr[0], 0);
+        load_a(o, addr_of(pr, 0));
         store_b();
         __syncthreads();
-        int it = 0;
-        for (; it + 1 < run; it += 2) {
-            pr[1] = pair_of(it + 1);
-            load_a(o[1], pr[1], 0);
-            clear_acc(); contract(o[0]); epilogue(pr[0]);
-            if (it + 2 < run) { pr[0] = pair_of(it + 2); load_a(o[0], pr[0], 0); }
-            clear_acc(); contract(o[1]); epilogue(pr[1]);
+        for (int it = 0; it < run; ++it) {
+            const bool more = it + 1 < run;
+            const Pair nxp = pair_of(more ? it + 1 : it);
+            const Addr nx = addr_of(nxp, 0);
+            clear_acc();
+            contract(o, nx, more);
+            epilogue(pr);
+            pr = nxp;
         }
-        if (it < run) { clear_acc(); contract(o[0]); epilogue(pr[0]); }
         return;
     }
     // several frequency taps (column tiles of <= 32 columns; every Bark-262 block with more than one tap has W <= 24, other plans
@@ -269,15 +312,14 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
         const Pair pr = pair_of(0);
         clear_acc();
         load_b(0);
-        load_a(o, pr, 0);
+        load_a(o, addr_of(pr, 0));
         for (int df = 0; df < kf; ++df) {
             if (df > 0) __syncthreads();                         // every wave is past the tap before: its weight tiles may go
             store_b();
             __syncthreads();
-            if (df + 1 < kf) load_b(df + 1);
-            const Ops oc = o;
-            if (df + 1 < kf) load_a(o, pr, df + 1);
-            contract(oc);
+            const bool more = df + 1 < kf;
+            if (more) load_b(df + 1);
+            contract(o, addr_of(pr, more ? df + 1 : df), more);
         }
         epilogue(pr);
     }
