@@ -283,23 +283,22 @@ def issue_bound(plan, B, chunk_lengths, winograd=True, l1f=True, l4f=True):
             if l4f and "cdae_l4f<4>" in K:
                 # layer 4 as F(2, 2) along the hop (csrc/cdae_l4f.h): row tiles of 64 output pairs x one column tile of 16 NCB <= 64
                 # columns; the four width classes are budgeted from probe kernels of their own (tools/isa_budget.py).  One tap: a
-                # workgroup runs up to 6 consecutive row tiles against weights resident in LDS -- the assembly's loop with the most
-                # MFMAs holds TWO row tiles; the workgroup's prologue is what is left of the out-of-loop count after one odd row
-                # tile.  Several taps (NCB <= 2): one row tile per workgroup, the other loop is one tap (the first one is peeled).
+                # workgroup runs up to 6 consecutive row tiles against weights resident in LDS -- the assembly's loop with the
+                # epilogue in it (the most vector instructions) is ONE row tile, the out-of-loop count is the workgroup's prologue.
+                # Several taps (NCB <= 2): one row tile per workgroup; the other loop is one tap, prologue + epilogue ~ 300.
                 cols = 16 * math.ceil(T / 16)
                 rtiles = math.ceil(B * F * S / 64)
                 for n0 in range(0, cols, 64):
                     ncb = min(4, (cols - n0) // 16)
                     k = K["cdae_l4f<%d>" % ncb]
                     tap_m = 39 * ncb * 32.0
-                    run_lp = max(k["loops"], key=lambda lp: lp["mfma_cycles"])
-                    tile_v = run_lp["valu"] / 2.0
+                    run_lp = max(k["loops"], key=lambda lp: lp["valu"])
                     if kf == 1:
                         nruns = math.ceil(rtiles / 6)
-                        add("cdae_l4_gemm", 4 * rtiles * 4, tap_m, tile_v)
-                        add("cdae_l4_gemm", 4 * nruns * 4, 0.0, max(0.0, k["outside"]["valu"] - tile_v - (300.0 if ncb <= 2 else 0.0)))
+                        add("cdae_l4_gemm", 4 * rtiles * 4, tap_m, run_lp["valu"])
+                        add("cdae_l4_gemm", 4 * nruns * 4, 0.0, 250.0)
                     else:
-                        tap_lp = min(k["loops"], key=lambda lp: lp["mfma_cycles"])
+                        tap_lp = min(k["loops"], key=lambda lp: lp["valu"])
                         add("cdae_l4_gemm", 4 * rtiles * 4, tap_m * kf, 300.0 + tap_lp["valu"] * kf)
                 continue
             # layer 4: N = T columns in tiles of 64 with a last tile of 16 / 32 / 48 / 64; K = kf * 104 padded to 16
