@@ -120,9 +120,9 @@ def algorithmic_work(plan, B, chunk_lengths, wiener):
 
 
 # event name -> the kernel launched under it, as named by tools/summarize_profiles.py in profiles/*_kernel_stats.csv
-_PMC_NAMES = {"cdae_l1_gemm": ["gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2Op>"], "cdae_l3_gemm": ["gemm<CdaeL3Op>"],
+_PMC_NAMES = {"cdae_l1_gemm": ["l1f<CdaeL1>", "gemm<CdaeL1Op>"], "cdae_l2_gemm": ["gemm<CdaeL2Op>"], "cdae_l3_gemm": ["gemm<CdaeL3Op>"],
               "cdae_l2_slab": ["wino<CdaeL2>", "slab<CdaeL2>"], "cdae_l3_slab": ["wino<CdaeL3>", "slab<CdaeL3>"],
-              "cdae_l4_gemm": ["gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
+              "cdae_l4_gemm": ["l4f<CdaeL4>", "gemm<CdaeL4Op>"], "band_synthesis_gemm": ["gemm<BandInvOp>"],
               "band_analysis_gemm": ["gemm<BandFwdOp>"], "band_synthesis_dft4": ["band_dft4s<inverse>", "band_dft4<inverse>"],
               "band_analysis_dft4": ["band_dft4s<forward>", "band_dft4<forward>"], "slice_irfft": ["k_slice_irfft"], "slice_rfft": ["k_slice_rfft"],
               "slice_irfft_ola": ["k_slice_irfft"],

@@ -37,6 +37,10 @@ def short(n):
     m = re.match(r"void xsq::cdae_wino_kernel<(true|false)>", n)
     if m:
         return "wino" + ("<CdaeL3>" if m.group(1) == "true" else "<CdaeL2>")
+    if "cdae_l1f_kernel" in n:                 # layers 1 / 4 as F(2, 2) along the hop (cdae_l1f.h, cdae_l4f.h: round 6)
+        return "l1f<CdaeL1>"
+    if "cdae_l4f_kernel" in n:
+        return "l4f<CdaeL4>"
     n = re.sub(r"void xsq::grouped_gemm_bf6_kernel<xsq::(\w+)>", r"gemm_bf6<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_bf3_kernel<xsq::(\w+), \d+, \d+>", r"gemm_bf3<\1>", n)
     n = re.sub(r"void xsq::grouped_gemm_kernel<xsq::(\w+)(?:, \d+)*>", r"gemm<\1>", n)
@@ -44,7 +48,7 @@ def short(n):
     return n.split("(")[0][:48]
 
 
-ours = "gemm|slab|wino|band_dft4|k_|fft|bluestein|c2r|r2c"
+ours = "gemm|slab|wino|l1f|l4f|band_dft4|k_|fft|bluestein|c2r|r2c"
 st = pd.read_csv(glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0])
 st["Kernel"] = st["Name"].map(short)
 st = st[["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"]]

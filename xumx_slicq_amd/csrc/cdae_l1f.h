@@ -36,6 +36,9 @@
 #ifndef XSQ_L1F_WAVES_PER_EU
 #define XSQ_L1F_WAVES_PER_EU 3
 #endif
+#ifndef XSQ_L1F_SCHED
+#define XSQ_L1F_SCHED -1    // >= 0: a scheduling barrier with this mask behind every component's MFMAs (A/B: profiles/r11_ab_runs.txt)
+#endif
 #ifndef XSQ_L1F_ABL
 #define XSQ_L1F_ABL 0       // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no operand loads, 16 no epilogue stores, 32 no MFMAs
 #endif
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
                     : "+v"(accv[j][cc])
                     : "v"(f.u[cc]), "v"(d[j][0]), "v"(d[j][1]), "v"(d[j][2]), "v"(d[j][3]));
             }
+            if (XSQ_L1F_SCHED >= 0) __builtin_amdgcn_sched_barrier(XSQ_L1F_SCHED);
         }
         if (next) store_chunk(cur ^ 1);          // the other buffer: last read in the chunk before, every wave is past that chunk's barrier
         cnt += 1;

@@ -44,6 +44,9 @@
 #ifndef XSQ_WINO_RAW_AHEAD
 #define XSQ_WINO_RAW_AHEAD 1   // 1: the pair's raw positions of chunk s + 1 are read while chunk s computes (20 more registers)
 #endif
+#ifndef XSQ_WINO_SCHED
+#define XSQ_WINO_SCHED -1   // >= 0: a scheduling barrier with this mask behind every component's MFMAs (A/B: profiles/r11_ab_runs.txt)
+#endif
 #ifndef XSQ_WINO_ABL
 #define XSQ_WINO_ABL 0      // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no slab loads, 16 no epilogue stores, 32 no input transform
 #endif
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                             : "v"(f.u[cc]), "v"(v[j][0]), "v"(v[j][1]), "v"(v[j][2]), "v"(v[j][3]));
                         if (s == 2) asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[j][cc]) : "v"(vt[j]), "v"(f.ut[cc]));
                     }
+                    if (XSQ_WINO_SCHED >= 0) __builtin_amdgcn_sched_barrier(XSQ_WINO_SCHED);
                 }
                 // other buffer: last read in the chunk before, every wave is past that chunk's barrier
                 if (s < 2) store_chunk(s + 1, cur ^ 1);
