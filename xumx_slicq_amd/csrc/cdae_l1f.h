@@ -37,7 +37,8 @@
 #define XSQ_L1F_WAVES_PER_EU 3
 #endif
 #ifndef XSQ_L1F_SCHED
-#define XSQ_L1F_SCHED -1    // >= 0: a scheduling barrier with this mask behind every component's MFMAs (A/B: profiles/r11_ab_runs.txt)
+#define XSQ_L1F_SCHED 0     // >= 0: a scheduling barrier with this mask behind every component's MFMAs (0.407-0.409 against 0.414-0.423
+                            // without: profiles/r11_ab_runs.txt r11r); -1: none
 #endif
 #ifndef XSQ_L1F_ABL
 #define XSQ_L1F_ABL 0       // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no operand loads, 16 no epilogue stores, 32 no MFMAs
