@@ -1048,7 +1048,21 @@ def variant_cli(args, sep, dev, ntracks=8):
             xaudio.save_wav_float_interleaved(os.path.join(wdir, "t%d.wav" % k), hout[k], 44100)
         write_ms = (time.perf_counter() - t0) * 1e3
         readers, writers = 3, 4
-        bound = max(decode_ms / readers, h2d_ms, d2h_ms, gpu_ms + inter_ms, write_ms / writers)
+        # the same write as the pipeline issues it: `writers` threads, one track (four wavs) each, at the same time -- a tmpfs does
+        # not scale with the threads (page allocation), so the stage's rate is measured, not write_ms / writers
+        import threading
+
+        def write_track(i):
+            for k in range(4):
+                xaudio.save_wav_float_interleaved(os.path.join(wdir, "p%d_%d.wav" % (i, k)), hout[k], 44100)
+        ths = [threading.Thread(target=write_track, args=(i,)) for i in range(writers)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        write_par_ms = (time.perf_counter() - t0) * 1e3 / writers
+        bound = max(decode_ms / readers, h2d_ms, d2h_ms, gpu_ms + inter_ms, write_par_ms)
         return {"what": "python -m xumx_slicq_amd over %d synthetic 240 s 16-bit stereo wavs in %s -> 4 float32 stem wavs per track; "
                         "pipelined loop (3 reader threads decoding straight into pinned buffers, 4 writer threads, channel interleave on the GPU)" % (ntracks, base),
                 "cli_tracks_per_s": round(rates[-1], 2), "cli_tracks_per_s_first_pass": round(rates[0], 2),
@@ -1056,9 +1070,10 @@ def variant_cli(args, sep, dev, ntracks=8):
                 "separator_ms_per_track": round(gpu_ms, 3),
                 "stages_alone_ms_per_track": {"read + decode_pcm16_to_pinned_float (1 thread)": round(decode_ms, 1), "h2d_85MB_pinned": round(h2d_ms, 2),
                                               "d2h_339MB_pinned": round(d2h_ms, 2), "gpu_interleave": round(inter_ms, 3),
-                                              "write_4_wavs (1 thread)": round(write_ms, 1)},
+                                              "write_4_wavs (1 thread)": round(write_ms, 1),
+                                              "write_4_wavs per track with %d threads writing at once" % writers: round(write_par_ms, 1)},
                 "pipeline_bound_ms_per_track": round(bound, 2),
-                "bound_note": "max over the stages of (time alone / threads of that stage): decode / 3, H2D, D2H, demix + interleave, write / 4",
+                "bound_note": "max over the stages: decode / 3 reader threads, H2D, D2H, demix + interleave, the write stage at its measured rate with 4 threads writing at once",
                 "ratio_to_bound": round(1e3 / rates[-1] / bound, 2)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
