@@ -47,7 +47,7 @@ class _PinnedPool:
                 buf = None
             if buf is None:
                 self._count += 1
-                return torch.empty(numel, dtype=torch.float32).pin_memory()
+                return torch.empty(numel, dtype=torch.float32, pin_memory=True)      # (allocated pinned: no pageable twin, no copy)
             if buf.numel() >= numel:
                 return buf
             self._count -= 1          # too small for this track: drop it, allocate a larger one
@@ -55,6 +55,9 @@ class _PinnedPool:
 
     def give(self, buf):
         self._free.put(buf)
+
+
+_POOLS: dict = {}        # process-wide pinned staging pools of demix_directory
 
 
 def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 3, writers: int = 4, depth: int = 3, quiet=False):
@@ -69,7 +72,8 @@ def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 3, w
 
     dev = torch.device(device)
     out_dir = Path(out_dir)
-    pool_in, pool_out = _PinnedPool(), _PinnedPool()
+    # the staging buffers outlive the call (page-locking a 339 MB block costs more than demixing the track it carries)
+    pool_in, pool_out = _POOLS.setdefault("in", _PinnedPool()), _POOLS.setdefault("out", _PinnedPool())
     copy_in, copy_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     results, errors = {}, []
@@ -86,23 +90,30 @@ def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 3, w
             raise ValueError(f"{path}: {rate} Hz, the model runs at {float(separator.sample_rate)} Hz: resample first")
         return path, view, keep[0], rate
 
+    lock = threading.Lock()
+
     def writer():
+        # one job = ONE stem of one track: the four stems of a track go out on four threads at once (a track's last write is what
+        # the end of a run waits for); the track's pinned buffer returns to the pool with its last stem
         while True:
             job = wq.get()
             if job is None:
                 return
+            path, host, buf, done, t0, t1, rate, n, k, left = job
             try:
-                path, host, buf, done, t0, t1, rate, n = job
                 done.synchronize()
                 target_dir = out_dir / path.stem
                 target_dir.mkdir(parents=True, exist_ok=True)
-                for k, target in enumerate(separator.sources):
-                    xaudio.save_wav_float_interleaved(str(target_dir / f"{target}.wav"), host[k], rate)
-                results[str(path)] = (path.name, n / rate, t0.elapsed_time(t1))
+                xaudio.save_wav_float_interleaved(str(target_dir / f"{separator.sources[k]}.wav"), host[k], rate)
             except Exception as e:                                   # noqa: BLE001 -- reported after the loop
-                errors.append((str(job[0]), e))
+                errors.append((str(path), e))
             finally:
-                pool_out.give(job[2])
+                with lock:
+                    left[0] -= 1
+                    last = left[0] == 0
+                if last:
+                    results[str(path)] = (path.name, n / rate, t0.elapsed_time(t1))
+                    pool_out.give(buf)
 
     threads = [threading.Thread(target=writer, daemon=True) for _ in range(writers)]
     for t in threads:
@@ -136,7 +147,9 @@ def demix_directory(separator, wavs, out_dir, device="cuda", readers: int = 3, w
                 done.record(copy_out)
             up.synchronize()                                         # the input buffer may be refilled once its upload is over
             pool_in.give(buf_in)
-            wq.put((path, host, buf_out, done, t0, t1, rate, n))
+            left = [len(separator.sources)]
+            for k in range(len(separator.sources)):
+                wq.put((path, host, buf_out, done, t0, t1, rate, n, k, left))
     for _ in threads:
         wq.put(None)
     for t in threads:
