@@ -173,7 +173,7 @@ __device__ __forceinline__ void relu_shift_epilogue_xw(const CdaeGroup& g, int r
     const __amdgpu_buffer_rsrc_t ro = buf_rsrc(g.out + (int64_t)__builtin_amdgcn_readfirstlane(rowb) * CS, 16u * (unsigned)__builtin_amdgcn_readfirstlane(nvalid));
 #pragma unroll
     for (int i = 0; i < (XW_TILE / 4 + 63) / 64; ++i)
-        buf_st4(*reinterpret_cast<const float4*>(img + 4 * (lane + 64 * i)), ro, 16u * (unsigned)lane, 1024 * i);      // (the range check covers lane + scalar offset: tools/probe/buf_range.hip)
+        buf_st4(*reinterpret_cast<const float4*>(img + 4 * (lane + 64 * i)), ro, 16u * (unsigned)lane + 1024u * i, 0);      // (displacement in the lane offset: common.h, buf_st4)
 }
 
 // ---- layer 1 -----------------------------------------------------------------------------

@@ -44,8 +44,14 @@
 #ifndef XSQ_WINO_RAW_AHEAD
 #define XSQ_WINO_RAW_AHEAD 1   // 1: the pair's raw positions of chunk s + 1 are read while chunk s computes (20 more registers)
 #endif
+#ifndef XSQ_WINO_SWAP
+#define XSQ_WINO_SWAP 1     // 1: the WEIGHTS are the MFMA's row operand -- a lane's accumulator registers are four consecutive output channels
+                            // of its own pair: 16-byte stores straight from registers; 0: pairs as rows, outputs through a per-wave LDS image
+#endif
 #ifndef XSQ_WINO_SCHED
-#define XSQ_WINO_SCHED -1   // >= 0: a scheduling barrier with this mask behind every component's MFMAs (A/B: profiles/r11_ab_runs.txt)
+#define XSQ_WINO_SCHED 0    // >= 0: a scheduling barrier with this mask behind every component's MFMAs; -1: none.  With the weights as the row
+                            // operand (XSQ_WINO_SWAP) mask 0 measured 0.841-0.843 / 0.859-0.863 ms against 0.889-0.908 / 0.878-0.891 for the
+                            // round-5 form; either change alone: nothing (profiles/r11_ab_runs.txt r11r, r11t)
 #endif
 #ifndef XSQ_WINO_ABL
 #define XSQ_WINO_ABL 0      // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no slab loads, 16 no epilogue stores, 32 no input transform
@@ -285,14 +291,26 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                     const float wc[4] = {f.w[2].x, f.w[2].y, f.w[2].z, f.w[2].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        if (XSQ_WINO_SWAP) {
+                            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], v[j][i], acc[j][0], 0, 0, 0);
+                            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i], v[j][i], acc[j][1], 0, 0, 0);
+                            acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[i], v[j][i], acc[j][2], 0, 0, 0);
+                            continue;
+                        }
                         acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][i], wa[i], acc[j][0], 0, 0, 0);
                         acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][i], wb[i], acc[j][1], 0, 0, 0);
                         acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][i], wc[i], acc[j][2], 0, 0, 0);
                     }
                     if (s == 2) {
+                        if (XSQ_WINO_SWAP) {
+                            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.wt[0], vt[j], acc[j][0], 0, 0, 0);
+                            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.wt[1], vt[j], acc[j][1], 0, 0, 0);
+                            acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.wt[2], vt[j], acc[j][2], 0, 0, 0);
+                        } else {
                         acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[j], f.wt[0], acc[j][0], 0, 0, 0);
                         acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[j], f.wt[1], acc[j][1], 0, 0, 0);
                         acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[j], f.wt[2], acc[j][2], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int cc = 0; cc < NV; ++cc) {
@@ -321,8 +339,55 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
 
         // ---- epilogue: output transform, shift + ReLU, through a per-wave LDS image (the planes are free: the
         // loop ended on a barrier), out as 16-byte stores.  Image row 2 p + r = output r of the wave's pair p.
-        float* img = slab + wave * 32 * CS;
         const float* shift = a.pool + t.shift_off;
+        if (XSQ_WINO_SWAP) {
+            // weights as the row operand: accumulator register r of this lane is output channel 16 cb + 4 kq + r of the lane's OWN
+            // pair -- output transform, shift + ReLU, one 16-byte store per column block and output, no LDS image, no index exchange
+            float* out = (TRANSPOSED ? a.act3 : a.act2) + t.out_off;
+            const __amdgpu_buffer_rsrc_t ro = buf_rsrc(out, 0x40000000u);
+            const int sg = pl >= n0 ? 1 : 0;
+            const int qq = sg ? pl - n0 : q0 + pl;
+            const bool ok0 = pl < npairs, ok1 = ok0 && 2 * qq + 1 < To;
+            const unsigned vo = 4u * (unsigned)((((b * Fo + f0 + sg) * To) + 2 * qq) * CS + 4 * kq);
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const float4 sh = *reinterpret_cast<const float4*>(shift + 16 * cb + 4 * kq);
+                const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                float y0[4], y1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[0][cb][r], m1 = acc[1][cb][r], m2 = acc[2][cb][r], m3 = acc[3][cb][r], m4 = acc[4][cb][r];
+                    y0[r] = fmaxf(((m0 + m1) + (m2 + m3)) + shv[r], 0.f);
+                    y1[r] = fmaxf((fmaf(2.f, m3, m1 - m2) + m4) + shv[r], 0.f);
+                }
+                const bool live = !((XSQ_WINO_ABL & 16) && y0[0] != 1.2345e-30f);
+                // (displacements in the LANE offset, scalar offset 0: the store-data hazard of 16-byte stores with an SGPR offset, common.h)
+                buf_st4(make_float4(y0[0], y0[1], y0[2], y0[3]), ro, (ok0 && live) ? vo + 64u * cb : BUF_OOB, 0);
+                buf_st4(make_float4(y1[0], y1[1], y1[2], y1[3]), ro, (ok1 && live) ? vo + 64u * cb + 4u * CS : BUF_OOB, 0);
+            }
+            float y0v[4] = {0.f, 0.f, 0.f, 0.f}, y1v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < NV; ++cc) {
+                float m[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {            // the four k-quads' partial sums meet here (fixed order)
+                    float x = accv[j][cc];
+                    x += __shfl_xor(x, 16);
+                    x += __shfl_xor(x, 32);
+                    m[j] = x;
+                }
+                y0v[cc] = ((m[0] + m[1]) + (m[2] + m[3]));
+                y1v[cc] = fmaf(2.f, m[3], m[1] - m[2]) + m[4];
+            }
+            const float4 sh = *reinterpret_cast<const float4*>(shift + 48);
+            const unsigned vt48 = vo - 16u * (unsigned)kq;                   // (channel 0 of the row)
+            buf_st4(make_float4(fmaxf(y0v[0] + sh.x, 0.f), fmaxf(y0v[1] + sh.y, 0.f), fmaxf(y0v[2] + sh.z, 0.f), fmaxf(y0v[3] + sh.w, 0.f)), ro,
+                    (ok0 && kq == 0) ? vt48 + 192u : BUF_OOB, 0);
+            buf_st4(make_float4(fmaxf(y1v[0] + sh.x, 0.f), fmaxf(y1v[1] + sh.y, 0.f), fmaxf(y1v[2] + sh.z, 0.f), fmaxf(y1v[3] + sh.w, 0.f)), ro,
+                    (ok1 && kq == 0) ? vt48 + 192u + 4u * CS : BUF_OOB, 0);
+            return;
+        }
+        float* img = slab + wave * 32 * CS;
         {
             const int rq = lane >> 4;
 #pragma unroll

@@ -73,9 +73,10 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo,
 __device__ __forceinline__ void buf_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u32x2, v), r, (int)vo, so, 0);
 }
-// NOTE (round 6, cdae_l4f.h): pass `so` = 0 or a compile-time constant to buf_st4.  With a RUN-TIME scalar offset (an SGPR) a
-// 16-byte store lost its first data dword to the next vector instruction that wrote that register -- the store-data hazard
-// the compiler guards only for stores without an SGPR offset.  Put run-time displacements into the lane offset `vo`.
+// NOTE (round 6, cdae_l4f.h / cdae_wino.h): pass `so` = 0 to buf_st4.  With the scalar offset in an SGPR -- a run-time value, or
+// a compile-time constant that is not an inline constant (128, 192, 1024 ...: the compiler moves it into an SGPR) -- a 16-byte
+// store lost its first data dword to the next vector instruction that wrote that register: the store-data hazard the compiler
+// guards only for stores WITHOUT an SGPR offset.  Put every displacement into the lane offset `vo`.
 __device__ __forceinline__ void buf_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned vo, int so) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_u32x4, v), r, (int)vo, so, 0);
 }
