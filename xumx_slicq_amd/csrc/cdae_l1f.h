@@ -27,8 +27,9 @@
 //    stride 24 words (cdae_wino.h explains the bank pattern); columns 48 / 49 on the vector ALU through one LDS word and
 //    v_fmac_f32_dpp row_newbcast.
 //  * per chunk and wave: 36 v_mfma_f32_16x16x4_f32 (1,152 cycles) where the implicit GEMM issues 1,536 for the same outputs.
-//  * epilogue: output sums, shift + ReLU, through a per-wave LDS image (the weight buffers are free), 16-byte stores.
-//   LDS 28.8 KB + 256 B.
+//  * the weights are the MFMA's ROW operand: a lane's accumulator registers are four consecutive output channels of its own pair --
+//    epilogue: output sums, shift + ReLU, 16-byte stores straight from registers.
+//   LDS 28.8 KB.
 #pragma once
 #include "cdae_api.h"
 #include "gemm_tile.h"
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
 #pragma clang fp contract(off)
     constexpr int NV = H1 - 48;                                  // real channels past 47
     __shared__ __attribute__((aligned(16))) float Bs[2 * 3 * LF_BTILE];
-    __shared__ unsigned obase[LF_PAIRS];                         // byte offset of a pair's first output row | 1 when its second output exists
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, kq = lane >> 4;
@@ -87,7 +87,6 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
     const int b = Qg / (F1 * P), Q = Qg - b * (F1 * P);
     const int f1 = Q / P, p = Q - f1 * P;
     const unsigned vo_row = pair_ok ? 4u * (unsigned)((b * 2 * F + f1) * Ti + 2 * p * hop) : BUF_OOB;
-    if (kq == 0) obase[pl] = pair_ok ? (4u * (unsigned)(((b * F1 + f1) * T1 + 2 * p) * CS) | (2 * p + 1 < T1 ? 1u : 0u)) : 0xffffffffu;
 
     // ---- K cursor of this lane: quad e4 = kq + 4 s of the padded K order -> (segment, quad inside the segment).  seg_off =
     // floats from the row base to the segment's row: segment (c, df) is input row (c F + f1 + df)
@@ -178,9 +177,11 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (XSQ_L1F_ABL & 32) { acc[j][0][i] += d[j][i] * wa[i]; acc[j][1][i] += d[j][i] * wb[i]; acc[j][2][i] += d[j][i] * wc[i]; continue; }
-                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wa[i], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wb[i], acc[j][1], 0, 0, 0);
-                acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[j][i], wc[i], acc[j][2], 0, 0, 0);
+                // (the WEIGHTS are the MFMA's row operand: accumulator register r of a lane is output channel 16 cb + 4 kq + r of the
+                //  lane's OWN pair -- 16-byte stores straight from registers, cdae_wino.h / cdae_l4f.h)
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], d[j][i], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i], d[j][i], acc[j][1], 0, 0, 0);
+                acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[i], d[j][i], acc[j][2], 0, 0, 0);
             }
 #pragma unroll
             for (int cc = 0; cc < NV; ++cc) {
@@ -212,59 +213,48 @@ __global__ __launch_bounds__(256, XSQ_L1F_WAVES_PER_EU) void cdae_l1f_kernel(Cda
         if (nchunks & 1) chunk(I0{}, s);
     }
 
-    // ---- epilogue: y[u] = m1 + m2, y[u + 1] = m2 + m3, shift + ReLU, through a per-wave LDS image (the loop ended on a
-    // barrier: the weight buffers are free), out as 16-byte stores.  Image row 2 p' + r = output r of the wave's pair p'.
-    float* img = Bs + wave * 32 * CS;
+    // ---- epilogue: y[u] = m1 + m2, y[u + 1] = m2 + m3, shift + ReLU, one 16-byte store per column block and output from the
+    // lane's own registers (displacements in the lane offset: common.h, buf_st4).  A pair that does not exist and the phantom
+    // second output of a row's last pair (T1 is odd: it would land on the NEXT row's first output) are switched out of range.
     const float* shift = a.pool + t.shift_off;
-    {
-        const int rq = lane >> 4;
-#pragma unroll
-        for (int cb = 0; cb < 3; ++cb) {
-            const int col = 16 * cb + q;
-            const float sh = shift[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m1 = acc[0][cb][r], m2 = acc[1][cb][r], m3 = acc[2][cb][r];
-                img[(2 * (4 * rq + r)) * CS + col] = fmaxf((m1 + m2) + sh, 0.f);
-                img[(2 * (4 * rq + r) + 1) * CS + col] = fmaxf((m2 + m3) + sh, 0.f);
-            }
-        }
-        float y0v[4] = {0.f, 0.f, 0.f, 0.f}, y1v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int cc = 0; cc < NV; ++cc) {
-            float m[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {                // the four k-quads' partial sums meet here (fixed order)
-                float x = accv[j][cc];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                m[j] = x;
-            }
-            y0v[cc] = m[0] + m[1];
-            y1v[cc] = m[1] + m[2];
-        }
-        if (kq == 0) {
-            const float4 sh = *reinterpret_cast<const float4*>(shift + 48);
-            *reinterpret_cast<float4*>(img + (2 * q) * CS + 48) =
-                make_float4(fmaxf(y0v[0] + sh.x, 0.f), fmaxf(y0v[1] + sh.y, 0.f), fmaxf(y0v[2] + sh.z, 0.f), fmaxf(y0v[3] + sh.w, 0.f));
-            *reinterpret_cast<float4*>(img + (2 * q + 1) * CS + 48) =
-                make_float4(fmaxf(y1v[0] + sh.x, 0.f), fmaxf(y1v[1] + sh.y, 0.f), fmaxf(y1v[2] + sh.z, 0.f), fmaxf(y1v[3] + sh.w, 0.f));
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // image row -> output row: pair 16 wave + (row >> 1) of the tile; a pair that does not exist and the phantom second output
-    // of a row's last pair (T1 is odd: it would land on the NEXT row's first output) are switched out of the descriptor's range
     const __amdgpu_buffer_rsrc_t ro = buf_rsrc(a.act1 + t.out_off, 0x40000000u);
+    const bool ok0 = pair_ok, ok1 = pair_ok && 2 * p + 1 < T1;
+    const unsigned vo = 4u * (unsigned)(((b * F1 + f1) * T1 + 2 * p) * CS + 4 * kq);
 #pragma unroll
-    for (int it = 0; it < (32 * (CS / 4) + 63) / 64; ++it) {
-        const int slot = lane + 64 * it;
-        const int row = slot / (CS / 4), c4 = slot - row * (CS / 4);
-        const unsigned ob = obase[wave * 16 + min(row >> 1, 15)];
-        const bool ok = slot < 32 * (CS / 4) && ob != 0xffffffffu && (!(row & 1) || (ob & 1u));
-        const unsigned vo = (ob & ~1u) + 4u * (unsigned)((row & 1) * CS + 4 * c4);
-        const float4 val = *reinterpret_cast<const float4*>(img + 4 * min(slot, 32 * (CS / 4) - 1));
-        buf_st4(val, ro, (ok && !((XSQ_L1F_ABL & 16) && val.x != 1.2345e-30f)) ? vo : BUF_OOB, 0);
+    for (int cb = 0; cb < 3; ++cb) {
+        const float4 sh = *reinterpret_cast<const float4*>(shift + 16 * cb + 4 * kq);
+        const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float y0[4], y1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m1 = acc[0][cb][r], m2 = acc[1][cb][r], m3 = acc[2][cb][r];
+            y0[r] = fmaxf((m1 + m2) + shv[r], 0.f);
+            y1[r] = fmaxf((m2 + m3) + shv[r], 0.f);
+        }
+        const bool live = !((XSQ_L1F_ABL & 16) && y0[0] != 1.2345e-30f);
+        buf_st4(make_float4(y0[0], y0[1], y0[2], y0[3]), ro, (ok0 && live) ? vo + 64u * cb : BUF_OOB, 0);
+        buf_st4(make_float4(y1[0], y1[1], y1[2], y1[3]), ro, (ok1 && live) ? vo + 64u * cb + 4u * CS : BUF_OOB, 0);
     }
+    float y0v[4] = {0.f, 0.f, 0.f, 0.f}, y1v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < NV; ++cc) {
+        float m[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                // the four k-quads' partial sums meet here (fixed order)
+            float x = accv[j][cc];
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            m[j] = x;
+        }
+        y0v[cc] = m[0] + m[1];
+        y1v[cc] = m[1] + m[2];
+    }
+    const float4 sh = *reinterpret_cast<const float4*>(shift + 48);
+    const unsigned v48 = vo - 16u * (unsigned)kq + 192u;             // channel 48 of the row
+    buf_st4(make_float4(fmaxf(y0v[0] + sh.x, 0.f), fmaxf(y0v[1] + sh.y, 0.f), fmaxf(y0v[2] + sh.z, 0.f), fmaxf(y0v[3] + sh.w, 0.f)), ro,
+            (ok0 && kq == 0) ? v48 : BUF_OOB, 0);
+    buf_st4(make_float4(fmaxf(y1v[0] + sh.x, 0.f), fmaxf(y1v[1] + sh.y, 0.f), fmaxf(y1v[2] + sh.z, 0.f), fmaxf(y1v[3] + sh.w, 0.f)), ro,
+            (ok1 && kq == 0) ? v48 + 4u * CS : BUF_OOB, 0);
 }
 
 }  // namespace xsq

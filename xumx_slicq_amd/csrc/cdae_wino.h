@@ -42,7 +42,8 @@
 #define XSQ_WINO_WAVES_PER_EU 2
 #endif
 #ifndef XSQ_WINO_RAW_AHEAD
-#define XSQ_WINO_RAW_AHEAD 1   // 1: the pair's raw positions of chunk s + 1 are read while chunk s computes (20 more registers)
+#define XSQ_WINO_RAW_AHEAD 0   // 1: the pair's raw positions of chunk s + 1 are read while chunk s computes (20 more registers; round 5's default.
+                               // With the scheduling barriers of round 6: 0.855 / 0.872 against 0.836 / 0.861 without it, r11v)
 #endif
 #ifndef XSQ_WINO_SWAP
 #define XSQ_WINO_SWAP 1     // 1: the WEIGHTS are the MFMA's row operand -- a lane's accumulator registers are four consecutive output channels
