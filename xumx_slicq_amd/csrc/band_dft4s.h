@@ -25,6 +25,10 @@
 #pragma once
 #include "band_dft4.h"
 
+#ifndef XSQ_S4_SCHED
+#define XSQ_S4_SCHED -1     // >= 0: a scheduling barrier with this mask behind every column block's MFMAs of a K-step (A/B: r11w)
+#endif
+
 namespace xsq {
 
 constexpr int S4_KP = 8, S4_NCB = 3, S4_AROWS = 16 * D4H_ROWS, S4_BROWS = 16 * S4_NCB;
@@ -219,6 +223,7 @@ void band_dft4s_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntil
                 acc[2][e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2][e].y, s.y, acc[2][e][cb], 0, 0, 0);
                 acc[3][e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3][e].y, s.y, acc[3][e][cb], 0, 0, 0);
             }
+            if (XSQ_S4_SCHED >= 0) __builtin_amdgcn_sched_barrier(XSQ_S4_SCHED);
         }
     };
     int k0 = 0;
