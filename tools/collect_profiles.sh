@@ -1,5 +1,5 @@
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}      # (resolved before the cd: the scripts run from /tmp)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_${ROUND:-r02}
 mkdir -p $O
 # kernel trace with the step counts the driver's bench run uses (--steps 20 --warmup 5): a 3 + 1 step run times its launches from

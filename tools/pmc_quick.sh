@@ -1,8 +1,8 @@
 # One SQ counter pass over the headline bench (2 steps) and a per-kernel table: matrix-pipe busy, vector-ALU issue utilisation,
 # share of wave cycles in s_waitcnt, LDS bank-conflict cycles per LDS-active... for the kernels matching FILTER (regex).
 # usage (GPU box): tools/pmc_quick.sh OUTDIR [FILTER]     (XSQ_LIB / XSQ_CDAE_VARIANT etc. pass through)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}      # (resolved before the cd: the scripts run from /tmp)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/$1; F=${2:-wino|slab}
 mkdir -p $O
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmcq -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants > /dev/null 2> $O/pmc.err

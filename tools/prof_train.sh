@@ -1,6 +1,6 @@
 # rocprofv3 kernel statistics of the training step (tools/bench_train.py).  usage (GPU box): tools/prof_train.sh OUTFILE [bench_train args]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}      # (resolved before the cd: the scripts run from /tmp)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/$1; shift
 rm -rf /tmp/prof_tr
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -- python3 $R/tools/bench_train.py --steps 20 --warmup 5 --no-profile "$@" > /tmp/tr.log 2> /tmp/tr.err

@@ -25,6 +25,10 @@
 #pragma once
 #include "band_dft4.h"
 
+#ifndef XSQ_S4_EARLY
+#define XSQ_S4_EARLY 0      // 1: the operands of K-step i + 2 are requested right behind the staging of K-step i + 1 (in front of the barrier:
+                            // they travel during the barrier wait AND the next K-step's MFMAs; same single register set) -- A/B r11y
+#endif
 #ifndef XSQ_S4_SCHED
 #define XSQ_S4_SCHED -1     // >= 0: a scheduling barrier with this mask behind every column block's MFMAs of a K-step (A/B: r11w)
 #endif
@@ -227,12 +231,23 @@ void band_dft4s_kernel(Band4Args a, const Tile4Dev* __restrict__ tiles, int ntil
         }
     };
     int k0 = 0;
-    for (; k0 + S4_KP < K2; k0 += S4_KP) {
-        load_set(k0 + S4_KP);
-        k_step();
-        store_set(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    if (XSQ_S4_EARLY) {
+        if (S4_KP < K2) load_set(S4_KP);
+        for (; k0 + S4_KP < K2; k0 += S4_KP) {
+            k_step();
+            store_set(cur ^ 1);
+            if (k0 + 2 * S4_KP < K2) load_set(k0 + 2 * S4_KP);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (; k0 + S4_KP < K2; k0 += S4_KP) {
+            load_set(k0 + S4_KP);
+            k_step();
+            store_set(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     k_step();
 
