@@ -327,7 +327,10 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
 
 template <bool WITH_Y>
 __global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void cdae_l4f_kernel(CdaeArgs a, const L4fTileDev* __restrict__ tiles, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float Bs[L4_BROWS * L4_BLD];
+#ifndef XSQ_L4F_LDS_ROWS
+#define XSQ_L4F_LDS_ROWS L4_BROWS
+#endif
+    __shared__ __attribute__((aligned(16))) float Bs[XSQ_L4F_LDS_ROWS * L4_BLD];
     const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.run), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
                  "s"(t.hop), "s"(t.n0), "s"(t.P), "s"(t.x_off));
