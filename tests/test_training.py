@@ -469,3 +469,27 @@ def test_hip_training_step_bf16_arm_at_config_size(oracle_step16):
         ref16 = torch.from_numpy(g[key]).double()
         d = float((grads[k].cpu().double() - ref16).norm())
         assert d <= (2.5 * rel_ref[k] + 0.02) * norm32[k] + 1e-7, (k, d, rel_ref[k], norm32[k])
+
+
+@pytest.mark.gpu
+def test_packed_bf16_weight_gradient_kernel_is_bitwise_the_lane_converting_one():
+    """Round 6: the bf16 arm's weight gradients on `wgrad_bf16p_kernel` (csrc/wgrad.h: operands rounded to bf16 ONCE at staging
+    time and held k-pair-packed in LDS, one 16-byte fragment read per MFMA operand; XSQ_TRAIN_WGRAD_PACKED=1, an A/B arm that
+    measured slower and stays off by default) against round 5's `wgrad_kernel<Op, true>` (fp32 K-steps in LDS, eight 4-byte reads
+    + four conversions per fragment).  The same values are
+    rounded by the same instruction and meet in the same MFMA in the same order: every gradient tensor must come out BITWISE
+    equal -- on fixture A's batch (B = 2) and on the config's B = 16 batch (ragged last chunks, all four weight-gradient launches)."""
+    import os
+    g = load_golden("training_step_bf16.npz")
+    for (x, y_t) in (_inputs(int(g["n"])), _inputs16()):
+        res = {}
+        for packed in ("1", "0"):
+            os.environ["XSQ_TRAIN_WGRAD_PACKED"] = packed
+            try:
+                _sep, tr = _trainer(False, precision="bf16")
+                res[packed] = (tr.step(x, y_t, apply_update=False), {k: v.clone() for k, v in tr.gradients().items()})
+            finally:
+                os.environ.pop("XSQ_TRAIN_WGRAD_PACKED", None)
+        assert res["1"][0] == res["0"][0]
+        bad = [k for k in res["1"][1] if not torch.equal(res["1"][1][k], res["0"][1][k])]
+        assert not bad, (len(bad), bad[:5])

@@ -391,6 +391,22 @@ struct WgL23Op {
     __device__ float4 load_b4(const Group&, const Row& r, const Cols& c) const {
         return c.n < 4 * CS ? *reinterpret_cast<const float4*>(r.p + c.n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // consecutive rows k, k + 1, ... without a (b, f2, t2) split per row (wgrad_bf16p_kernel)
+    struct RowIt { const float* p; int f2, t2; };
+    __device__ RowIt row_it(const Group& g, int k, int df) const {
+        const int per = g.F2 * d.T2;
+        const int b = k / per, r = k - b * per;
+        const int f2 = r / d.T2, t2 = r - f2 * d.T2;
+        return RowIt{g.B + ((int64_t)(b * g.F1 + f2 + df) * d.T1 + t2) * CS, f2, t2};
+    }
+    __device__ Row row_of(const RowIt& it) const { return Row{it.p}; }
+    __device__ void advance(const Group& g, RowIt& it) const {
+        it.p += CS;
+        if (++it.t2 == d.T2) {
+            it.t2 = 0; it.p += (int64_t)(d.T1 - d.T2) * CS;
+            if (++it.f2 == g.F2) { it.f2 = 0; it.p += (int64_t)(g.F1 - g.F2) * d.T1 * CS; }
+        }
+    }
 };
 
 // layers 1 / 4:  gw1[co][ci,df,dt] = sum_k gz1[k][co] * xin[b, ci, f1+df, t1*hop + dt - pad]
@@ -443,6 +459,23 @@ struct WgL14Op {
         if (t + 2 >= 0 && t + 2 < g.ST) v.z = p[2];
         if (t + 3 >= 0 && t + 3 < g.ST) v.w = p[3];
         return v;
+    }
+    // consecutive rows k, k + 1, ... without a (b, f1, t1) split per row (wgrad_bf16p_kernel)
+    struct RowIt { const float* p; int64_t tau0; int f1, t1; };
+    __device__ RowIt row_it(const Group& g, int k, int) const {
+        const int per = g.F1 * d.T1;
+        const int b = k / per, r = k - b * per;
+        const int f1 = r / d.T1, t1 = r - f1 * d.T1;
+        const int64_t tau0 = (int64_t)t1 * g.hop - g.pad;
+        return RowIt{g.R + ((int64_t)b * 2 * g.F + f1) * g.ST + tau0, tau0, f1, t1};
+    }
+    __device__ Row row_of(const RowIt& it) const { return Row{it.p, it.tau0}; }
+    __device__ void advance(const Group& g, RowIt& it) const {
+        it.p += g.hop; it.tau0 += g.hop;
+        if (++it.t1 == d.T1) {
+            it.t1 = 0; it.p += g.ST - (int64_t)d.T1 * g.hop; it.tau0 = -g.pad;
+            if (++it.f1 == g.F1) { it.f1 = 0; it.p += (int64_t)(2 * g.F - g.F1) * g.ST; }
+        }
     }
 };
 
@@ -1010,9 +1043,16 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     // bf16 arm: the weight gradients on bf16 operands as well (XSQ_TRAIN_WGRAD_FP32=1: keep them on the fp32 pipe, an A/B arm)
     static const bool wgrad_fp32 = getenv("XSQ_TRAIN_WGRAD_FP32") && atoi(getenv("XSQ_TRAIN_WGRAD_FP32")) != 0;
     const bool bf16w = Mo->precision == 3 && !wgrad_fp32;
+    // XSQ_TRAIN_WGRAD_PACKED=1: the bf16 weight gradients on wgrad_bf16p_kernel (operands rounded once at staging time, k-pair-packed
+    // in LDS, one 16-byte fragment read per MFMA operand) -- an A/B arm, bitwise the default's gradients and measured SLOWER
+    // (0.30-0.34 ms per launch against 0.24, step 3.19 against 3.02 on one box: its 8-byte staging writes land 16 lanes on four
+    // banks and it holds four rows of loads per thread; profiles/r11_ab_runs.txt r11wg).  Default: round 5's kernel.
+    const char* wp_ = getenv("XSQ_TRAIN_WGRAD_PACKED");          // (read per step: tests/test_training.py flips it inside one process)
+    const bool wgrad_packed = wp_ && atoi(wp_) != 0;
     XSQ_HIP(fork(0));
     { XSQ_PROF("train_l4_wgrad", ws_);
-      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      if (bf16w && wgrad_packed) hipLaunchKernelGGL((wgrad_bf16p_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
+      else if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
       else hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{a3, gM, Tr->d_groups, d, 1, 0}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 4, gp); }
     CdaeArgs bw{Mo->d_blocks, Tr->d_pool_bwd, xin, g1, g2, g3, X, Y, nullptr, Bn, S, T1, T2, Tr->causal, 1, nullptr, nullptr};
@@ -1024,7 +1064,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)(nq1 / ((int64_t)(Bn * T1) * 13))), dim3(256), 0, stream, (const float4*)z3, (float4*)g3, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 2, stats, Tr->d_params); }
     XSQ_HIP(fork(1));
     { XSQ_PROF("train_l3_wgrad", ws_);
-      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      if (bf16w && wgrad_packed) hipLaunchKernelGGL((wgrad_bf16p_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
+      else if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
       else hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{a2, g3, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 3, gp); }
     bw.act1 = g3; bw.act2 = g2;                                                    // g_a2 <- g_z3   (layer-2 operator)
@@ -1034,7 +1075,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)(nq2 / ((int64_t)(Bn * T2) * 13))), dim3(256), 0, stream, (const float4*)z2, (float4*)g2, Tr->d_groups, Tr->d_frow2, Bn * T2, nq2, 1, stats, Tr->d_params); }
     XSQ_HIP(fork(2));
     { XSQ_PROF("train_l2_wgrad", ws_);
-      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      if (bf16w && wgrad_packed) hipLaunchKernelGGL((wgrad_bf16p_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
+      else if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL23Op, true>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
       else hipLaunchKernelGGL((wgrad_kernel<WgL23Op>), dim3(wt.n23), dim3(256), 0, ws_, WgL23Op{g2, a1, Tr->d_groups, d}, wt.d_t23, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce23, dim3(grid1(maxR23).x, G), dim3(256), 0, ws_, wpart, wt.d_i23, Tr->d_groups, 2, gp); }
     bw.act2 = g2; bw.act3 = g1;                                                    // g_a1 <- g_z2   (layer-3 operator)
@@ -1044,7 +1086,8 @@ int xsq_train_step(xsq_train* Tr, const float* X, const float* Yt, int Bn, int S
     { XSQ_PROF("train_bn_bwd_apply", stream); hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)(nq1 / ((int64_t)(Bn * T1) * 13))), dim3(256), 0, stream, (const float4*)z1, (float4*)g1, Tr->d_groups, Tr->d_frow1, Bn * T1, nq1, 0, stats, Tr->d_params); }
     XSQ_HIP(fork(3));
     { XSQ_PROF("train_l1_wgrad", ws_);
-      if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      if (bf16w && wgrad_packed) hipLaunchKernelGGL((wgrad_bf16p_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
+      else if (bf16w) hipLaunchKernelGGL((wgrad_kernel<WgL14Op, true>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
       else hipLaunchKernelGGL((wgrad_kernel<WgL14Op>), dim3(wt.n14), dim3(256), 0, ws_, WgL14Op{g1, xin, Tr->d_groups, d, 0, 1}, wt.d_t14, wpart);
       hipLaunchKernelGGL(k_wgrad_reduce14, dim3(grid1(maxW14).x, G), dim3(256), 0, ws_, wpart, wt.d_i14, Tr->d_groups, 1, gp); }
     bw.act3 = g1; bw.gx8 = gY;                                                     // g_xin (per target) <- g_z1   (layer-4 operator);

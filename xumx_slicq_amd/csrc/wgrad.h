@@ -137,4 +137,101 @@ __global__ __launch_bounds__(256) void wgrad_kernel(Op op, const WgTile* __restr
         }
 }
 
+// A/B ARM (XSQ_TRAIN_WGRAD_PACKED=1; bitwise the default's results, measured 25-35 % SLOWER per launch: profiles/r11_ab_runs.txt r11wg).
+// The bf16 arm with its K-step staged TRANSPOSED AND PACKED (round 6; DESIGN.md section 8 lead of round 5).  wgrad_kernel<Op, true>
+// reads every MFMA operand as eight 4-byte LDS words and converts them lane by lane: per K-step and wave 16 + 8 NBW ds_read_b32
+// and 4 (2 + NBW) conversions beside 2 NBW MFMAs of 32 cycles -- an LDS-instruction loop with some matrix work attached.  Here the
+// rounding to bf16 (the same v_cvt_pk_bf16_f32 of the same values: bitwise the same operands) happens ONCE, at staging time, and
+// LDS holds, per column and half K-step, the eight bf16 of rows 8 h .. 8 h + 7 as ONE 16-byte word: a fragment is one
+// ds_read_b128, 2 + NBW of them per K-step.  Staging: thread (quarter h2 = tid >> 6: rows 4 h2 .. 4 h2 + 3 of the K-step, column
+// quad cq = tid & 63) loads four consecutive rows' float4, packs the two row pairs of each of its four columns and writes four
+// 8-byte words; the operator walks its rows with an iterator (one (b, f, t) split per K-step, three increments) instead of a split
+// per row.
+template <class Op>
+__global__ __launch_bounds__(256) void wgrad_bf16p_kernel(Op op, const WgTile* __restrict__ tiles, float* __restrict__ partial) {
+    constexpr int NTL = Op::NTL, NB = NTL / 32, NBW = (NB + 3) / 4, NCQ = NTL / 4;
+    static_assert(NCQ <= 64, "one column quad per thread of a 64-thread staging quarter");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const WgTile t = tiles[blockIdx.x];
+    const typename Op::Group g = op.group(t.group);
+    __shared__ __attribute__((aligned(16))) unsigned Ap[2][2][64][4];        // [buffer][half K-step][column][row pair]
+    __shared__ __attribute__((aligned(16))) unsigned Bp[2][2][NTL][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int h2 = tid >> 6, cq = tid & 63;
+    const bool b_on = cq < NCQ, a_on = cq < 13, a_pad = cq >= 13 && cq < 16;       // A: 52 channels = 13 quads, 3 quads of zeros
+    const typename Op::Cols cols = op.cols(g, t.ntile, 4 * (b_on ? cq : 0));
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4], rb[4];
+    auto gload = [&](int kbase) {
+        const int k = kbase + 4 * h2;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        typename Op::RowIt it = op.row_it(g, k < t.k1 ? k : t.k0, t.ntile);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = k + j < t.k1;
+            ra[j] = (live && a_on) ? *reinterpret_cast<const float4*>(op.a_row(g, k + j) + 4 * cq) : z;
+            rb[j] = (live && b_on) ? op.load_b4(g, op.row_of(it), cols) : z;
+            if (j < 3) op.advance(g, it);
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int half = h2 >> 1, w0 = 2 * (h2 & 1);
+        const float va[4][4] = {{ra[0].x, ra[0].y, ra[0].z, ra[0].w}, {ra[1].x, ra[1].y, ra[1].z, ra[1].w},
+                                {ra[2].x, ra[2].y, ra[2].z, ra[2].w}, {ra[3].x, ra[3].y, ra[3].z, ra[3].w}};
+        const float vb[4][4] = {{rb[0].x, rb[0].y, rb[0].z, rb[0].w}, {rb[1].x, rb[1].y, rb[1].z, rb[1].w},
+                                {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, {rb[3].x, rb[3].y, rb[3].z, rb[3].w}};
+        if (a_on || a_pad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<uint2*>(&Ap[buf][half][4 * cq + c][w0]) = make_uint2(bf16_rne2(va[0][c], va[1][c]), bf16_rne2(va[2][c], va[3][c]));
+        }
+        if (b_on) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<uint2*>(&Bp[buf][half][4 * cq + c][w0]) = make_uint2(bf16_rne2(vb[0][c], vb[1][c]), bf16_rne2(vb[2][c], vb[3][c]));
+        }
+    };
+    gload(t.k0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    const int l32 = lane & 31, lk = lane >> 5;
+    for (int kb = t.k0; kb < t.k1; kb += 16) {
+        const bool more = kb + 16 < t.k1;
+        if (more) gload(kb + 16);
+        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][l32][0]));
+        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][32 + l32][0]));
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int nb = wave * NBW + j;
+            if (nb < NB) {          // wave-uniform
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Bp[buf][lk][nb * 32 + l32][0]));
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][j], 0, 0, 0);
+            }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = partial + (int64_t)blockIdx.x * 64 * NTL;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int nb = wave * NBW + j;
+            if (nb < NB) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[(int64_t)(i * 32 + acc_row(r) + 4 * lk) * NTL + nb * 32 + l32] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace xsq
