@@ -154,8 +154,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16p_kernel(Op op, const WgTile* _
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const WgTile t = tiles[blockIdx.x];
     const typename Op::Group g = op.group(t.group);
-    __shared__ __attribute__((aligned(16))) unsigned Ap[2][2][64][4];        // [buffer][half K-step][column][row pair]
-    __shared__ __attribute__((aligned(16))) unsigned Bp[2][2][NTL][4];
+    // [buffer][half K-step][slot of the column][row pair]; column n sits in slot (n & 3) * QP + (n >> 2): the four columns of a
+    // staging thread's quad land QP slots apart, consecutive quads in consecutive slots -- the 8-byte staging writes of a wave
+    // walk the banks instead of putting 16 lanes on four of them, and a fragment read's four column phases start 128 bytes apart
+    constexpr int QPA = 16 + 8, QPB = NCQ + 8;
+    __shared__ __attribute__((aligned(16))) unsigned Ap[2][2][4 * QPA][4];
+    __shared__ __attribute__((aligned(16))) unsigned Bp[2][2][4 * QPB][4];
+    auto slot_a = [&](int n) { return (n & 3) * QPA + (n >> 2); };
+    auto slot_b = [&](int n) { return (n & 3) * QPB + (n >> 2); };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int h2 = tid >> 6, cq = tid & 63;
     const bool b_on = cq < NCQ, a_on = cq < 13, a_pad = cq >= 13 && cq < 16;       // A: 52 channels = 13 quads, 3 quads of zeros
@@ -189,12 +195,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16p_kernel(Op op, const WgTile* _
         if (a_on || a_pad) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<uint2*>(&Ap[buf][half][4 * cq + c][w0]) = make_uint2(bf16_rne2(va[0][c], va[1][c]), bf16_rne2(va[2][c], va[3][c]));
+                *reinterpret_cast<uint2*>(&Ap[buf][half][c * QPA + cq][w0]) = make_uint2(bf16_rne2(va[0][c], va[1][c]), bf16_rne2(va[2][c], va[3][c]));
         }
         if (b_on) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<uint2*>(&Bp[buf][half][4 * cq + c][w0]) = make_uint2(bf16_rne2(vb[0][c], vb[1][c]), bf16_rne2(vb[2][c], vb[3][c]));
+                *reinterpret_cast<uint2*>(&Bp[buf][half][c * QPB + cq][w0]) = make_uint2(bf16_rne2(vb[0][c], vb[1][c]), bf16_rne2(vb[2][c], vb[3][c]));
         }
     };
     gload(t.k0);
@@ -205,13 +211,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16p_kernel(Op op, const WgTile* _
     for (int kb = t.k0; kb < t.k1; kb += 16) {
         const bool more = kb + 16 < t.k1;
         if (more) gload(kb + 16);
-        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][l32][0]));
-        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][32 + l32][0]));
+        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][slot_a(l32)][0]));
+        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Ap[buf][lk][slot_a(32 + l32)][0]));
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             const int nb = wave * NBW + j;
             if (nb < NB) {          // wave-uniform
-                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Bp[buf][lk][nb * 32 + l32][0]));
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(&Bp[buf][lk][slot_b(nb * 32 + l32)][0]));
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][j], 0, 0, 0);
             }
