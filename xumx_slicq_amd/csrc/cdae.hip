@@ -776,9 +776,16 @@ static int get_l1f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
 // tiles of the layer-4 F(2, 2) kernel (cdae_l4f.h): 64 consecutive output PAIRS of one batch item in the flattened (f, pair)
 // space x one column tile of <= 64 columns; one (block, target) after the other (the targets share nothing; the column tiles
 // of a row block share its operand rows, neighbouring row blocks share rows through the frequency taps)
-static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
+// taps = 0: the one-tap blocks (cdae_l4f_kernel); taps = 1: the multi-tap blocks, whose weight tiles of all taps fit the LDS of
+// cdae_l4f_taps_kernel (kf * 3 * 16 NCB rows <= L4_RES_ROWS) -- a launch of their own; multi-tap blocks that do not fit stay with
+// taps = 0 (one row tile per workgroup, weights re-staged per tap)
+static bool l4f_resident(const CdaeBlockDev& d) {
+    const int cols = l4f_cols(d.T);
+    return d.kf > 1 && cols <= 32 && d.kf * 3 * cols <= L4_RES_ROWS;
+}
+static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out, int taps = 0) {
     std::lock_guard<std::mutex> lk(Mo->mu);
-    auto key = std::make_tuple(4 + 160, Bn, S);
+    auto key = std::make_tuple(4 + 160 + 32 * taps, Bn, S);
     auto it = Mo->tiles.find(key);
     if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
     const int T1 = 2 * S - 1, P = S;
@@ -788,6 +795,10 @@ static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
     std::vector<L4fTileDev> t;
     for (int b : order) {
         const CdaeBlockDev& d = Mo->blocks[b];
+        // XSQ_L4F_RESIDENT=1 (A/B arm, off): the multi-tap blocks on cdae_l4f_taps_kernel, a launch of their own with all taps' weight
+        // tiles resident -- measured SLOWER (0.570-0.572 against 0.541-0.542 ms for the layer, profiles/r11_ab_runs.txt r11res)
+        static const bool res_on = getenv("XSQ_L4F_RESIDENT") && atoi(getenv("XSQ_L4F_RESIDENT")) != 0;
+        if ((l4f_resident(d) && res_on) != (taps != 0)) continue;
         const int W = d.T, cols = l4f_cols(W);
         const int64_t FST = (int64_t)d.F * S * d.T;
         L4fTileDev e;
@@ -797,7 +808,7 @@ static int get_l4f_tiles(xsq_model* Mo, int Bn, int S, TileTable* out) {
         // one tap: a workgroup keeps its column tile's weights in LDS for a run of consecutive row tiles (cdae_l4f.h); runs of
         // equal length, at most l4f_run row tiles
         static const int l4f_run = getenv("XSQ_L4F_RUN") ? std::max(1, atoi(getenv("XSQ_L4F_RUN"))) : 6;
-        const int nruns = d.kf == 1 ? (rtiles + l4f_run - 1) / l4f_run : rtiles;
+        const int nruns = (d.kf == 1 || taps) ? (rtiles + l4f_run - 1) / l4f_run : rtiles;
         for (int tgt = 0; tgt < NT; ++tgt) {
             e.in_off = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);
             e.out_off = (int64_t)Bn * 8 * S * d.cum + (int64_t)tgt * Bn * 2 * FST;
@@ -1166,9 +1177,17 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
                         "xsq_cdae_forward: B=%d S=%d overflows the 32-bit offsets of a block's coefficients; split the batch", a.Bn, a.S);
         int rcf = get_l4f_tiles(Mo, a.Bn, a.S, &tt);
         if (rcf) return rcf;
+        TileTable t2;
+        if ((rcf = get_l4f_tiles(Mo, a.Bn, a.S, &t2, 1))) return rcf;
         XSQ_PROF(prof_name ? prof_name : "cdae_l4_gemm", stream);
-        if (a.Y) hipLaunchKernelGGL(cdae_l4f_kernel<true>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
-        else hipLaunchKernelGGL(cdae_l4f_kernel<false>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
+        if (t2.ntiles) {           // the multi-tap blocks first (the longest tiles of the layer)
+            if (a.Y) hipLaunchKernelGGL(cdae_l4f_taps_kernel<true>, dim3(t2.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)t2.d_tiles, t2.ntiles);
+            else hipLaunchKernelGGL(cdae_l4f_taps_kernel<false>, dim3(t2.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)t2.d_tiles, t2.ntiles);
+        }
+        if (tt.ntiles) {
+            if (a.Y) hipLaunchKernelGGL(cdae_l4f_kernel<true>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
+            else hipLaunchKernelGGL(cdae_l4f_kernel<false>, dim3(tt.ntiles), dim3(256), 0, stream, a, (const L4fTileDev*)tt.d_tiles, tt.ntiles);
+        }
         return XSQ_OK;
     }
     const bool n16 = !bf3 && !bf6 && layer == 4 && !a.raw && !a.xin8 && !a.gx8 && !(variant & 256);      // fp32 inference: 16-column granularity

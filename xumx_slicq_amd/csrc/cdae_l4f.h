@@ -65,7 +65,7 @@ struct L4fTileDev {                // 64 bytes: one scalar load
 };
 static_assert(sizeof(L4fTileDev) == 64, "L4fTileDev is meant to be one 64-byte scalar load");
 
-template <int NCB, bool WITH_Y>
+template <int NCB, bool WITH_Y, bool RES = false>
 __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDev& t, float* const Bs) {
 #pragma clang fp contract(off)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,6 +78,9 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
 
     // ---- weight tiles of a tap -> LDS.  Global: [component][column < 16 NCB][52 k] = 39 x 16 NCB float4; float4 x -> LDS row
     // component * 64 + column, words 4 (x % 13) ..
+    // RES (the multi-tap launch, column tiles of <= 32 columns): the weight tiles of ALL taps stay in LDS, compact -- rows
+    // (tap * 3 + component) * 16 NCB + column; otherwise one tap, rows component * 64 + column
+    constexpr int JS = RES ? 16 * NCB : 64, TAPW = 3 * JS * L4_BLD;
     constexpr int NB4 = 3 * 16 * NCB * (CS / 4);
     constexpr int NLD = (NB4 + 255) / 256;
     const int tapf = l4f_tap_floats(W);
@@ -87,7 +90,7 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     for (int r = 0; r < NLD; ++r) {
         const int x = tid + 256 * r, row = x / (CS / 4), k4 = x - row * (CS / 4);
         const int j = row / (16 * NCB), col = row - j * (16 * NCB);
-        b_lds[r] = x < NB4 ? (j * 64 + col) * L4_BLD + 4 * k4 : -1;
+        b_lds[r] = x < NB4 ? (j * JS + col) * L4_BLD + 4 * k4 : -1;
     }
     float4 gb[NLD];
     auto load_b = [&](int df) {
@@ -95,11 +98,11 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
 #pragma unroll
         for (int r = 0; r < NLD; ++r) gb[r] = buf_ld4(ru, (r < NLD - 1 || tid + 256 * r < NB4) ? 16u * (unsigned)(tid + 256 * r) : BUF_OOB, 4 * df * tapf);
     };
-    auto store_b = [&]() {
+    auto store_b = [&](int tap = 0) {
         if (XSQ_L4F_ABL & 4) return;
 #pragma unroll
         for (int r = 0; r < NLD; ++r)
-            if (r < NLD - 1 || b_lds[r] >= 0) *reinterpret_cast<float4*>(&Bs[b_lds[r]]) = gb[r];
+            if (r < NLD - 1 || b_lds[r] >= 0) *reinterpret_cast<float4*>(&Bs[tap * TAPW + b_lds[r]]) = gb[r];
     };
 
     // ---- a lane's pair of row tile `it` of the run: pair Qg of the flattened (b, f, pair) space
@@ -165,11 +168,12 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
     // `refill`: chunk s of the NEXT operand set (`nx`: the next row tile of the run, or the next tap) is requested into the
     // registers of chunk s as soon as that chunk has been transformed -- one operand set in registers instead of two (a second
     // set in flight cost 39 registers: 58 spilled in the 64-column body); the request is a whole row tile ahead of its use.
-    auto contract = [&](Ops& o, const Addr& nx, bool refill) {
+    auto contract = [&](Ops& o, const Addr& nx, bool refill, int tap = 0) {
+        const float* const Bt = Bs + tap * TAPW;
         float4 w[2][NCB];
         auto read_w = [&](int g, float4 (&dst)[NCB]) {
             const int s = g / 3, j = g - 3 * s;
-            const float* Bj = Bs + j * 64 * L4_BLD + bf + 16 * s;
+            const float* Bj = Bt + j * JS * L4_BLD + bf + 16 * s;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) dst[cb] = *reinterpret_cast<const float4*>(&Bj[cb * 16 * L4_BLD]);
         };
@@ -202,7 +206,7 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
         if (refill) load_chunk_a(o, nx, 3);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float* Bj = Bs + j * 64 * L4_BLD + bf - 4 * kq + 48 + kq;      // channel 48 + kq of column q
+            const float* Bj = Bt + j * JS * L4_BLD + bf - 4 * kq + 48 + kq;      // channel 48 + kq of column q
             float wt[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) wt[cb] = Bj[cb * 16 * L4_BLD];
@@ -281,6 +285,28 @@ __device__ __forceinline__ void cdae_l4f_body(const CdaeArgs& a, const L4fTileDe
         }
     };
 
+    if constexpr (RES) {
+        // the multi-tap blocks on a launch of their own (64.5 KB of LDS: two workgroups per CU, which the one-tap tiles do not want:
+        // r11z): all kf taps' weight tiles resident for the workgroup's run of row tiles -- no barrier and no weight traffic
+        // inside the run; the operand set is refilled in place for the next (row tile, tap)
+        Ops o;
+        Pair pr = pair_of(0);
+        for (int df = 0; df < kf; ++df) { load_b(df); store_b(df); }
+        load_a(o, addr_of(pr, 0));
+        __syncthreads();
+        for (int it = 0; it < run; ++it) {
+            const bool more = it + 1 < run;
+            const Pair nxp = pair_of(more ? it + 1 : it);
+            clear_acc();
+            for (int df = 0; df < kf; ++df) {
+                const bool last = df + 1 == kf;
+                contract(o, last ? addr_of(nxp, 0) : addr_of(pr, df + 1), !last || more, df);
+            }
+            epilogue(pr);
+            pr = nxp;
+        }
+        return;
+    }
     if (kf == 1) {
         // ONE frequency tap (67 of the 70 Bark-262 blocks): the column tile's weights go into LDS once and STAY for the run of
         // `run` consecutive row tiles this workgroup owns; the next row tile's operands are requested chunk by chunk into the
@@ -339,6 +365,19 @@ __global__ __launch_bounds__(256, XSQ_L4F_WAVES_PER_EU) void cdae_l4f_kernel(Cda
     else if (rem == 48) cdae_l4f_body<3, WITH_Y>(a, t, Bs);
     else if (rem == 32) cdae_l4f_body<2, WITH_Y>(a, t, Bs);
     else cdae_l4f_body<1, WITH_Y>(a, t, Bs);
+}
+
+// the multi-tap blocks' launch (column tiles of <= 32 columns, all taps resident: up to 3 taps x 96 rows or 5 taps x 48 rows of 56 words)
+constexpr int L4_RES_ROWS = 288;
+template <bool WITH_Y>
+__global__ __launch_bounds__(256, 2) void cdae_l4f_taps_kernel(CdaeArgs a, const L4fTileDev* __restrict__ tiles, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float Bs[L4_RES_ROWS * L4_BLD];
+    const L4fTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
+    asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.F), "s"(t.run), "s"(t.in_off), "s"(t.out_off), "s"(t.bias_off), "s"(t.u_off),
+                 "s"(t.hop), "s"(t.n0), "s"(t.P), "s"(t.x_off));
+    const int rem = l4f_cols(2 * t.hop) - t.n0;                  // (workgroup-uniform; <= 32 by construction of the tile table)
+    if (rem == 32) cdae_l4f_body<2, WITH_Y, true>(a, t, Bs);
+    else cdae_l4f_body<1, WITH_Y, true>(a, t, Bs);
 }
 
 }  // namespace xsq
