@@ -180,7 +180,7 @@ int xsq_model_destroy(xsq_model* model);
  *      product, one fp32 rounding -- measured as close to the torch-cpu reference as mode 0
  *      (1.1e-7 RMS), 6/16 of the matrix-pipe time.                                              */
 int xsq_model_set_precision(xsq_model* model, int mode);
-/* Fast-convolution forms of the fp32 inference layers, a bit mask (default 3 = both):
+/* Fast-convolution forms of the fp32 inference layers, a bit mask (default 7 = bits 1, 2 and 4):
  *   1  layers 2 / 3 (the 4-tap time convolutions of model.py:140-170), rows of >= 127 time positions: Winograd F(2, 4) along
  *      the time taps (csrc/cdae_wino.h: five MFMA products per output pair and channel pair instead of eight; input transform
  *      with integer coefficients in registers, weights transformed on the host in fp64; ~2e-7 RMS of a layer's output against
@@ -188,7 +188,13 @@ int xsq_model_set_precision(xsq_model* model, int mode);
  *   2  layer 1 (model.py:130-139, non-causal): F(2, 2) along the hop (csrc/cdae_l1f.h: the strided (kf, W) convolution is a
  *      two-tap convolution in units of the hop -- three half-window products per output pair instead of four, W0 + W1 summed
  *      on the host in fp64).  Without the bit: the implicit GEMM (CdaeL1Op).
- * The split-bf16 modes, the causal first layer and (bit 1) shorter rows always take the direct kernels.                  */
+ *   4  layer 4 (model.py:171-181, non-causal): F(2, 2) along the hop the same way (csrc/cdae_l4f.h), masks only or with the
+ *      estimates materialised.  Without the bit: the implicit GEMM (CdaeL4Op).
+ *   8  (with bit 1) layers 2 / 3, rows of >= 253 time positions: Winograd F(4, 4) (csrc/cdae_wino4.h: seven products per
+ *      output quad instead of ten).  An A/B arm, off by default: parity-green and measured 8-10 % slower than F(2, 4) on
+ *      MI355X.  Its weights are built only into models created with XSQ_WINO4=1 in the environment; the bit is an error on
+ *      any other model.
+ * The split-bf16 modes, the causal first layer and (bits 1, 8) shorter rows always take the direct kernels.              */
 int xsq_model_set_winograd(xsq_model* model, int on);
 size_t xsq_cdae_workspace(const xsq_model* model, int B, int S);          /* 0 on error */
 /*   X      mix coefficients, arena for 2*B channels (B, 2, ...)

@@ -910,6 +910,37 @@ def test_evaluation_harness_scores_with_the_real_separator(seps, oracle_plan, se
             assert np.isfinite(res["scores"][name]) and abs(res["scores"][name] - s_ref) < 1e-3, (name, res["scores"][name], s_ref)
 
 
+def test_winograd_f44_arm_matches_the_f24_kernels(seps, monkeypatch):
+    """Layers 2 / 3 as Winograd F(4, 4) (csrc/cdae_wino4.h, bit 8 of xsq_model_set_winograd: an A/B arm, off by default -- built,
+    parity-green and measured 8-10 % slower than F(2, 4)) against the default F(2, 4) kernels, which the
+    test below holds to the oracle (model.py:140-170).  n = 1,250,000 samples: S = 140 slices, T1 = 279 (not a multiple of
+    four: phantom outputs in the last quad of every row), T2 = 276, 70 / 69 quads per row -- every 64-quad tile straddles two
+    (b, f) rows --, two samples per batch, blocks with 1, 3 and 5 frequency taps.  Bars: 3e-7 RMS / 5e-6 max between the two
+    forms (measured 7e-8 / 7e-7 at the bench's size).  The arm's weights exist only in a model created with XSQ_WINO4=1."""
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.separator import seeded_separator
+    with pytest.raises(_lib.XsqError):
+        try:
+            seps["offline_phasemix"].xumx_model.set_winograd(15)
+            seps["offline_phasemix"](synth_audio(70000, seed=1).cuda())      # (the handle is built on first use)
+        finally:
+            seps["offline_phasemix"].xumx_model.set_winograd(True)
+    monkeypatch.setenv("XSQ_WINO4", "1")
+    sep = seeded_separator(realtime=False, wiener=False)
+    x = synth_audio(1_250_000, seed=78, nb_samples=2).cuda()
+    f24 = sep(x).cpu()
+    sep.xumx_model.set_winograd(15)
+    f44 = sep(x).cpu()
+    again = sep(x).cpu()
+    assert torch.equal(f44, again)                                   # deterministic
+    assert not torch.equal(f44, f24)                                 # ... and really another kernel
+    d = (f44 - f24).double()
+    rms, mx = float(d.pow(2).mean().sqrt()), float(d.abs().max())
+    print(f"F(4, 4) vs F(2, 4): rms {rms:.2e} max {mx:.2e}")
+    assert rms < 3e-7 and mx < 5e-6, (rms, mx)
+    assert float(f24.abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("name,wiener", [("offline_phasemix", False), ("offline_wiener", True)])
 def test_winograd_layers_match_the_direct_kernels_and_the_oracle(seps, oracle_plan, seeded_sd, name, wiener):
     """Layers 2 / 3 as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h, the fp32 default for rows of >= 127

@@ -2,6 +2,7 @@
 step time, and the stems' distance between the arms.  python3 tools/ab_wino_mask.py 1 3 [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("XSQ_WINO4", "1")      # build the F(4, 4) weights with the model (bit 8 of the mask; csrc/cdae_wino4.h)
 import torch
 from xumx_slicq_amd import _lib
 from xumx_slicq_amd.separator import seeded_separator

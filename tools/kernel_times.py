@@ -1,6 +1,7 @@
 """Per-kernel ms/step of the bench step (fp32), for diagnostic library builds (XSQ_LIB=...)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("XSQ_WINO4", "1")      # build the F(4, 4) weights with the model (bit 8 of the mask; csrc/cdae_wino4.h)
 import torch
 from xumx_slicq_amd import _lib
 from xumx_slicq_amd.separator import seeded_separator
@@ -8,6 +9,8 @@ from xumx_slicq_amd.synth import synth_audio
 dev = torch.device("cuda", 0)
 sep = seeded_separator(realtime=False, wiener=False, device=dev)
 sep.xumx_model.set_precision(os.environ.get("PREC", "fp32"))
+if os.environ.get("WINO_MASK"):     # xsq_model_set_winograd bit mask (default 7; 15 = F(4, 4) for layers 2 / 3)
+    sep.xumx_model.set_winograd(int(os.environ["WINO_MASK"]))
 if os.environ.get("NO_TAIL"):       # four full chunks, one stacked pass, nothing on the side stream: clean per-kernel times
     sep.overlap_tail = False
     x = synth_audio(4 * 2_621_440, seed=20260101).to(dev)

@@ -584,6 +584,7 @@ struct CdaeL4Op {
 }  // namespace xsq
 #include "cdae_slab.h"
 #include "cdae_wino.h"
+#include "cdae_wino4.h"
 #include "cdae_l1f.h"
 #include "cdae_l4f.h"
 namespace xsq {
@@ -593,6 +594,10 @@ namespace xsq {
 // ------------------------------------------------------------------------------------------
 }  // namespace xsq
 namespace xsq {
+
+// F(4, 4) weights of layers 2 / 3 (cdae_wino4.h: an A/B arm, off by default) are built with a model only when XSQ_WINO4=1 is set at
+// xsq_model_create -- 7 / 5 of the F(2, 4) pool on top, and their share of the fp64 transform at load time
+static bool wino4_wanted() { return getenv("XSQ_WINO4") && atoi(getenv("XSQ_WINO4")) != 0; }
 
 static const int L23_MT = 1;     // 256-row tiles (MT = 2) measured slower: 192 VGPR -> 2 waves per SIMD (L3 1.51 -> 1.74 ms)
 
@@ -723,6 +728,45 @@ static int get_wino_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* ou
             e.pad0 = e.pad1 = 0;
             for (int bi = 0; bi < Bn; ++bi)
                 for (int Q = 0; Q < perb; Q += WN_PAIRS) {
+                    e.Q0 = Q; e.b = bi;
+                    t.push_back(e);
+                }
+        }
+    }
+    TileTable tt;                    // (d_tiles holds WinoTileDev entries for this key: cast at the launch site)
+    tt.ntiles = (int)t.size();
+    XSQ_HIP(hipMalloc((void**)&tt.d_tiles, t.size() * sizeof(WinoTileDev)));
+    XSQ_HIP(hipMemcpy(tt.d_tiles, t.data(), t.size() * sizeof(WinoTileDev), hipMemcpyHostToDevice));
+    Mo->tiles[key] = tt;
+    *out = tt;
+    return XSQ_OK;
+}
+
+// tiles of the F(4, 4) kernels (cdae_wino4.h): 64 consecutive output QUADS of one batch item in the flattened (f, quad) space
+static int get_wino4_tiles(xsq_model* Mo, int layer, int Bn, int S, TileTable* out) {
+    std::lock_guard<std::mutex> lk(Mo->mu);
+    auto key = std::make_tuple(layer + 192, Bn, S);
+    auto it = Mo->tiles.find(key);
+    if (it != Mo->tiles.end()) { *out = it->second; return XSQ_OK; }
+    const int T1 = Mo->causal ? 2 * S : 2 * S - 1, T2 = T1 - 3;
+    std::vector<int> order(Mo->nblocks);
+    for (int b = 0; b < Mo->nblocks; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Mo->blocks[x].kf > Mo->blocks[y].kf; });
+    std::vector<WinoTileDev> t;
+    const int To = layer == 2 ? T2 : T1, P = (To + 3) / 4;
+    for (int b : order) {
+        const CdaeBlockDev& d = Mo->blocks[b];
+        for (int tgt = 0; tgt < NT; ++tgt) {
+            const int64_t off1 = (int64_t)CS * Bn * T1 * (4 * (int64_t)d.cumF1 + (int64_t)tgt * d.F1);   // act1 / act3 of the (block, target)
+            const int64_t off2 = (int64_t)CS * Bn * T2 * (4 * (int64_t)d.cumF2 + (int64_t)tgt * d.F2);   // act2
+            WinoTileDev e;
+            e.kf = d.kf; e.P = P;
+            if (layer == 2) { e.Fo = d.F2; e.Fi = d.F1; e.in_off = off1; e.out_off = off2; e.shift_off = d.s2[tgt]; e.u_off = d.uq2[tgt]; }
+            else { e.Fo = d.F1; e.Fi = d.F2; e.in_off = off2; e.out_off = off1; e.shift_off = d.s3[tgt]; e.u_off = d.uq3[tgt]; }
+            const int perb = e.Fo * P;
+            e.pad0 = e.pad1 = 0;
+            for (int bi = 0; bi < Bn; ++bi)
+                for (int Q = 0; Q < perb; Q += W4_QUADS) {
                     e.Q0 = Q; e.b = bi;
                     t.push_back(e);
                 }
@@ -881,6 +925,7 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
     xsq_model* Mo = new xsq_model();
     *partial = Mo;
     Mo->causal = causal ? 1 : 0; Mo->nblocks = nblocks; Mo->sumFT = PL.sumFT; Mo->table = PL.blocks;
+    Mo->wino4 = wino4_wanted();
     const double eps = 1e-5;
     std::vector<float> pool, upool, mean, scale;
     std::vector<int64_t> cum(P->nblocks + 1, 0);
@@ -983,6 +1028,24 @@ static int model_build(xsq_model** out, int nblocks, const int32_t* F, const int
                                 upool[u + (size_t)df * WN_UDF + wino_u_off(j, col, ci)] = (float)acc;
                             }
             }
+            // ---- Winograd F(4, 4) along the time taps (cdae_wino4.h), the same way: seven components
+            for (int layer = 2; layer <= 3; ++layer) {
+                (layer == 2 ? d.uq2[t] : d.uq3[t]) = -1;
+                if (!Mo->wino4) continue;
+                const int64_t wsrc = layer == 2 ? d.w2[t] : d.w3[t];
+                const int64_t u = (int64_t)upool.size();
+                upool.resize(upool.size() + (size_t)kf * W4_UDF, 0.f);
+                (layer == 2 ? d.uq2[t] : d.uq3[t]) = u;
+                for (int df = 0; df < kf; ++df)
+                    for (int j = 0; j < W4_NC; ++j)
+                        for (int col = 0; col < WN_COLS; ++col)
+                            for (int ci = 0; ci < CS; ++ci) {
+                                double acc = 0.0;
+                                for (int dt = 0; dt < 4; ++dt)
+                                    acc += W4_G[j][dt] * (double)pool[wsrc + (size_t)col * K2 + (df * 4 + dt) * CS + ci];
+                                upool[u + (size_t)df * W4_UDF + wino4_u_off(j, col, ci)] = (float)acc;
+                            }
+            }
             // ---- L4: ConvTranspose2d weight (50,2,kf,W) = (in,out,kH,kW); bias(2)
             //      k = (df*2 + (1 - tap))*52 + c3 (tap 1 first: CdaeL4Op) ;  n = c*hop + dtlo ;  kernel column = dtlo + tap*hop
             w = p; p += (size_t)H1 * 2 * kf * W;
@@ -1057,8 +1120,18 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
     return XSQ_OK;
 }
 
+#if XSQ_WINO4_STAMPS
+extern "C" int xsq_debug_w4_stamps(unsigned long long* out, int reset) {     // diagnostic builds only (cdae_wino4.h)
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(xsq::g_w4_stamps), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; XSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(xsq::g_w4_stamps), z, sizeof(z))); }
+    return XSQ_OK;
+}
+#endif
+
 int xsq_model_set_winograd(xsq_model* Mo, int on) {
-    XSQ_REQUIRE(Mo && on >= 0 && on <= 7, "xsq_model_set_winograd: null model or mask %d (1 = layers 2 / 3 Winograd F(2, 4), 2 / 4 = layer 1 / 4 F(2, 2))", on);
+    XSQ_REQUIRE(Mo && on >= 0 && on <= 15, "xsq_model_set_winograd: null model or mask %d (1 = layers 2 / 3 Winograd F(2, 4), 2 / 4 = layer 1 / 4 F(2, 2), 8 = F(4, 4) for long rows)", on);
+    XSQ_REQUIRE(!(on & 8) || Mo->wino4, "xsq_model_set_winograd: bit 8 (F(4, 4)) needs a model created with XSQ_WINO4=1 in the environment");
     Mo->winograd = on;
     return XSQ_OK;
 }
@@ -1129,6 +1202,15 @@ int cdae_launch_layer(xsq_model* Mo, int layer, const CdaeArgs& a, hipStream_t s
         // fp32: Winograd F(2, 4) along the four time taps (cdae_wino.h) -- 5 instead of 8 MFMA products per output pair;
         // rows of >= 64 pairs, i.e. To >= 127.  xsq_model_set_winograd(0) / XSQ_CDAE_VARIANT=2048: the direct slab kernels.
         if (!bf3 && !bf6 && a.upool && (Mo->winograd & 1) && !(variant & 2048) && ((layer == 2 ? a.T2 : a.T1) + 1) / 2 >= WN_PAIRS) {
+            // bit 8: F(4, 4) (cdae_wino4.h) -- 7 products per output quad instead of 10; rows of >= 64 quads, i.e. To >= 253
+            if ((Mo->winograd & 8) && Mo->wino4 && ((layer == 2 ? a.T2 : a.T1) + 3) / 4 >= W4_QUADS) {
+                int rcq = get_wino4_tiles(Mo, layer, a.Bn, a.S, &tt);
+                if (rcq) return rcq;
+                XSQ_PROF(prof_name ? prof_name : (layer == 2 ? "cdae_l2_slab" : "cdae_l3_slab"), stream);
+                if (layer == 2) hipLaunchKernelGGL((cdae_wino4_kernel<false>), dim3(tt.ntiles), dim3(512), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
+                else hipLaunchKernelGGL((cdae_wino4_kernel<true>), dim3(tt.ntiles), dim3(512), 0, stream, a, (const WinoTileDev*)tt.d_tiles, tt.ntiles);
+                return XSQ_OK;
+            }
             // XSQ_WINO_MIN_KF (A/B): blocks with fewer frequency taps stay on the direct kernel (their tiles are short: a
             // prologue per 64 pairs and tap), the Winograd kernel takes the rest
             static const int min_kf = getenv("XSQ_WINO_MIN_KF") ? atoi(getenv("XSQ_WINO_MIN_KF")) : 0;

@@ -25,6 +25,7 @@ struct CdaeBlockDev {
     int64_t u1[NT];                           // F(2, 2)-along-the-hop weights of layer 1 (W0 | W0 + W1 | W1 per chunk of 16 k; cdae_l1f.h: nch1 x LF_U16 floats)
     int nch1, pad_;                           // chunks of 16 k of that form: l1f_chunks(kf, hop)
     int64_t u4[NT];                           // F(2, 2)-along-the-hop weights of layer 4 (Wb | Wa + Wb | Wa per frequency tap and column tile; cdae_l4f.h)
+    int64_t uq2[NT], uq3[NT];                 // Winograd F(4, 4) transformed weights of layers 2 / 3 (cdae_wino4.h: kf x W4_UDF floats), -1: not built
 };
 
 }  // namespace xsq
@@ -33,8 +34,9 @@ struct xsq_model {
     int causal = 0;
     int precision = 0;             // 0 fp32 MFMA, 1 split-bf16 MFMA (xsq_model_set_precision)
     int winograd = 7;              // fast-convolution forms of the fp32 inference layers (xsq_model_set_winograd), a bit mask: 1 = layers 2 / 3 as Winograd
-                                   // F(2, 4) along the time taps (cdae_wino.h), 2 / 4 = layer 1 / layer 4 as F(2, 2) along the hop (cdae_l1f.h, cdae_l4f.h);
-                                   // 0 = the direct kernels
+                                   // F(2, 4) along the time taps (cdae_wino.h), 2 / 4 = layer 1 / layer 4 as F(2, 2) along the hop (cdae_l1f.h, cdae_l4f.h),
+                                   // 8 = layers 2 / 3 as F(4, 4) where the rows are long enough (cdae_wino4.h; needs bit 1); 0 = the direct kernels
+    bool wino4 = false;            // the F(4, 4) weights of layers 2 / 3 exist (XSQ_WINO4=1 at xsq_model_create; cdae_wino4.h)
     int nblocks = 0;
     int64_t sumFT = 0;             // complex coefficients per channel-slice
     std::vector<xsq::BlockHost> table;

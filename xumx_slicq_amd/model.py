@@ -342,7 +342,8 @@ class Unmix(nn.Module):
     def set_winograd(self, on):
         """Fast-convolution forms of the fp32 inference layers.  True (default) = all of them, False = the direct kernels, an int =
         a bit mask: 1 = layers 2 / 3 of long rows as Winograd F(2, 4) along the four time taps (csrc/cdae_wino.h), 2 / 4 = layer 1 /
-        layer 4 as F(2, 2) along the hop (csrc/cdae_l1f.h, csrc/cdae_l4f.h).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
+        layer 4 as F(2, 2) along the hop (csrc/cdae_l1f.h, csrc/cdae_l4f.h), 8 = layers 2 / 3 of rows >= 253 as F(4, 4) (csrc/cdae_wino4.h: an A/B
+        arm, measured slower; needs a model created with XSQ_WINO4=1).  Same result to fp32 rounding (~2e-7 of a layer's output)."""
         self.winograd = (7 if on else 0) if isinstance(on, bool) else int(on)
         for _ver, h in self._handles.values():
             _lib.check(_lib.lib.xsq_model_set_winograd(h, self.winograd), "xsq_model_set_winograd")
