@@ -1120,6 +1120,14 @@ int xsq_model_set_precision(xsq_model* Mo, int mode) {
     return XSQ_OK;
 }
 
+#if XSQ_WINO_STAMPS
+extern "C" int xsq_debug_wn_stamps(unsigned long long* out, int reset) {     // diagnostic builds only (cdae_wino.h)
+    XSQ_HIP(hipDeviceSynchronize());
+    XSQ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(xsq::g_wn_stamps), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; XSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(xsq::g_wn_stamps), z, sizeof(z))); }
+    return XSQ_OK;
+}
+#endif
 #if XSQ_WINO4_STAMPS
 extern "C" int xsq_debug_w4_stamps(unsigned long long* out, int reset) {     // diagnostic builds only (cdae_wino4.h)
     XSQ_HIP(hipDeviceSynchronize());

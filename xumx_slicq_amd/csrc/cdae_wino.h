@@ -60,6 +60,19 @@
 
 namespace xsq {
 
+#ifndef XSQ_WINO_STAMPS
+#define XSQ_WINO_STAMPS 0    // diagnostic build: thread 0 of every workgroup adds its phase times (s_memrealtime ticks of 10 ns) to g_wn_stamps:
+                             // 0 prologue, 1 chunk loop, 2 epilogue, 3 tiles, 4 of the loop: thread 0 waiting at its barriers (tools/w4_stamps.py)
+#endif
+#if XSQ_WINO_STAMPS
+__device__ unsigned long long g_wn_stamps[8];
+#define WN_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_wn_stamps[i], now_ - wn_t0); wn_t0 = now_; } } while (0)
+#define WN_SUB(i, expr) do { const unsigned long long a_ = wall_clock64(); expr; if (tid == 0) atomicAdd(&g_wn_stamps[i], wall_clock64() - a_); } while (0)
+#else
+#define WN_STAMP(i) do { } while (0)
+#define WN_SUB(i, expr) do { expr; } while (0)
+#endif
+
 constexpr int WN_PAIRS = 64;                              // output pairs per tile (4 waves x 16)
 constexpr int WN_MAXSEG = 2;                              // (b, f) rows a tile may touch (needs P >= WN_PAIRS)
 constexpr int WN_EROWS = WN_PAIRS + 2 * WN_MAXSEG;        // even-plane rows: pairs + 2 per segment
@@ -117,6 +130,9 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     const WinoTileDev t = tiles[xcd_remap(blockIdx.x, ntiles)];
     asm volatile("" :: "s"(t.Q0), "s"(t.kf), "s"(t.Fo), "s"(t.Fi), "s"(t.in_off), "s"(t.out_off), "s"(t.shift_off), "s"(t.u_off),
                  "s"(t.b), "s"(t.P));
+#if XSQ_WINO_STAMPS
+    unsigned long long wn_t0 = wall_clock64();
+#endif
     const int kf = t.kf, Fo = t.Fo, Fi = t.Fi, P = t.P, b = t.b;
     const int To = TRANSPOSED ? a.T1 : a.T2, Ti = TRANSPOSED ? a.T2 : a.T1;
     const float* in = (TRANSPOSED ? a.act2 : a.act1) + t.in_off;
@@ -242,6 +258,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
     store_slab();
     store_chunk(0, 0);
     __syncthreads();
+    WN_STAMP(0);
 
     {
         const int myseg = pl >= n0 ? 1 : 0;
@@ -330,13 +347,14 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                 if (s < 2) store_chunk(s + 1, cur ^ 1);
                 else if (more) store_chunk(0, cur ^ 1);
                 cnt += 1;
-                __syncthreads();
+                WN_SUB(4, __syncthreads());
             }
             if (more) {                  // every wave is past the barrier behind the slab's last reader
                 store_slab();
-                __syncthreads();
+                WN_SUB(4, __syncthreads());
             }
         }
+        WN_STAMP(1);
 
         // ---- epilogue: output transform, shift + ReLU, through a per-wave LDS image (the planes are free: the
         // loop ended on a barrier), out as 16-byte stores.  Image row 2 p + r = output r of the wave's pair p.
@@ -386,6 +404,10 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                     (ok0 && kq == 0) ? vt48 + 192u : BUF_OOB, 0);
             buf_st4(make_float4(fmaxf(y1v[0] + sh.x, 0.f), fmaxf(y1v[1] + sh.y, 0.f), fmaxf(y1v[2] + sh.z, 0.f), fmaxf(y1v[3] + sh.w, 0.f)), ro,
                     (ok1 && kq == 0) ? vt48 + 192u + 4u * CS : BUF_OOB, 0);
+            WN_STAMP(2);
+#if XSQ_WINO_STAMPS
+            if (tid == 0) atomicAdd(&g_wn_stamps[3], 1ull);
+#endif
             return;
         }
         float* img = slab + wave * 32 * CS;
