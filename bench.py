@@ -729,6 +729,11 @@ def bench_track(args, sep, dev, world, rank, dist):
             variants.update(variant_precisions(args, sep, step, out))
         if not args.wiener:
             variants["wiener"] = variant_wiener(args, dev, track, plan, my_items)
+        if not args.wiener and args.precision == "fp32":
+            try:
+                variants["winograd_f44"] = variant_winograd_f44(args, dev, track, out)
+            except Exception as e:                       # noqa: BLE001 -- an A/B arm must not cost the headline line
+                variants["winograd_f44"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         variants["train_step"] = variant_train_step(args, sep, dev)
         variants["train_step_bf16"] = variant_train_step(args, sep, dev, precision="bf16")
         if not args.wiener:
@@ -843,6 +848,38 @@ def variant_precisions(args, sep, step, out):
         del vout, d
     sep.xumx_model.set_precision("fp32")
     return variants
+
+
+def variant_winograd_f44(args, dev, track, out):
+    """A/B arm: layers 2 / 3 as Winograd F(4, 4) (csrc/cdae_wino4.h, bit 8 of xsq_model_set_winograd; its weights exist only in a
+    model created with XSQ_WINO4=1) against the default F(2, 4): the same track, the stems' distance to the headline stems."""
+    import contextlib
+    import torch
+    from xumx_slicq_amd import _lib
+    from xumx_slicq_amd.separator import seeded_separator
+    os.environ["XSQ_WINO4"] = "1"
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            sep4 = seeded_separator(realtime=False, wiener=False, device=dev, chunk_size=CHUNK)
+        sep4.xumx_model.set_winograd(15)
+        o4 = sep4(track)                                  # (the model handle is created here, with the variable still set)
+    finally:
+        os.environ.pop("XSQ_WINO4", None)                 # (the line's `env` block describes the headline run)
+    for _ in range(max(1, args.warmup)):
+        o4 = sep4(track)
+    _lib.profile_enable(True); _lib.profile_reset()
+    sep4.overlap_tail = False
+    sep4(track)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read(); _lib.profile_enable(False)
+    sep4.overlap_tail = True
+    dt, enq, o4 = _timed_loop(lambda: sep4(track), args.steps)
+    d = (o4 - out).double()
+    return {"what": "A/B arm, off by default: CDAE layers 2 / 3 as Winograd F(4, 4) along the time taps (7 MFMA products per output quad instead "
+                    "of 10; one 512-thread workgroup per CU) instead of F(2, 4); everything else unchanged",
+            "value": round(TRACK_SAMPLES / FS / dt, 2), "unit": "x real-time", "ms_per_step": round(dt * 1e3, 3),
+            "kernels_ms": {k: round(v[0], 4) for k, v in prof.items() if k in ("cdae_l2_slab", "cdae_l3_slab")},
+            "stems_vs_default": {"rms": float(d.pow(2).mean().sqrt()), "max_abs": float(d.abs().max())}}
 
 
 def variant_wiener(args, dev, track, plan, my_items):
