@@ -54,6 +54,10 @@
                             // operand (XSQ_WINO_SWAP) mask 0 measured 0.841-0.843 / 0.859-0.863 ms against 0.889-0.908 / 0.878-0.891 for the
                             // round-5 form; either change alone: nothing (profiles/r11_ab_runs.txt r11r, r11t)
 #endif
+#ifndef XSQ_WINO_SCHED2
+#define XSQ_WINO_SCHED2 -1  // >= 0: ... and one behind the NEXT component's fragment reads, which pins them in front of this component's MFMAs (the
+                            // compiler otherwise sinks them to the last MFMA of the group and waits one MFMA later); A/B r11s2
+#endif
 #ifndef XSQ_WINO_ABL
 #define XSQ_WINO_ABL 0      // diagnostic builds (wrong results, timings only): 2 no vector columns, 4 no weight stream, 8 no slab loads, 16 no epilogue stores, 32 no input transform
 #endif
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256, XSQ_WINO_WAVES_PER_EU) void cdae_wino_kernel(C
                 for (int j = 0; j < 5; ++j) {
                     const Frag& f = fr[j & 1];
                     if (j < 4) read_frag(fr[(j + 1) & 1], Bc + (j + 1) * WN_BTILE, s == 2);
+                    if (XSQ_WINO_SCHED2 >= 0) __builtin_amdgcn_sched_barrier(XSQ_WINO_SCHED2);
                     const float wa[4] = {f.w[0].x, f.w[0].y, f.w[0].z, f.w[0].w}, wb[4] = {f.w[1].x, f.w[1].y, f.w[1].z, f.w[1].w};
                     const float wc[4] = {f.w[2].x, f.w[2].y, f.w[2].z, f.w[2].w};
 #pragma unroll
