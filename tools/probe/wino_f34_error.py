@@ -16,10 +16,9 @@ def cook_toom(m, r, pts):
         M = [[p ** j for j in range(k)] for p in pts]
         M.append([Fr(0)] * (k - 1) + [Fr(1)])
         return M
-    # linear convolution via Toom-Cook: s = V^-1 [(Vg g) * (Vd d)], then the transposition principle turns it into the FIR filter:
-    # y = Vd^T-part... use the standard construction: AT = ev(m)^T, G = ev(r) scaled, BT = (V^-1)^T with V = ev(n)
+    # Toom-Cook for the linear convolution s = V^-1 [(ev(r) g) * (ev(m) d)], transposed into the FIR filter (the transposition
+    # principle): AT = ev(m)^T, G = ev(r), BT = (V^-1)^T with V = ev(n)
     V = ev(n)
-    # scale: N_i = prod_{j != i} (p_i - p_j) for finite points
     Vinv = inv_frac(V)
     AT = [[ev(m)[i][j] for i in range(n)] for j in range(m)]
     G = ev(r)
@@ -66,7 +65,6 @@ def check(m, pts, trials=3, C=52, kf=3, N=4096, seed=0):
     for _ in range(trials):
         w = (rng.standard_normal((kf * C, r)) * (1.0 / np.sqrt(kf * C * r))).astype(np.float32)
         d = np.maximum(rng.standard_normal((N, kf * C, n)), 0).astype(np.float32)
-        ref = np.einsum("ckt,nck->nk", np.stack([w[:, None, :].repeat(m, 1)[:, k, :] for k in range(m)], 1)[:, :, :].astype(np.float64) * 0, np.zeros((N, kf * C, m))) if False else None
         y64 = np.zeros((N, m))
         for k in range(m):
             y64[:, k] = np.einsum("ct,nct->n", w.astype(np.float64), d[:, :, k:k + r].astype(np.float64))
